@@ -1,0 +1,156 @@
+"""Python mirror of the reference interface (htscodecs/rANS_static4x16.h:41-50) on top of the
+C ABI, plus the batch calls.  Same names and argument meaning as the C functions; errors come
+back as ``None`` exactly where the C functions return NULL."""
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+
+
+def rans_compress_bound_4x16(size, order):
+    return _lib.load().rans_compress_bound_4x16(size, order)
+
+
+def rans_compress_4x16(data, order):
+    """bytes -> compressed bytes, or None (C: NULL).  rANS_static4x16pr.c:1347."""
+    L = _lib.load()
+    src = np.frombuffer(bytes(data), dtype=np.uint8)
+    cap = L.rans_compress_bound_4x16(len(src), order)
+    out = np.empty(cap, dtype=np.uint8)
+    n = C.c_uint(cap)
+    r = L.rans_compress_to_4x16(src.ctypes.data if len(src) else out.ctypes.data, len(src),
+                                out.ctypes.data, C.byref(n), order)
+    return out[:n.value].tobytes() if r else None
+
+
+def rans_uncompress_4x16(comp, out_size=None):
+    """compressed bytes -> bytes, or None.  out_size: capacity of the caller buffer (needed for
+    X_NOSZ streams, rANS_static4x16pr.c:1456)."""
+    L = _lib.load()
+    src = np.frombuffer(bytes(comp), dtype=np.uint8)
+    if out_size is None:
+        n = C.c_uint(0)
+        p = L.rans_uncompress_4x16(src.ctypes.data, len(src), C.byref(n))
+        if not p:
+            return None
+        res = C.string_at(p, n.value)
+        C.CDLL(None).free(C.c_void_p(p))
+        return res
+    out = np.empty(out_size + 1, dtype=np.uint8)
+    n = C.c_uint(out_size)
+    r = L.rans_uncompress_to_4x16(src.ctypes.data, len(src), out.ctypes.data, C.byref(n))
+    return out[:n.value].tobytes() if r else None
+
+
+class _Ctx:
+    def __init__(self, device=-1):
+        self.L = _lib.load()
+        self.h = self.L.rans4x16_hip_create(device)
+        if not self.h:
+            raise RuntimeError("rans4x16_hip_create failed: no usable HIP device (no CPU path exists)")
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.L.rans4x16_hip_destroy(self.h)
+        except Exception:
+            pass
+
+    def error(self):
+        return self.L.rans4x16_hip_last_error(self.h).decode()
+
+
+def _host_batch(blocks, decode, orders=None, caps=None):
+    ctx = _Ctx()
+    L = ctx.L
+    n = len(blocks)
+    srcs = [np.frombuffer(bytes(b), dtype=np.uint8) for b in blocks]
+    if decode:
+        capv = list(caps)
+    else:
+        capv = [L.rans_compress_bound_4x16(len(s), o) for s, o in zip(srcs, orders)]
+    outs = [np.empty(max(c, 1), dtype=np.uint8) for c in capv]
+    dummy = np.zeros(1, dtype=np.uint8)
+    in_p = (C.c_void_p * n)(*[(s.ctypes.data if len(s) else dummy.ctypes.data) for s in srcs])
+    out_p = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    in_sz = (C.c_uint * n)(*[len(s) for s in srcs])
+    out_sz = (C.c_uint * n)(*capv)
+    status = (C.c_int * n)()
+    if decode:
+        rc = L.rans4x16_hip_uncompress_batch(ctx.h, n, in_p, in_sz, out_p, out_sz, status)
+    else:
+        ords = (C.c_int * n)(*orders)
+        rc = L.rans4x16_hip_compress_batch(ctx.h, n, in_p, in_sz, out_p, out_sz, ords, status)
+    if rc < 0:
+        raise RuntimeError("batch call failed: " + ctx.error())
+    res = [outs[i][:out_sz[i]].tobytes() if status[i] == 0 else None for i in range(n)]
+    return res, list(status)
+
+
+def compress_batch(blocks, orders):
+    """list of bytes, list of int -> (list of bytes|None, list of status)."""
+    return _host_batch(blocks, False, orders=orders)
+
+
+def uncompress_batch(blocks, caps):
+    """list of compressed bytes, list of output capacities -> (list of bytes|None, statuses)."""
+    return _host_batch(blocks, True, caps=caps)
+
+
+class DeviceCodec:
+    """Device-resident batches on torch tensors (torch is used for device memory and streams
+    only).  All tensors must live on the context's device."""
+
+    def __init__(self, device_index=0):
+        import torch
+        self.torch = torch
+        self.dev = torch.device("cuda", device_index)
+        with torch.cuda.device(self.dev):
+            self.ctx = _Ctx(device_index)
+        self.L = self.ctx.L
+
+    def timing(self, enable=True):
+        self.L.rans4x16_hip_timing(self.ctx.h, 1 if enable else 0)
+
+    def timing_read(self, which, reset=True):
+        ms = C.c_double(0)
+        k = C.c_int(0)
+        rc = self.L.rans4x16_hip_timing_read(self.ctx.h, which, C.byref(ms), C.byref(k), 1 if reset else 0)
+        if rc != 0:
+            raise RuntimeError("timing_read failed")
+        return ms.value, k.value
+
+    def workspace_bytes(self):
+        return self.L.rans4x16_hip_workspace_bytes(self.ctx.h)
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def compress(self, d_in, in_off, in_size, d_out, out_off, out_cap, out_size, status, order,
+                 max_in_size, d_order=None):
+        t = self.torch
+        assert d_in.dtype == t.uint8 and d_out.dtype == t.uint8
+        assert in_off.dtype == t.int64 and out_off.dtype == t.int64
+        assert in_size.dtype == t.int32 and out_cap.dtype == t.int32
+        assert out_size.dtype == t.int32 and status.dtype == t.int32
+        n = in_off.numel()
+        rc = self.L.rans4x16_hip_compress_dev(
+            self.ctx.h, n, d_in.data_ptr(), in_off.data_ptr(), in_size.data_ptr(),
+            d_out.data_ptr(), out_off.data_ptr(), out_cap.data_ptr(), out_size.data_ptr(),
+            status.data_ptr(), int(order), d_order.data_ptr() if d_order is not None else None,
+            int(max_in_size), self._stream())
+        if rc != 0:
+            raise RuntimeError("compress_dev: " + self.ctx.error())
+
+    def uncompress(self, d_in, in_off, in_size, d_out, out_off, out_cap, out_size, status,
+                   max_in_size, max_out_cap):
+        t = self.torch
+        assert d_in.dtype == t.uint8 and d_out.dtype == t.uint8
+        n = in_off.numel()
+        rc = self.L.rans4x16_hip_uncompress_dev(
+            self.ctx.h, n, d_in.data_ptr(), in_off.data_ptr(), in_size.data_ptr(),
+            d_out.data_ptr(), out_off.data_ptr(), out_cap.data_ptr(), out_size.data_ptr(),
+            status.data_ptr(), int(max_in_size), int(max_out_cap), self._stream())
+        if rc != 0:
+            raise RuntimeError("uncompress_dev: " + self.ctx.error())

@@ -1,0 +1,450 @@
+// r4x16_api.hip — host side of librans4x16_hip.so (include/rans4x16_hip.h).
+//
+// Host code is orchestration only: argument checks, workspace, staging copies, kernel launches.
+// Every byte of codec work (histograms, tables, rANS, transforms) runs in the HIP kernels of
+// r4x16_encode.hip / r4x16_decode.hip; there is no CPU code path to fall back to.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+#include <string>
+#include <vector>
+#include <mutex>
+
+#include "../../include/rans4x16_hip.h"
+#include "r4x16_dev.h"
+
+extern "C" {
+void r4x16_launch_dec_front(const BatchArgs *, const DecWs *, int, int, hipStream_t);
+void r4x16_launch_dec_chain(const DecWs *, int, int, u32, hipStream_t);
+void r4x16_launch_dec_back(const BatchArgs *, const DecWs *, int, int, hipStream_t);
+void r4x16_launch_enc_front(const BatchArgs *, const EncWs *, int, int, hipStream_t);
+void r4x16_launch_enc_chain(const EncWs *, int, int, hipStream_t);
+void r4x16_launch_enc_finish(const BatchArgs *, const EncWs *, int, int, hipStream_t);
+u32  r4x16_compress_bound(u32 size, int order);
+}
+
+struct TimedLaunch { hipEvent_t a, b; };
+
+struct rans4x16_hip_ctx {
+    int device = 0;
+    std::string err;
+    // one growing device workspace
+    u8 *ws = nullptr;
+    size_t ws_bytes = 0;
+    double *logtab = nullptr;
+    // staging for the host-buffer entry points
+    u8 *stage = nullptr;
+    size_t stage_bytes = 0;
+    // timing hook
+    int timing = 0;
+    std::vector<TimedLaunch> timed[2];
+    size_t max_ws = (size_t)48 << 30;       // cap for one chunk of blocks
+};
+
+#define HIPCHK(ctx, call)                                                                   \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                 \
+            return -1;                                                                      \
+        }                                                                                   \
+    } while (0)
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" const char *rans4x16_hip_version(void) { return "rans4x16_hip 0.1 (gfx950)"; }
+
+extern "C" rans4x16_hip_ctx *rans4x16_hip_create(int device)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        static std::once_flag once;
+        std::call_once(once, [] { fprintf(stderr, "rans4x16_hip: no HIP device available; this library has no CPU path\n"); });
+        return nullptr;
+    }
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return nullptr; }
+    if (device >= ndev) return nullptr;
+    rans4x16_hip_ctx *c = new rans4x16_hip_ctx();
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete c; return nullptr; }
+    // log(1024+k), log(4096+k) from the host libm: the same values the reference's compute_shift
+    // obtains at rANS_static4x16pr.c:651-652 on this machine.
+    double tab[2 * 257];
+    for (int k = 0; k <= 256; k++) { tab[k] = log((double)(1024 + k)); tab[257 + k] = log((double)(4096 + k)); }
+    if (hipMalloc((void **)&c->logtab, sizeof(tab)) != hipSuccess ||
+        hipMemcpy(c->logtab, tab, sizeof(tab), hipMemcpyHostToDevice) != hipSuccess) {
+        fprintf(stderr, "rans4x16_hip: cannot allocate on device %d\n", device);
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+extern "C" void rans4x16_hip_destroy(rans4x16_hip_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (int w = 0; w < 2; w++)
+        for (auto &t : c->timed[w]) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    if (c->ws) (void)hipFree(c->ws);
+    if (c->stage) (void)hipFree(c->stage);
+    if (c->logtab) (void)hipFree(c->logtab);
+    delete c;
+}
+
+extern "C" const char *rans4x16_hip_last_error(const rans4x16_hip_ctx *c) { return c ? c->err.c_str() : "no context"; }
+extern "C" size_t rans4x16_hip_workspace_bytes(const rans4x16_hip_ctx *c) { return c ? c->ws_bytes : 0; }
+
+extern "C" void rans4x16_hip_timing(rans4x16_hip_ctx *c, int enable) { if (c) c->timing = enable; }
+
+extern "C" int rans4x16_hip_timing_read(rans4x16_hip_ctx *c, int which, double *ms_total, int *launches, int reset)
+{
+    if (!c || which < 0 || which > 1) return -1;
+    double tot = 0;
+    int n = 0;
+    for (auto &t : c->timed[which]) {
+        float ms = 0;
+        if (hipEventSynchronize(t.b) != hipSuccess) return -1;
+        if (hipEventElapsedTime(&ms, t.a, t.b) != hipSuccess) return -1;
+        tot += ms;
+        n++;
+    }
+    if (ms_total) *ms_total = tot;
+    if (launches) *launches = n;
+    if (reset) {
+        for (auto &t : c->timed[which]) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+        c->timed[which].clear();
+    }
+    return 0;
+}
+
+static int ensure_ws(rans4x16_hip_ctx *c, size_t bytes)
+{
+    if (bytes <= c->ws_bytes) return 0;
+    if (c->ws) { HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, hipFree(c->ws)); c->ws = nullptr; c->ws_bytes = 0; }
+    HIPCHK(c, hipMalloc((void **)&c->ws, bytes));
+    c->ws_bytes = bytes;
+    return 0;
+}
+
+// carve helper
+struct Carver {
+    u8 *p; size_t off = 0;
+    explicit Carver(u8 *base) : p(base) {}
+    template <class T> T *take(size_t count, size_t elem = sizeof(T)) {
+        off = align_up(off, 256);
+        T *r = (T *)(p ? p + off : nullptr);
+        off += count * elem;
+        return r;
+    }
+};
+
+static void time_begin(rans4x16_hip_ctx *c, int which, hipStream_t s, TimedLaunch &t)
+{
+    (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b);
+    (void)hipEventRecord(t.a, s);
+    (void)which;
+}
+static void time_end(rans4x16_hip_ctx *c, int which, hipStream_t s, TimedLaunch &t)
+{
+    (void)hipEventRecord(t.b, s);
+    c->timed[which].push_back(t);
+}
+
+// ---------------------------------------------------------------------------------------------
+// device-resident batches
+// ---------------------------------------------------------------------------------------------
+static size_t enc_ws_layout(u8 *base, size_t nblk, u64 scratch_stride, EncWs *w)
+{
+    Carver cv(base);
+    w->desc = cv.take<EncDesc>(nblk);
+    w->items = cv.take<EncItem>(2 * nblk);
+    w->images = cv.take<u8>(nblk, ENC_IMG_BYTES);
+    w->tabraw = cv.take<u8>(nblk, TAB_BYTES);
+    w->tab = cv.take<u8>(nblk, TAB_BYTES);
+    w->scratch = cv.take<u8>(nblk, scratch_stride);
+    w->F = cv.take<u32>(nblk * 65536);
+    w->scratch_stride = scratch_stride;
+    return align_up(cv.off, 256);
+}
+
+extern "C" int rans4x16_hip_compress_dev(rans4x16_hip_ctx *c, int n,
+                                         const unsigned char *d_in, const uint64_t *d_in_off,
+                                         const uint32_t *d_in_size,
+                                         unsigned char *d_out, const uint64_t *d_out_off,
+                                         const uint32_t *d_out_cap, uint32_t *d_out_size,
+                                         int32_t *d_status, int order, const int32_t *d_order,
+                                         uint32_t max_in_size, void *stream)
+{
+    if (!c) return -1;
+    if (n < 0 || (n && (!d_in || !d_in_off || !d_in_size || !d_out || !d_out_off || !d_out_cap || !d_out_size || !d_status))) {
+        c->err = "compress_dev: bad arguments";
+        return -1;
+    }
+    if (n == 0) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+
+    // backward-write area per block: the order-1 bound of the largest block (covers the nested
+    // table coder and the RLE meta stream as well)
+    const u64 scratch_stride = align_up((size_t)r4x16_compress_bound(max_in_size, 0xc1) + 64, 256);
+    EncWs w;
+    const size_t per_blk = enc_ws_layout(nullptr, 1, scratch_stride, &w) + 4096;
+    size_t chunk = c->max_ws / per_blk;
+    if (chunk < 1) chunk = 1;
+    if (chunk > (size_t)n) chunk = (size_t)n;
+    const size_t need = enc_ws_layout(nullptr, chunk, scratch_stride, &w);
+    if (ensure_ws(c, need) != 0) return -1;
+    enc_ws_layout(c->ws, chunk, scratch_stride, &w);
+    w.logtab = c->logtab;
+
+    BatchArgs a;
+    a.in = d_in; a.in_off = d_in_off; a.in_size = d_in_size;
+    a.out = d_out; a.out_off = d_out_off; a.out_cap = d_out_cap; a.out_size = d_out_size;
+    a.status = d_status; a.d_order = d_order; a.order = order; a.n = n;
+
+    for (size_t base = 0; base < (size_t)n; base += chunk) {
+        const int nb = (int)((size_t)n - base < chunk ? (size_t)n - base : chunk);
+        r4x16_launch_enc_front(&a, &w, (int)base, nb, s);
+        TimedLaunch t;
+        if (c->timing) time_begin(c, 0, s, t);
+        r4x16_launch_enc_chain(&w, 2 * nb, 16, s);
+        if (c->timing) time_end(c, 0, s, t);
+        r4x16_launch_enc_finish(&a, &w, (int)base, nb, s);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+static size_t dec_ws_layout(u8 *base, size_t nblk, u64 tmp_stride, u64 meta_stride, DecWs *w)
+{
+    Carver cv(base);
+    w->desc = cv.take<DecDesc>(nblk);
+    w->items = cv.take<DecItem>(2 * nblk);
+    w->images = cv.take<u8>(nblk, (size_t)DEC_IMG_SLOT);
+    w->tbuf = cv.take<u8>(nblk, TBUF_BYTES);
+    w->tmp = cv.take<u8>(nblk, tmp_stride);
+    w->meta = cv.take<u8>(nblk, meta_stride);
+    w->tmp_stride = tmp_stride;
+    w->meta_stride = meta_stride;
+    return align_up(cv.off, 256);
+}
+
+extern "C" int rans4x16_hip_uncompress_dev(rans4x16_hip_ctx *c, int n,
+                                           const unsigned char *d_in, const uint64_t *d_in_off,
+                                           const uint32_t *d_in_size,
+                                           unsigned char *d_out, const uint64_t *d_out_off,
+                                           const uint32_t *d_out_cap, uint32_t *d_out_size,
+                                           int32_t *d_status, uint32_t max_in_size, uint32_t max_out_cap,
+                                           void *stream)
+{
+    if (!c) return -1;
+    if (n < 0 || (n && (!d_in || !d_in_off || !d_in_size || !d_out || !d_out_off || !d_out_cap || !d_out_size || !d_status))) {
+        c->err = "uncompress_dev: bad arguments";
+        return -1;
+    }
+    if (n == 0) return 0;
+    (void)max_in_size;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+
+    const u64 tmp_stride = 0, meta_stride = 0;      // PACK / RLE staging: milestone 2
+    (void)max_out_cap;
+    DecWs w;
+    const size_t per_blk = dec_ws_layout(nullptr, 1, tmp_stride, meta_stride, &w) + 4096;
+    size_t chunk = c->max_ws / per_blk;
+    if (chunk < 1) chunk = 1;
+    if (chunk > (size_t)n) chunk = (size_t)n;
+    const size_t need = dec_ws_layout(nullptr, chunk, tmp_stride, meta_stride, &w);
+    if (ensure_ws(c, need) != 0) return -1;
+    dec_ws_layout(c->ws, chunk, tmp_stride, meta_stride, &w);
+
+    BatchArgs a;
+    a.in = d_in; a.in_off = d_in_off; a.in_size = d_in_size;
+    a.out = d_out; a.out_off = d_out_off; a.out_cap = d_out_cap; a.out_size = d_out_size;
+    a.status = d_status; a.d_order = nullptr; a.order = 0; a.n = n;
+
+    for (size_t base = 0; base < (size_t)n; base += chunk) {
+        const int nb = (int)((size_t)n - base < chunk ? (size_t)n - base : chunk);
+        r4x16_launch_dec_front(&a, &w, (int)base, nb, s);
+        TimedLaunch t;
+        if (c->timing) time_begin(c, 1, s, t);
+        r4x16_launch_dec_chain(&w, 2 * nb, 16, 0, s);
+        if (c->timing) time_end(c, 1, s, t);
+        r4x16_launch_dec_back(&a, &w, (int)base, nb, s);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-buffer batches: stage through one device arena, run the *_dev path, copy results back.
+// ---------------------------------------------------------------------------------------------
+static int ensure_stage(rans4x16_hip_ctx *c, size_t bytes)
+{
+    if (bytes <= c->stage_bytes) return 0;
+    if (c->stage) { HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, hipFree(c->stage)); c->stage = nullptr; c->stage_bytes = 0; }
+    HIPCHK(c, hipMalloc((void **)&c->stage, bytes));
+    c->stage_bytes = bytes;
+    return 0;
+}
+
+static int run_host_batch(rans4x16_hip_ctx *c, int n, bool decode,
+                          const unsigned char *const *in, const unsigned int *in_size,
+                          unsigned char *const *out, unsigned int *out_size, const int *order, int *status)
+{
+    if (!c) return -1;
+    if (n <= 0) return n == 0 ? 0 : -1;
+    HIPCHK(c, hipSetDevice(c->device));
+
+    // arena: [in blocks][out slots][offset/size/status arrays]
+    std::vector<u64> in_off(n), out_off(n);
+    std::vector<u32> cap(n);
+    std::vector<i32> ord(n);
+    size_t in_tot = 0, out_tot = 0;
+    u32 max_in = 0, max_cap = 0;
+    for (int i = 0; i < n; i++) {
+        in_off[i] = in_tot; in_tot += align_up((size_t)in_size[i] + 16, 256);
+        cap[i] = out_size[i];
+        out_off[i] = out_tot; out_tot += align_up((size_t)cap[i] + 16, 256);
+        if (in_size[i] > max_in) max_in = in_size[i];
+        if (cap[i] > max_cap) max_cap = cap[i];
+        ord[i] = order ? order[i] : 0;
+    }
+    const size_t arr = align_up((size_t)n * 8, 256);
+    const size_t total = in_tot + out_tot + 6 * arr;
+    if (ensure_stage(c, total) != 0) return -1;
+    u8 *d_in = c->stage, *d_out = d_in + in_tot, *meta = d_out + out_tot;
+    u64 *d_in_off = (u64 *)meta, *d_out_off = (u64 *)(meta + arr);
+    u32 *d_in_size = (u32 *)(meta + 2 * arr), *d_cap = (u32 *)(meta + 3 * arr), *d_osz = (u32 *)(meta + 4 * arr);
+    i32 *d_status = (i32 *)(meta + 5 * arr);
+    i32 *d_order = (i32 *)(meta + 5 * arr + arr / 2);
+
+    for (int i = 0; i < n; i++)
+        if (in_size[i]) HIPCHK(c, hipMemcpyAsync(d_in + in_off[i], in[i], in_size[i], hipMemcpyHostToDevice, 0));
+    HIPCHK(c, hipMemcpyAsync(d_in_off, in_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, 0));
+    HIPCHK(c, hipMemcpyAsync(d_out_off, out_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, 0));
+    HIPCHK(c, hipMemcpyAsync(d_in_size, in_size, (size_t)n * 4, hipMemcpyHostToDevice, 0));
+    HIPCHK(c, hipMemcpyAsync(d_cap, cap.data(), (size_t)n * 4, hipMemcpyHostToDevice, 0));
+    HIPCHK(c, hipMemcpyAsync(d_order, ord.data(), (size_t)n * 4, hipMemcpyHostToDevice, 0));
+
+    int rc;
+    if (decode)
+        rc = rans4x16_hip_uncompress_dev(c, n, d_in, d_in_off, d_in_size, d_out, d_out_off, d_cap, d_osz,
+                                         d_status, max_in, max_cap, nullptr);
+    else
+        rc = rans4x16_hip_compress_dev(c, n, d_in, d_in_off, d_in_size, d_out, d_out_off, d_cap, d_osz,
+                                       d_status, 0, d_order, max_in, nullptr);
+    if (rc != 0) return -1;
+
+    std::vector<u32> osz(n);
+    std::vector<i32> st(n);
+    HIPCHK(c, hipMemcpy(osz.data(), d_osz, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(st.data(), d_status, (size_t)n * 4, hipMemcpyDeviceToHost));
+    int failed = 0;
+    for (int i = 0; i < n; i++) {
+        if (status) status[i] = st[i];
+        if (st[i] != 0) { out_size[i] = 0; failed++; continue; }
+        out_size[i] = osz[i];
+        if (osz[i]) HIPCHK(c, hipMemcpyAsync(out[i], d_out + out_off[i], osz[i], hipMemcpyDeviceToHost, 0));
+    }
+    HIPCHK(c, hipStreamSynchronize(0));
+    return failed;
+}
+
+extern "C" int rans4x16_hip_compress_batch(rans4x16_hip_ctx *c, int n,
+                                           const unsigned char *const *in, const unsigned int *in_size,
+                                           unsigned char *const *out, unsigned int *out_size,
+                                           const int *order, int *status)
+{
+    return run_host_batch(c, n, false, in, in_size, out, out_size, order, status);
+}
+
+extern "C" int rans4x16_hip_uncompress_batch(rans4x16_hip_ctx *c, int n,
+                                             const unsigned char *const *in, const unsigned int *in_size,
+                                             unsigned char *const *out, unsigned int *out_size, int *status)
+{
+    return run_host_batch(c, n, true, in, in_size, out, out_size, nullptr, status);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The five htscodecs entry points (htscodecs/rANS_static4x16.h:41-50).
+// ---------------------------------------------------------------------------------------------
+static rans4x16_hip_ctx *thread_ctx()
+{
+    // one context per host thread: the reference API is re-entrant from thread pools
+    struct Holder { rans4x16_hip_ctx *c = nullptr; ~Holder() { rans4x16_hip_destroy(c); } };
+    static thread_local Holder h;
+    if (!h.c) h.c = rans4x16_hip_create(-1);
+    return h.c;
+}
+
+extern "C" unsigned int rans_compress_bound_4x16(unsigned int size, int order)
+{
+    return r4x16_compress_bound(size, order);
+}
+
+extern "C" unsigned char *rans_compress_to_4x16(unsigned char *in, unsigned int in_size,
+                                                unsigned char *out, unsigned int *out_size, int order)
+{
+    rans4x16_hip_ctx *c = thread_ctx();
+    if (!c || !out_size) return nullptr;
+    unsigned char *mine = nullptr;
+    if (!out) {
+        *out_size = rans_compress_bound_4x16(in_size, order);
+        if (!(out = mine = (unsigned char *)malloc(*out_size))) return nullptr;
+    }
+    const unsigned char *ins[1] = { in };
+    unsigned char *outs[1] = { out };
+    unsigned int isz[1] = { in_size };
+    int ord[1] = { order };
+    if (run_host_batch(c, 1, false, ins, isz, outs, out_size, ord, nullptr) != 0) { free(mine); return nullptr; }
+    return out;
+}
+
+extern "C" unsigned char *rans_compress_4x16(unsigned char *in, unsigned int in_size,
+                                             unsigned int *out_size, int order)
+{
+    return rans_compress_to_4x16(in, in_size, nullptr, out_size, order);
+}
+
+// uncompressed size stored in the container header (host read of <= 6 bytes; needed to size the
+// malloc the reference API promises when out == NULL, rANS_static4x16pr.c:1459-1462)
+static int peek_size(const unsigned char *in, unsigned int in_size, unsigned int *usz)
+{
+    if (in_size < 1 || (in[0] & X_NOSZ)) return -1;
+    unsigned int v = 0, i = 1;
+    unsigned char ch;
+    if (i >= in_size) { *usz = 0; return 0; }
+    do { ch = in[i++]; v = (v << 7) | (ch & 0x7f); } while ((ch & 0x80) && i < in_size);
+    *usz = v;
+    return 0;
+}
+
+extern "C" unsigned char *rans_uncompress_to_4x16(unsigned char *in, unsigned int in_size,
+                                                  unsigned char *out, unsigned int *out_size)
+{
+    rans4x16_hip_ctx *c = thread_ctx();
+    if (!c || !out_size || in_size == 0) return nullptr;
+    unsigned char *mine = nullptr;
+    if (!out) {
+        unsigned int usz;
+        if (peek_size(in, in_size, &usz) != 0) return nullptr;       // X_NOSZ needs a caller buffer (:1456)
+        if (usz >= INT_MAX) return nullptr;
+        if (!(out = mine = (unsigned char *)malloc(usz ? usz : 1))) return nullptr;
+        *out_size = usz;
+    }
+    const unsigned char *ins[1] = { in };
+    unsigned char *outs[1] = { out };
+    unsigned int isz[1] = { in_size };
+    if (run_host_batch(c, 1, true, ins, isz, outs, out_size, nullptr, nullptr) != 0) { free(mine); return nullptr; }
+    return out;
+}
+
+extern "C" unsigned char *rans_uncompress_4x16(unsigned char *in, unsigned int in_size, unsigned int *out_size)
+{
+    return rans_uncompress_to_4x16(in, in_size, nullptr, out_size);
+}

@@ -1,0 +1,175 @@
+// r4x16_common.h — definitions shared by the host shim and the gfx950 kernels.
+//
+// Vocabulary (follows the reference / CRAM, not ML):
+//   block  : one independent CRAM EXTERNAL block = one call of rans_(un)compress_to_4x16
+//   stream : a bare O0stream / O1stream — table, 4 states, 16-bit words
+//   chain  : one of the 4 interleaved rANS states of a stream; a *quad* (4 adjacent lanes of a
+//            wave64) runs the 4 chains of one stream in lock-step, up to 16 streams per wave
+//   item   : one stream scheduled on the chain kernel (a block's payload, or its RLE meta)
+//   image  : the decode / encode lookup tables of one item in the layout the chain kernel reads
+#pragma once
+#include <stdint.h>
+
+typedef uint8_t  u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t  i32;
+
+// container flag bits, rANS_static4x16pr.c:38-43
+#define X_ORDER  0x01
+#define X_STRIPE 0x08
+#define X_NOSZ   0x10
+#define X_CAT    0x20
+#define X_RLE    0x40
+#define X_PACK   0x80
+
+#define RANS_LOW (1u << 15)   // rANS_word.h:63
+#define O0_BITS  12           // rANS_static4x16pr.c:81
+
+// status codes mirror include/rans4x16_hip.h
+#define ST_OK 0
+#define ST_CAPACITY 1
+#define ST_TRUNCATED 2
+#define ST_TABLE 3
+#define ST_STATE 4
+#define ST_SIZE 5
+#define ST_UNSUPPORTED 6
+#define ST_CONTEXT 7
+#define ST_RLE 8
+#define ST_EMPTY 9
+
+// ---------------------------------------------------------------------------------------------
+// Decode image (per item).  A sequence of rows, each 16-byte aligned, one per context
+// (order-0: a single row).  Row layout, all little-endian:
+//
+//   +0              u32 hdr      : byte value of this context | ROW_EMPTY flag | nnz << 16
+//   +4              u8  coarse[C]: C = 1 << (look-2); coarse[c] = index r of the entry that owns
+//                                  slot 4*c
+//   +4+C            u32 ent[nnz+4]: ent[r] = start_r | (link_r << 16) for the nnz symbols with a
+//                                  non-zero frequency, in symbol order; then a terminal entry
+//                                  with start = 1 << bits, then three pads with start 0xFFFF.
+//                                  link = (offset of that symbol's own row) / 16 for order-1,
+//                                       = the symbol's byte value for order-0.
+//
+// Lookup of slot m (m < 1<<look): r = coarse[m>>2]; r += #(k in 1..3 : m >= start[r+k]);
+// start = start[r], freq = start[r+1] - start[r].  Four slots hold at most four symbols, so
+// three comparisons always suffice.  This gives the same answers as the reference's 4096- or
+// 1024-entry reverse tables (rANS_static4x16pr.c:538-549, :985-995) in about a third of the
+// bytes — which is what limits how many streams a CU can keep in its 160 KB LDS — and the
+// link field removes the context->row multiply from the dependent chain.
+// ---------------------------------------------------------------------------------------------
+#define ROW_EMPTY 0x100u      // hdr flag: context has no table row (T == 0): using it is an error
+static inline __host__ __device__ u32 img_cells(u32 look) { return 1u << (look - 2); }
+static inline __host__ __device__ u32 img_row_bytes(u32 nnz, u32 look)
+{
+    return (4u + img_cells(look) + 4u * (nnz + 4u) + 15u) & ~15u;
+}
+#define IMG_O0_BYTES  2080u                       // one 12-bit row, 256 symbols
+#define IMG_MAX_BYTES (256u * 2080u)              // 256 rows, 12-bit, 256 symbols each
+
+// One stream for the chain decoder.  80 bytes.
+struct DecItem {
+    u64 words;       // device address of the first 16-bit word (just after the 4 states)
+    u64 out;         // device address of the first decoded byte
+    u64 image;       // device address of the image; row of context 0 / the only row is at +0
+    u32 words_len;   // bytes from `words` to the end of the stream's input window
+    u32 out_sz;      // symbols to produce
+    u32 R[4];        // initial states
+    u32 img_bytes;   // size of the image
+    u32 look;        // bits looked up per symbol: 12, or 10
+    u32 order;       // 0: byte i on chain i&3;  1: chain k owns quarter k (+tail on chain 3)
+    u32 active;      // 0 = nothing to do (failed block, CAT, empty)
+    u32 blk;         // owning block (errors are reported there)
+    u32 pad[3];
+};
+
+// Per-block record of the decode pipeline.
+struct DecDesc {
+    i32 status;
+    u32 flags;
+    u32 osz;         // final size of the block
+    u32 s1_size;     // bytes produced by the entropy stage (or copied for CAT)
+    u64 s1;          // where the entropy stage writes
+    u64 cat_src;     // CAT: source of the raw copy (0 if none)
+    u32 cat_len;
+    u32 pack_per;    // symbols per byte (8,4,2), 0 = constant, 1 = copy
+    u8  pack_map[16];
+    u32 rle_meta_len;    // decoded meta length
+    u32 rle_meta_raw;    // 1: meta bytes live in the input at rle_meta; 0: decoded into workspace
+    u64 rle_meta;        // device address of meta (nsyms, syms, run varints)
+    u64 s2, s3;          // stage buffers after un-RLE / un-PACK
+    u32 pad[2];
+};
+
+// ---------------------------------------------------------------------------------------------
+// Encode image (per item): one 8-byte entry per (context row, byte value):
+//   u32 rcp   reciprocal (rANS_word.h:252, or ~0 for freq 1)
+//   u32 pk    bias[0:13) | cmpl_freq[13:26) | rcp_shift[26:31)     (rANS_word.h:190-266)
+//   x_max is (M - cmpl_freq) << (31 - bits).
+// Rows are indexed by byte value directly (256 entries, 2 KB per row); order-1 uses rows only
+// for contexts that occur, addressed through ctxrow[256] (u16 row number per context byte).
+// ---------------------------------------------------------------------------------------------
+struct EncEntry { u32 rcp; u32 pk; };
+
+struct EncItem {
+    u64 data;        // device address of the bytes to code
+    u64 image;       // device address of EncEntry rows
+    u64 scratch_end; // device address one past the end of this item's backward-write area (even)
+    u32 n;           // number of bytes
+    u32 bits;        // 12 (order-0) or 10/12
+    u32 order;
+    u32 active;
+    u32 pay_len;     // OUT: bytes written backwards (states + words)
+    u32 blk;
+    u16 ctxrow[256]; // order-1: context byte -> row number in image (order-0: unused)
+};
+
+// Per-block record of the encode pipeline.
+struct EncDesc {
+    i32 status;
+    u32 flags;       // first stream byte as decided so far
+    u32 hdr_len;     // bytes of hdr[] in use (flag byte, size, pack meta ...)
+    u8  hdr[44];
+    u64 data;        // bytes handed to the entropy stage (after PACK / RLE)
+    u32 dlen;
+    u32 nosz;
+    u32 cat;         // 1: copy `data` raw (explicit X_CAT)
+    u32 tab_len;     // bytes of table (incl. order-1 header byte) staged in tab[]
+    u64 tab;         // device address of the staged table bytes
+    u32 rle_on, rle_mlen, rle_lits;   // RLE meta bookkeeping (meta raw bytes at rle_meta)
+    u32 meta_tab_len;
+    u64 rle_meta;
+    u64 meta_tab;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Device workspace carved per chunk of blocks by r4x16_api.hip.
+// ---------------------------------------------------------------------------------------------
+#define TBUF_BYTES     204800u                          // an un-nested order-1 table (257*257*3 = 198147 max)
+#define DEC_IMG_SLOT   (IMG_MAX_BYTES + IMG_O0_BYTES)   // payload image + one order-0 image
+#define ENC_IMG_ROWS   257u
+#define ENC_IMG_BYTES  (ENC_IMG_ROWS * 256u * 8u)       // 256 context rows + 1 spare row (nested / meta)
+#define TAB_BYTES      198656u                          // >= 1 + 257*257*3 (assert at rANS_static4x16pr.c:784)
+
+struct DecWs {
+    DecDesc *desc;     // [nblk]
+    DecItem *items;    // [2*nblk]   2b = payload stream, 2b+1 = RLE meta stream
+    u8 *images;        // [nblk][DEC_IMG_SLOT]
+    u8 *tbuf;          // [nblk][TBUF_BYTES]
+    u8 *tmp;           // [nblk][tmp_stride]   stage buffer for PACK / RLE
+    u8 *meta;          // [nblk][meta_stride]  decoded RLE meta
+    u64 tmp_stride, meta_stride;
+};
+
+struct EncWs {
+    EncDesc *desc;      // [nblk]
+    EncItem *items;     // [2*nblk]  2b = payload stream, 2b+1 = RLE meta stream
+    u8 *images;         // [nblk][ENC_IMG_BYTES]
+    u8 *tabraw;         // [nblk][TAB_BYTES]  serialised order-1 table before nesting
+    u8 *tab;            // [nblk][TAB_BYTES]  table bytes as they go into the stream
+    u8 *scratch;        // [nblk][scratch_stride]  backward-written states + words
+    u32 *F;             // [nblk][65536]  order-1 counters when the alphabet is too big for LDS
+    const double *logtab;   // [2][257]  log(1024+k), log(4096+k) from the host libm (:651-652)
+    u64 scratch_stride;
+};

@@ -1,0 +1,143 @@
+// r4x16_dev.h — device-side helpers shared by the decode and encode kernels (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "r4x16_common.h"
+
+#define WAVE 64
+
+// Arguments of a device-resident batch (include/rans4x16_hip.h, *_dev entry points).
+struct BatchArgs {
+    const u8  *in;
+    const u64 *in_off;
+    const u32 *in_size;
+    u8        *out;
+    const u64 *out_off;
+    const u32 *out_cap;
+    u32       *out_size;
+    i32       *status;
+    const i32 *d_order;
+    int        order;
+    int        n;
+};
+
+// ---------------------------------------------------------------------------------------------
+// Sequential byte reader for the single lane that parses headers and tables.  Keeps an
+// 8-byte window so that a run of dependent byte reads costs one global load per 8 bytes.
+// `fresh` makes the loads bypass the CU's vector L1 (data written earlier by this launch).
+// ---------------------------------------------------------------------------------------------
+struct ByteSrc {
+    const u8 *base;
+    u64 win;
+    u64 win_addr;
+    bool fresh;
+    __device__ ByteSrc(const u8 *b, bool fresh_ = false) : base(b), win(0), win_addr(~0ull), fresh(fresh_) {}
+    __device__ __forceinline__ u8 at(u32 pos) {
+        u64 a = (u64)(base + pos);
+        u64 al = a & ~7ull;
+        if (al != win_addr) {
+            win_addr = al;
+            win = fresh ? __hip_atomic_load((const u64 *)al, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                        : *(const u64 *)al;
+        }
+        return (u8)(win >> ((a & 7) * 8));
+    }
+};
+
+// varint.h:131-160 on a ByteSrc: bytes [pos, end).  Returns bytes consumed (0 if pos >= end).
+__device__ __forceinline__ u32 var_get(ByteSrc &s, u32 pos, u32 end, u32 *v)
+{
+    u32 acc = 0, p = pos;
+    u8 c;
+    if (pos >= end) { *v = 0; return 0; }
+    do {
+        c = s.at(p++);
+        acc = (acc << 7) | (c & 0x7f);
+    } while ((c & 0x80) && p < end);
+    *v = acc;
+    return p - pos;
+}
+
+// varint.h:85-104
+__device__ __forceinline__ u32 var_put(u8 *cp, u32 v)
+{
+    u32 groups = 1;
+    for (u32 t = v >> 7; t; t >>= 7) groups++;
+    for (int g = (int)groups - 1; g >= 0; g--)
+        *cp++ = (u8)(((v >> (7 * g)) & 0x7f) | (g ? 0x80 : 0));
+    return groups;
+}
+
+__device__ __forceinline__ u32 var_len(u32 v)
+{
+    u32 groups = 1;
+    for (u32 t = v >> 7; t; t >>= 7) groups++;
+    return groups;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Quad (4-lane) cross-lane helpers.  DPP quad_perm moves data inside each group of four
+// adjacent lanes at VALU speed — no LDS round trip.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ u32 dpp_mov(u32 v)
+{
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+#define QP(a, b, c, d) ((a) | ((b) << 2) | ((c) << 4) | ((d) << 6))
+__device__ __forceinline__ u32 quad_bcast0(u32 v) { return dpp_mov<QP(0, 0, 0, 0)>(v); }
+__device__ __forceinline__ u32 quad_bcast1(u32 v) { return dpp_mov<QP(1, 1, 1, 1)>(v); }
+__device__ __forceinline__ u32 quad_bcast2(u32 v) { return dpp_mov<QP(2, 2, 2, 2)>(v); }
+__device__ __forceinline__ u32 quad_bcast3(u32 v) { return dpp_mov<QP(3, 3, 3, 3)>(v); }
+
+// For a per-lane predicate: 4-bit mask of the predicate over this lane's quad.
+__device__ __forceinline__ u32 quad_ballot(bool p, u32 lane)
+{
+    u64 m = __ballot(p);
+    return (u32)(m >> (lane & ~3u)) & 0xfu;
+}
+
+__device__ __forceinline__ u32 wave_any(bool p) { return __ballot(p) != 0ull; }
+
+// wave-wide inclusive prefix sum over 64 lanes (shuffle based; used outside the hot loops)
+__device__ __forceinline__ u32 wave_incl_scan(u32 v, u32 lane)
+{
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        u32 t = __shfl_up(v, d);
+        if (lane >= (u32)d) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ u32 wave_sum(u32 v)
+{
+#pragma unroll
+    for (int d = WAVE / 2; d; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+__device__ __forceinline__ u32 pow2_ceil(u32 v)      // rANS_static4x16pr.c:105-114
+{
+    v--;
+    v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16;
+    return v + 1;
+}
+
+// byte-granular copy by one wave, any alignment (header / table / payload assembly)
+__device__ __forceinline__ void wave_copy(u8 *dst, const u8 *src, u32 n, u32 lane)
+{
+    // head bytes until dst is 4-aligned, then dwords when src is co-aligned, else bytes
+    if ((((u64)dst ^ (u64)src) & 3) == 0) {
+        u32 head = (u32)((4 - ((u64)dst & 3)) & 3);
+        if (head > n) head = n;
+        if (lane < head) dst[lane] = src[lane];
+        u32 body = (n - head) >> 2;
+        const u32 *s4 = (const u32 *)(src + head);
+        u32 *d4 = (u32 *)(dst + head);
+        for (u32 i = lane; i < body; i += WAVE) d4[i] = s4[i];
+        u32 done = head + body * 4;
+        if (done + lane < n) dst[done + lane] = src[done + lane];
+    } else {
+        for (u32 i = lane; i < n; i += WAVE) dst[i] = src[i];
+    }
+}

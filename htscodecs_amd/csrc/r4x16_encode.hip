@@ -1,0 +1,672 @@
+// r4x16_encode.hip — gfx950 kernels for rans_compress_to_4x16 (rANS_static4x16pr.c:1138-1345).
+//
+// Pipeline for a batch of blocks (one launch each, in stream order):
+//   k_enc_front  : one wave per block.  Container header, histograms (hist8 / hist1_4,
+//                  utils.h:80-202) with LDS counters, frequency normalisation (:116-179), the
+//                  10/12-bit decision (:629-691, double precision, evaluation order kept),
+//                  table serialisation (:182-325) incl. the nested order-0 compression of a
+//                  large order-1 table (:767-780), and the encoder symbol table ("image").
+//   k_enc_chain  : the hot loop (:442-485, :794-839).  A quad runs the 4 states of a stream
+//                  backwards over the input; emitted 16-bit words are placed with a 4-bit
+//                  ballot prefix inside the quad.
+//   k_enc_finish : one wave per block.  Chooses CAT fall-back (:1332-1337), assembles
+//                  header + table + payload into the caller's slot, writes size and status.
+#include "r4x16_dev.h"
+
+#define FRONT_DYN_LDS  61440u                           // LDS counters: alphabets up to 123 symbols
+#define FRONT_LDS_NSYM 123u
+
+// ---------------------------------------------------------------------------------------------
+// rANS_static4x16pr.c:360-372, same expression, same evaluation order, in double.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ static inline u32 compress_bound(u32 size, int order)
+{
+    int N = order >> 8;
+    if (!N) N = 4;
+    order &= 0xff;
+    double d = (order == 0 ? 1.05 * size + 257 * 3 + 4
+                           : 1.05 * size + 257 * 257 * 3 + 4 + 257 * 3 + 4)
+             + ((order & X_PACK) ? 1 : 0)
+             + ((order & X_RLE) ? 1 + 257 * 3 + 4 : 0) + 20
+             + ((order & X_STRIPE) ? 1 + 5 * N : 0);
+    int sz = (int)d;
+    return (u32)(sz + (sz & 1) + 2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// normalise_freq, rANS_static4x16pr.c:116-163, over `cnt` counters F[0..cnt) (zero = absent).
+// Integer types as in the reference.  One lane.
+// ---------------------------------------------------------------------------------------------
+__device__ int normalise_freq(u32 *F, u32 cnt, int size, u32 tot)
+{
+    int retried = 0;
+    if (!size) return 0;
+    for (;;) {
+        const u64 scale = ((u64)tot << 31) / (u64)(long)size + (u64)(long)((1 << 30) / size);
+        u32 best = 0, arg = 0;
+        int sum = 0;
+        for (u32 j = 0; j < cnt; j++) {
+            u32 f = F[j];
+            if (!f) continue;
+            if (best < f) { best = f; arg = j; }
+            f = (u32)(((u64)f * scale) >> 31);
+            if (f == 0) f = 1;
+            F[j] = f;
+            sum += (int)f;
+        }
+        int adjust = (int)(tot - (u32)sum);
+        if (adjust > 0) {
+            F[arg] += (u32)adjust;
+        } else if (adjust < 0) {
+            const u32 need = (u32)(-adjust);
+            if (F[arg] > need && (retried || F[arg] / 2 >= need)) {
+                F[arg] -= need;
+            } else if (!retried) {
+                retried = 1;
+                size = sum;
+                continue;
+            } else {
+                adjust += (int)(F[arg] - 1);
+                F[arg] = 1;
+                for (u32 j = 0; adjust && j < cnt; j++) {
+                    if (F[j] < 2) continue;
+                    const int take = (F[j] > (u32)(-adjust)) ? adjust : (int)(1 - F[j]);
+                    F[j] += (u32)take;
+                    adjust -= take;
+                }
+            }
+        }
+        return F[arg] > 0 ? 0 : -1;
+    }
+}
+
+// RansEncSymbolInit, rANS_word.h:190-266, packed into an EncEntry.
+__device__ __forceinline__ EncEntry make_entry(u32 start, u32 freq, u32 bits)
+{
+    EncEntry e;
+    const u32 M = 1u << bits;
+    const u32 cmpl = M - freq;
+    u32 bias, rsh;
+    if (freq < 2) {
+        e.rcp = ~0u;
+        rsh = 0;
+        bias = start + M - 1;
+    } else {
+        u32 shift = 0;
+        while (freq > (1u << shift)) shift++;
+        e.rcp = (u32)(((1ull << (shift + 31)) + freq - 1) / freq);
+        rsh = shift - 1;
+        bias = start;
+    }
+    e.pk = bias | (cmpl << 13) | (rsh << 26);
+    return e;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The chain encoder.  lane&3 = chain, lane>>2 = stream.  Returns the number of bytes written
+// backwards from scratch_end (16 bytes of states + 2 per emitted word), same in all 4 lanes.
+//
+// Per step and chain (rANS_word.h:281-321): if x >= x_max emit the low 16 bits and shift;
+// then x += bias + ((x * rcp) >> rcp_shift) * cmpl_freq.  Within one step the reference emits
+// in chain order 3,2,1,0 onto a descending pointer, so chain k's word lands
+// 2 * (1 + #emitting chains above k) below the step's starting pointer.
+// ---------------------------------------------------------------------------------------------
+template <int ORDER>
+__device__ __forceinline__ u32 chain_encode(const u8 *data, u32 n, const EncEntry *img,
+                                            const u16 *ctxrow, u32 bits, u8 *scratch_end,
+                                            bool active, u32 lane)
+{
+    const u32 k = lane & 3;
+    u32 x = RANS_LOW;
+    u32 written = 0;                 // words emitted by the quad so far
+    u32 nsteps, first;               // this lane takes part in steps [first, nsteps)
+    u32 p;                           // position of the symbol coded at this lane's next step
+    const u32 q = n >> 2;
+    if (ORDER == 0) {
+        const u32 gtop = n ? (n - 1) >> 2 : 0;
+        nsteps = n ? gtop + 1 : 0;
+        first = (4 * gtop + k < n) ? 0 : 1;      // the top group may be partial (:442-448)
+        p = 4 * (gtop - (first ? 1 : 0)) + k;    // unused when nsteps <= first
+    } else {
+        const u32 tail = n - 4 * q;              // extra bytes on chain 3 (:806-811)
+        nsteps = tail + q;
+        first = (k == 3) ? 0 : tail;
+        p = (k == 3) ? n - 1 : k * q + q - 1;
+    }
+    if (!active) { nsteps = 0; first = 0; }
+
+    u32 cur = 0;
+    if (nsteps > first) cur = data[p];
+    const u32 row0 = (ORDER == 1 && active) ? (u32)ctxrow[0] : 0u;
+
+    for (u32 s = 0; wave_any(s < nsteps); s++) {
+        const bool live = s >= first && s < nsteps;
+        bool emit = false;
+        EncEntry e;
+        e.rcp = 0; e.pk = 0;
+        u32 nextc = 0;
+        if (live) {
+            u32 row;
+            if (ORDER == 0) {
+                row = 0;
+                if (p >= 4) nextc = data[p - 4];
+            } else {
+                // context = previous byte, except at the start of the quarter (:831-834)
+                const bool at_start = (s == nsteps - 1);
+                if (!at_start) { nextc = data[p - 1]; row = ctxrow[nextc]; }
+                else row = row0;
+            }
+            e = img[row * 256u + cur];
+            const u32 cmpl = (e.pk >> 13) & 0x1fffu;
+            const u32 x_max = ((1u << bits) - cmpl) << (31 - bits);
+            emit = x >= x_max;
+        }
+        const u32 em = quad_ballot(emit, lane);
+        if (emit) {
+            const u32 above = __popc(em >> (k + 1));
+            *(u16 *)(scratch_end - 2 * (written + above + 1)) = (u16)x;
+            x >>= 16;
+        }
+        written += __popc(em);
+        if (live) {
+            const u32 qq = (u32)(((u64)x * e.rcp) >> (32 + (e.pk >> 26)));
+            x = x + (e.pk & 0x1fffu) + qq * ((e.pk >> 13) & 0x1fffu);
+            cur = nextc;
+            p -= (ORDER == 0) ? 4 : 1;
+        }
+    }
+    // RansEncFlush x4 in order 3,2,1,0 (:482-485): R0 ends up lowest in memory
+    if (active) *(u32 *)(scratch_end - 2 * written - 16 + 4 * k) = x;
+    return active ? 2 * written + 16 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Shared state of k_enc_front.
+// ---------------------------------------------------------------------------------------------
+struct EncShared {
+    u32 F[256];          // order-0 counters / scratch row
+    u32 T[256];          // order-1: context totals (by compact index)
+    int S[256];          // order-1: per-context target from compute_shift (by compact index)
+    u32 rowlen[256];     // order-1: serialised length of each row
+    u8  present[256];
+    u8  idx_of[256];     // byte -> compact
+    u8  alpha[256];      // compact -> byte
+    double t10[256], t12[256];
+    u8  pmask[256];      // terms present in this row
+    u32 nsym, tab_len, bits;
+    i32 status;
+};
+
+// ---- wave histogram of bytes (hist8, utils.h:80-102) into S.F ---------------------------------
+__device__ void wave_hist8(const u8 *data, u32 n, u32 *F, u32 lane)
+{
+    for (u32 j = lane; j < 256; j += WAVE) F[j] = 0;
+    __syncthreads();
+    u32 head = (u32)((16 - ((u64)data & 15)) & 15);
+    if (head > n) head = n;
+    if (lane < head) atomicAdd(&F[data[lane]], 1u);
+    const u32 body = (n - head) >> 4;
+    const uint4 *v = (const uint4 *)(data + head);
+    for (u32 i = lane; i < body; i += WAVE) {
+        const uint4 w = v[i];
+        const u32 ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            atomicAdd(&F[ww[c] & 0xff], 1u);
+            atomicAdd(&F[(ww[c] >> 8) & 0xff], 1u);
+            atomicAdd(&F[(ww[c] >> 16) & 0xff], 1u);
+            atomicAdd(&F[ww[c] >> 24], 1u);
+        }
+    }
+    const u32 done = head + body * 16;
+    if (done + lane < n) atomicAdd(&F[data[done + lane]], 1u);
+    __syncthreads();
+}
+
+// put_alphabet, rANS_static4x16pr.c:182-206.  One lane.
+__device__ u32 put_alphabet(u8 *cp, const u8 *present)
+{
+    u8 *start = cp;
+    u32 implicit = 0;
+    for (u32 j = 0; j < 256; j++) {
+        if (!present[j]) continue;
+        if (implicit) { implicit--; continue; }
+        *cp++ = (u8)j;
+        if (j && present[j - 1]) {
+            u32 kk = j + 1;
+            while (kk < 256 && present[kk]) kk++;
+            implicit = kk - (j + 1);
+            *cp++ = (u8)implicit;
+        }
+    }
+    *cp++ = 0;
+    return (u32)(cp - start);
+}
+
+// Order-0 stream front end (rANS_static4x16pr.c:405-435): histogram, two normalisations, table
+// bytes to `tab`, encoder row to `imgrow`.  All lanes call.  Sets S.tab_len / S.status.
+__device__ void enc_o0_front(const u8 *data, u32 n, u8 *tab, EncEntry *imgrow, EncShared &S, u32 lane)
+{
+    wave_hist8(data, n, S.F, lane);
+    if (lane == 0) {
+        u32 target = pow2_ceil(n);
+        if (target > (1u << O0_BITS)) target = 1u << O0_BITS;
+        S.status = ST_OK;
+        if (normalise_freq(S.F, 256, (int)n, target) < 0) S.status = ST_TABLE;
+        for (u32 j = 0; j < 256; j++) S.present[j] = S.F[j] != 0;
+        u8 *cp = tab;
+        cp += put_alphabet(cp, S.present);
+        for (u32 j = 0; j < 256; j++)
+            if (S.F[j]) cp += var_put(cp, S.F[j]);
+        S.tab_len = (u32)(cp - tab);
+        if (normalise_freq(S.F, 256, (int)target, 1u << O0_BITS) < 0) S.status = ST_TABLE;   // :426
+    }
+    __syncthreads();
+    // cumulative starts by a wave scan, 4 symbols per lane
+    u32 f[4], sum = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) { f[c] = S.F[lane * 4 + c]; sum += f[c]; }
+    u32 start = wave_incl_scan(sum, lane) - sum;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        if (f[c]) imgrow[lane * 4 + c] = make_entry(start, f[c], O0_BITS);
+        start += f[c];
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_enc_front
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double approx_log(double a)            // fast_log :620-623
+{
+    const long long bits = __double_as_longlong(a);
+    return (double)(bits - 4606921278410026770LL) * 1.539095918623324e-16;
+}
+
+__global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int base)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 dyn[];
+    __shared__ EncShared S;
+    __shared__ struct { i32 status; u32 go, order, dlen, nested_len; double e10, e12; int max_tot; } H;
+
+    const u32 lane = threadIdx.x;
+    const u32 b = blockIdx.x;
+    const int i = base + (int)b;
+    EncDesc *D = &ws.desc[b];
+    EncItem *I0 = &ws.items[2 * b], *I1 = &ws.items[2 * b + 1];
+    const u8 *in = a.in + a.in_off[i];
+    const u32 in_size = a.in_size[i];
+    const u32 cap = a.out_cap[i];
+    int order = a.d_order ? a.d_order[i] : a.order;
+    EncEntry *img = (EncEntry *)(ws.images + (u64)b * ENC_IMG_BYTES);
+    u8 *tab = ws.tab + (u64)b * TAB_BYTES;
+    u8 *tabraw = ws.tabraw + (u64)b * TAB_BYTES;
+    u8 *scratch = ws.scratch + (u64)b * ws.scratch_stride;
+    u8 *scratch_end = scratch + ws.scratch_stride;
+
+    // ---- container header (:1144-1237) ---------------------------------------------------------
+    if (lane == 0) {
+        I0->active = 0; I1->active = 0; I0->pay_len = 0; I1->pay_len = 0;
+        I0->blk = b; I1->blk = b;
+        D->cat = 0; D->rle_on = 0; D->tab_len = 0; D->hdr_len = 0; D->dlen = 0; D->tab = (u64)tab;
+        i32 st = ST_OK;
+        u32 go = 0;
+        if (cap < compress_bound(in_size, order)) st = ST_CAPACITY;
+        else {
+            if (in_size <= 20) order &= ~X_STRIPE;                         // :1151
+            if (order & X_STRIPE) st = ST_UNSUPPORTED;                     // host entry points split stripes
+            else if (order & X_CAT) {                                      // :1218-1225
+                D->hdr[0] = X_CAT;
+                D->hdr_len = 1 + var_put(D->hdr + 1, in_size);
+                D->cat = 1; D->data = (u64)in; D->dlen = in_size; D->flags = X_CAT;
+            } else if (order & (X_PACK | X_RLE)) {
+                st = ST_UNSUPPORTED;                                       // TODO(milestone 2)
+            } else {
+                u32 flags = (u32)order & 0xff;
+                u32 hl = 1;
+                D->nosz = flags & X_NOSZ;
+                if (!(flags & X_NOSZ)) hl += var_put(D->hdr + 1, in_size); // :1234-1235
+                u32 o = order & 1;
+                if (o && in_size < 8) { flags &= ~1u; o = 0; }             // :1322-1325
+                D->flags = flags; D->hdr[0] = (u8)flags; D->hdr_len = hl;
+                D->data = (u64)in; D->dlen = in_size;
+                H.order = o; H.dlen = in_size;
+                go = in_size != 0;
+            }
+        }
+        D->status = st;
+        H.status = st; H.go = go;
+    }
+    __syncthreads();
+    if (H.status != ST_OK || !H.go) return;
+
+    const u8 *data = in;
+    const u32 n = H.dlen;
+
+    if (H.order == 0) {
+        enc_o0_front(data, n, tab, img, S, lane);
+        if (lane == 0) {
+            D->status = S.status;
+            D->tab_len = S.tab_len;
+            I0->data = (u64)data; I0->n = n; I0->image = (u64)img; I0->bits = O0_BITS; I0->order = 0;
+            I0->scratch_end = (u64)scratch_end;
+            __threadfence();
+            I0->active = S.status == ST_OK;
+        }
+        return;
+    }
+
+    // ---- order-1 (:694-780) ---------------------------------------------------------------------
+    // pass 1: which bytes occur (present8, utils.h:108-131) -> compact alphabet F0 (0 forced in :731)
+    wave_hist8(data, n, S.F, lane);
+    if (lane == 0) {
+        u32 ns = 0;
+        for (u32 j = 0; j < 256; j++) {
+            S.present[j] = (S.F[j] != 0) || j == 0;
+            if (S.present[j]) { S.idx_of[j] = (u8)ns; S.alpha[ns] = (u8)j; ns++; }
+        }
+        S.nsym = ns;
+    }
+    __syncthreads();
+    const u32 ns = S.nsym;
+    u32 *Fp = (ns <= FRONT_LDS_NSYM) ? (u32 *)dyn : ws.F + (u64)b * 65536u;
+    for (u32 j = lane; j < ns * ns; j += WAVE) Fp[j] = 0;
+    __syncthreads();
+
+    // pass 2: hist1_4 (utils.h:136-202): every adjacent pair, the first byte in context 0
+    {
+        const u32 pieces = (n + 15) >> 4;
+        u32 carry = 0;                                   // compact index of the byte before this piece row
+        for (u32 pb = 0; pb < pieces; pb += WAVE) {
+            const u32 pi = pb + lane;
+            const u32 off = pi * 16;
+            u32 cnt = 0;
+            if (pi < pieces) cnt = (n - off < 16) ? n - off : 16;
+            u32 ci[16];                                  // compact indices of this lane's bytes
+            u32 last = 0;
+            if (cnt == 16 && ((u64)(data + off) & 3) == 0) {
+                const u32 *w = (const u32 *)(data + off);
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const u32 ww = w[c];
+                    ci[4 * c] = S.idx_of[ww & 0xff]; ci[4 * c + 1] = S.idx_of[(ww >> 8) & 0xff];
+                    ci[4 * c + 2] = S.idx_of[(ww >> 16) & 0xff]; ci[4 * c + 3] = S.idx_of[ww >> 24];
+                }
+                last = ci[15];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 16; c++) {
+                    ci[c] = 0;
+                    if (c < (int)cnt) { ci[c] = S.idx_of[data[off + c]]; last = ci[c]; }
+                }
+            }
+            u32 prev = __shfl_up(last, 1);
+            const u32 wrap = __shfl(last, WAVE - 1);     // lane 63 always holds a full piece unless at the end
+            if (lane == 0) prev = carry;
+            carry = wrap;
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                if (c < (int)cnt) {
+                    atomicAdd(&Fp[prev * ns + ci[c]], 1u);
+                    prev = ci[c];
+                }
+            }
+        }
+        __syncthreads();
+        // the three quarter starts are coded in context 0 (:720-723)
+        if (lane >= 1 && lane < 4) atomicAdd(&Fp[0 * ns + S.idx_of[data[lane * (n >> 2)]]], 1u);
+        __syncthreads();
+        // context totals = row sums
+        for (u32 r = lane; r < ns; r += WAVE) {
+            u32 t = 0;
+            for (u32 j = 0; j < ns; j++) t += Fp[r * ns + j];
+            S.T[r] = t;
+        }
+        __syncthreads();
+    }
+
+    // ---- compute_shift (:629-691): row by row; terms in parallel, sums in reference order ------
+    if (lane == 0) { H.e10 = 0; H.e12 = 0; H.max_tot = 0; }
+    __syncthreads();
+    for (u32 r = 0; r < ns; r++) {
+        const u32 Tr = S.T[r];
+        const int target0 = (int)pow2_ceil(Tr);
+        u32 tiny10 = 0, tiny12 = 0, nz = 0;
+        for (u32 j = lane; j < ns; j += WAVE) {
+            const u32 f = Fp[r * ns + j];
+            if (f) {
+                nz++;
+                if ((u32)target0 / f > 1024u) tiny10++;
+                if ((u32)target0 / f > 4096u) tiny12++;
+            }
+        }
+        tiny10 = wave_sum(tiny10); tiny12 = wave_sum(tiny12); nz = wave_sum(nz);
+        const double l10 = ws.logtab[tiny10], l12 = ws.logtab[257 + tiny12];
+        for (u32 j = lane; j < ns; j += WAVE) {
+            const u32 f = Fp[r * ns + j];
+            S.pmask[j] = f != 0;
+            if (f) {
+                int x = (int)((double)1024 * (double)f / (double)Tr);
+                S.t10[j] = (double)f * (approx_log((double)(x > 1 ? x : 1)) - l10);
+                x = (int)((double)4096 * (double)f / (double)Tr);
+                S.t12[j] = (double)f * (approx_log((double)(x > 1 ? x : 1)) - l12);
+            }
+        }
+        __syncthreads();
+        if (lane == 0) {
+            double e10 = H.e10, e12 = H.e12;
+            for (u32 j = 0; j < ns; j++) {
+                if (!S.pmask[j]) continue;
+                e10 -= S.t10[j];
+                e12 -= S.t12[j];
+                e10 += 4;
+                e12 += 6;
+            }
+            H.e10 = e10; H.e12 = e12;
+            int target = target0;
+            if (nz < 64 && target > 128) target /= 2;                  // :678-681
+            if (target > 1024) target /= 2;
+            if (target > 4096) target = 4096;
+            S.S[r] = target;
+            if (H.max_tot < target) H.max_tot = target;
+        }
+        __syncthreads();
+    }
+    const u32 bits = (H.e10 / H.e12 < 1.01 || H.max_tot <= 1024) ? 10u : 12u;      // :685
+
+    // ---- per-context normalisation (:740-752), one context row per lane ---------------------------
+    for (u32 rb = 0; rb < ns; rb += WAVE) {
+        const u32 r = rb + lane;
+        if (r < ns) {
+            int target = S.S[r];
+            if (bits == 10 && target > 1024) target = 1024;
+            S.S[r] = target;
+            if (normalise_freq(Fp + r * ns, ns, (int)S.T[r], (u32)target) < 0) H.status = ST_TABLE;
+            // serialised length of the row (:295-325)
+            u32 len = 0, zeros = 0;
+            for (u32 j = 0; j < ns; j++) {
+                const u32 f = Fp[r * ns + j];
+                if (f) { if (zeros) { len += 2; zeros = 0; } len += var_len(f); }
+                else zeros++;
+            }
+            if (zeros) len += 2;
+            S.rowlen[r] = len;
+        }
+    }
+    __syncthreads();
+    if (H.status != ST_OK) { if (lane == 0) D->status = H.status; return; }
+
+    // ---- serialise: alphabet, then rows at their prefix offsets -----------------------------------
+    if (lane == 0) {
+        u32 off = put_alphabet(tabraw, S.present);                    // :732
+        for (u32 r = 0; r < ns; r++) { const u32 l = S.rowlen[r]; S.rowlen[r] = off; off += l; }
+        S.tab_len = off;
+    }
+    __syncthreads();
+    for (u32 rb = 0; rb < ns; rb += WAVE) {
+        const u32 r = rb + lane;
+        if (r < ns) {
+            u8 *cp = tabraw + S.rowlen[r];
+            u32 zeros = 0;
+            for (u32 j = 0; j < ns; j++) {
+                const u32 f = Fp[r * ns + j];
+                if (f) {
+                    if (zeros) { *cp++ = 0; *cp++ = (u8)(zeros - 1); zeros = 0; }
+                    cp += var_put(cp, f);
+                } else zeros++;
+            }
+            if (zeros) { *cp++ = 0; *cp++ = (u8)(zeros - 1); }
+        }
+    }
+    const u32 tlen = S.tab_len;
+
+    // ---- encoder image: scale each row up to 1<<bits (:756) and build entries (:759-762) -----------
+    for (u32 j = lane; j < 256; j += WAVE) I0->ctxrow[j] = S.present[j] ? (u16)S.idx_of[j] : (u16)0;
+    for (u32 r = 0; r < ns; r++) {
+        u32 sh = 0;
+        const u32 tgt = (u32)S.S[r];
+        if (tgt != 0 && tgt != (1u << bits)) { u32 sz = tgt; while (sz < (1u << bits)) { sz *= 2; sh++; } }
+        u32 carry = 0;
+        for (u32 jb = 0; jb < ns; jb += WAVE) {
+            const u32 j = jb + lane;
+            const u32 f = (j < ns) ? (Fp[r * ns + j] << sh) : 0u;
+            const u32 incl = wave_incl_scan(f, lane);
+            if (f) img[r * 256u + S.alpha[j]] = make_entry(carry + incl - f, f, bits);
+            carry += __shfl(incl, WAVE - 1);
+        }
+    }
+    __threadfence();
+    __syncthreads();
+
+    // ---- table into the stream, nested order-0 if it pays (:766-780) ------------------------------
+    u32 final_len = 0;
+    bool nested = false;
+    if (1 + tlen > 1000) {
+        EncEntry *img0 = img + 256u * 256u;
+        u8 *ntab = scratch;                                           // nested table bytes, staged low
+        enc_o0_front(tabraw, tlen, ntab, img0, S, lane);
+        __threadfence();
+        __syncthreads();
+        const u32 npay = chain_encode<0>(tabraw, tlen, img0, nullptr, O0_BITS, scratch_end, lane < 4, lane);
+        const u32 np = __shfl(npay, 0);
+        __threadfence();
+        __syncthreads();
+        const u32 nlen = S.tab_len + np;
+        if (S.status == ST_OK && nlen + 6 < 1 + tlen) {               // :772
+            nested = true;
+            u32 hl = 0;
+            if (lane == 0) {
+                tab[0] = (u8)((bits << 4) | 1);
+                hl = 1;
+                hl += var_put(tab + hl, tlen);
+                hl += var_put(tab + hl, nlen);
+                H.nested_len = hl;
+            }
+            __syncthreads();
+            hl = H.nested_len;
+            wave_copy(tab + hl, ntab, S.tab_len, lane);
+            wave_copy(tab + hl + S.tab_len, scratch_end - np, np, lane);
+            final_len = hl + nlen;
+        }
+    }
+    if (!nested) {
+        if (lane == 0) tab[0] = (u8)(bits << 4);
+        wave_copy(tab + 1, tabraw, tlen, lane);
+        final_len = 1 + tlen;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        D->tab_len = final_len;
+        I0->data = (u64)data; I0->n = n; I0->image = (u64)img; I0->bits = bits; I0->order = 1;
+        I0->scratch_end = (u64)scratch_end;
+        __threadfence();
+        I0->active = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_enc_chain: QPW streams per wave.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_enc_chain(EncItem *items, int nitems, int qpw)
+{
+    const u32 lane = threadIdx.x;
+    const u32 quad = lane >> 2;
+    const int it = (int)blockIdx.x * qpw + (int)quad;
+    const bool mine = quad < (u32)qpw && it < nitems;
+    EncItem *I = mine ? &items[it] : &items[0];
+    const bool active = mine && I->active;
+    const u32 order = active ? I->order : 2u;
+    const u8 *data = (const u8 *)I->data;
+    const EncEntry *img = (const EncEntry *)I->image;
+    u8 *send = (u8 *)I->scratch_end;
+    u32 pay = chain_encode<1>(data, I->n, img, I->ctxrow, I->bits, send, order == 1, lane);
+    pay |= chain_encode<0>(data, I->n, img, I->ctxrow, I->bits, send, order == 0, lane);
+    if (active && (lane & 3) == 0) I->pay_len = pay;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_enc_finish
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVE) void k_enc_finish(BatchArgs a, EncWs ws, int base)
+{
+    const u32 lane = threadIdx.x;
+    const u32 b = blockIdx.x;
+    const int i = base + (int)b;
+    const EncDesc *D = &ws.desc[b];
+    const EncItem *I0 = &ws.items[2 * b];
+    u8 *out = a.out + a.out_off[i];
+    const i32 st = D->status;
+    if (st != ST_OK) {
+        if (lane == 0) { a.status[i] = st; a.out_size[i] = 0; }
+        return;
+    }
+    u32 pos = D->hdr_len;
+    const u32 dlen = D->dlen;
+    u32 flags = D->hdr[0];
+    if (D->cat) {
+        wave_copy(out + pos, (const u8 *)D->data, dlen, lane);
+        pos += dlen;
+    } else {
+        const u32 pay = I0->active ? I0->pay_len : 0;
+        const u32 plen = D->tab_len + pay;
+        if (plen >= dlen) {                                           // :1332-1337
+            flags = (flags & ~3u) | X_CAT | D->nosz;
+            wave_copy(out + pos, (const u8 *)D->data, dlen, lane);
+            pos += dlen;
+        } else {
+            wave_copy(out + pos, (const u8 *)D->tab, D->tab_len, lane);
+            pos += D->tab_len;
+            wave_copy(out + pos, (const u8 *)I0->scratch_end - pay, pay, lane);
+            pos += pay;
+        }
+    }
+    if (lane == 0) {
+        out[0] = (u8)flags;
+        a.status[i] = ST_OK;
+        a.out_size[i] = pos;
+    }
+    if (lane >= 1 && lane < D->hdr_len) out[lane] = D->hdr[lane];
+}
+
+// ---- host-callable launchers -------------------------------------------------------------------
+extern "C" void r4x16_launch_enc_front(const BatchArgs *a, const EncWs *ws, int base, int nblk, hipStream_t s)
+{
+    // static + dynamic LDS exceeds the 64 KB default; gfx950 has 160 KB per CU
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute((const void *)k_enc_front, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_DYN_LDS);
+        once = true;
+    }
+    hipLaunchKernelGGL(k_enc_front, dim3(nblk), dim3(WAVE), FRONT_DYN_LDS, s, *a, *ws, base);
+}
+extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, int qpw, hipStream_t s)
+{
+    const int grid = (nitems + qpw - 1) / qpw;
+    hipLaunchKernelGGL(k_enc_chain, dim3(grid), dim3(WAVE), 0, s, ws->items, nitems, qpw);
+}
+extern "C" void r4x16_launch_enc_finish(const BatchArgs *a, const EncWs *ws, int base, int nblk, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_enc_finish, dim3(nblk), dim3(WAVE), 0, s, *a, *ws, base);
+}
+extern "C" u32 r4x16_compress_bound(u32 size, int order) { return compress_bound(size, order); }

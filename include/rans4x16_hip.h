@@ -1,0 +1,130 @@
+/*
+ * rans4x16_hip.h — C ABI of librans4x16_hip.so: the MI355X (gfx950) implementation of the
+ * CRAM 3.1 rANS 4x16 codec, bit-exact with htscodecs 1.1.
+ *
+ * Two layers, both plain C (pointers + sizes, no C++/torch types):
+ *
+ *  1. The five entry points of htscodecs/rANS_static4x16.h:41-50, same names, same argument
+ *     meaning, same ownership and error rules.  A program linked against
+ *     libhtscodecs can be re-linked against this library for this codec without source changes.
+ *     Buffers are HOST memory; each call stages through the GPU as a batch of one.
+ *
+ *  2. Batch entry points — the shape of the reference's own benchmark loop
+ *     (tests/rANS_static4x16pr_test.c:191-206: a serial loop of rans_compress_to_4x16 /
+ *     rans_uncompress_to_4x16 over independent blocks), which is what a GPU needs to be fed.
+ *     *_batch take host buffers; *_dev take device-resident buffers (no PCIe in the call),
+ *     enqueue on a caller-supplied HIP stream and do not synchronise.
+ *
+ * All GPU work is done by hand-written HIP kernels; there is no CPU fallback.  If no usable
+ * GPU is present every entry point fails (NULL / negative return) and says why on stderr once.
+ */
+#ifndef RANS4X16_HIP_H
+#define RANS4X16_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- 1. drop-in replacements (htscodecs/rANS_static4x16.h:41-50) ------------------------- */
+
+/* rANS_static4x16pr.c:360-372.  Pure host arithmetic. */
+unsigned int rans_compress_bound_4x16(unsigned int size, int order);
+
+/* rANS_static4x16pr.c:1138-1345.  out==NULL: malloc'd result (caller frees); else *out_size is
+ * the capacity on entry (must be >= rans_compress_bound_4x16(in_size, order), otherwise NULL)
+ * and the produced size on return.  order: bit0 order-1, 0x80 PACK, 0x40 RLE, 0x20 CAT,
+ * 0x10 NOSZ, 0x08 STRIPE, bits 8..15 stripe count. */
+unsigned char *rans_compress_to_4x16(unsigned char *in, unsigned int in_size,
+                                     unsigned char *out, unsigned int *out_size, int order);
+/* rANS_static4x16pr.c:1347-1350 */
+unsigned char *rans_compress_4x16(unsigned char *in, unsigned int in_size,
+                                  unsigned int *out_size, int order);
+/* rANS_static4x16pr.c:1352-1636.  NULL on any malformed input. */
+unsigned char *rans_uncompress_to_4x16(unsigned char *in, unsigned int in_size,
+                                       unsigned char *out, unsigned int *out_size);
+/* rANS_static4x16pr.c:1638-1641 */
+unsigned char *rans_uncompress_4x16(unsigned char *in, unsigned int in_size,
+                                    unsigned int *out_size);
+
+/* ---- 2. batch interface ------------------------------------------------------------------ */
+
+typedef struct rans4x16_hip_ctx rans4x16_hip_ctx;
+
+/* Per-block status codes written to the status arrays (0 = success). */
+enum {
+    R4X16_OK            = 0,
+    R4X16_E_CAPACITY    = 1,   /* output capacity too small (encode: < bound; decode: < stored size) */
+    R4X16_E_TRUNCATED   = 2,   /* input ends inside a header, table or state words               */
+    R4X16_E_TABLE       = 3,   /* frequency table does not sum to a power of two / overflows      */
+    R4X16_E_STATE       = 4,   /* initial rANS state below 2^15                                   */
+    R4X16_E_SIZE        = 5,   /* inconsistent size fields (pack / rle / cat)                     */
+    R4X16_E_UNSUPPORTED = 6,   /* valid-looking stream this build does not handle */
+    R4X16_E_CONTEXT     = 7,   /* order-1 stream used a context that has no table row             */
+    R4X16_E_RLE         = 8,   /* run-length expansion overran the output                         */
+    R4X16_E_EMPTY       = 9    /* zero-length compressed input                                    */
+};
+
+/* One context per (host thread, device).  device < 0 selects the current HIP device.
+ * Returns NULL if the device or the code object is unusable. */
+rans4x16_hip_ctx *rans4x16_hip_create(int device);
+void              rans4x16_hip_destroy(rans4x16_hip_ctx *ctx);
+const char       *rans4x16_hip_last_error(const rans4x16_hip_ctx *ctx);
+
+/* Host-buffer batches: n independent blocks, semantics of n calls of the functions in part 1
+ * with caller-provided output buffers (out[i] != NULL, out_size[i] = capacity in / size out).
+ * Returns the number of failed blocks (their out_size[i] is set to 0 and status[i] != 0 if
+ * status is not NULL), or -1 if the batch could not be run at all. */
+int rans4x16_hip_compress_batch(rans4x16_hip_ctx *ctx, int n,
+                                const unsigned char *const *in, const unsigned int *in_size,
+                                unsigned char *const *out, unsigned int *out_size,
+                                const int *order, int *status);
+int rans4x16_hip_uncompress_batch(rans4x16_hip_ctx *ctx, int n,
+                                  const unsigned char *const *in, const unsigned int *in_size,
+                                  unsigned char *const *out, unsigned int *out_size,
+                                  int *status);
+
+/* Device-resident batches.  Every pointer below is a DEVICE pointer.
+ *   d_in  + d_in_off[i]   : block i input,  d_in_size[i] bytes
+ *   d_out + d_out_off[i]  : block i output slot, d_out_cap[i] bytes available
+ *   d_out_size[i]         : bytes produced (0 on failure);  d_status[i]: code above
+ * `order` applies to all blocks unless d_order != NULL (device array of n ints).
+ * max_in_size / max_out_cap are host-side upper bounds on the per-block sizes, used only to
+ * size the workspace (no device->host read-back happens inside these calls).
+ * `stream` is a hipStream_t (NULL = default stream).  The call only enqueues work.
+ * X_STRIPE (0x08) is handled by the host entry points, not by *_dev (status UNSUPPORTED).
+ * Returns 0 if enqueued, -1 on argument / allocation / launch errors. */
+int rans4x16_hip_compress_dev(rans4x16_hip_ctx *ctx, int n,
+                              const unsigned char *d_in, const uint64_t *d_in_off,
+                              const uint32_t *d_in_size,
+                              unsigned char *d_out, const uint64_t *d_out_off,
+                              const uint32_t *d_out_cap, uint32_t *d_out_size,
+                              int32_t *d_status, int order, const int32_t *d_order,
+                              uint32_t max_in_size, void *stream);
+int rans4x16_hip_uncompress_dev(rans4x16_hip_ctx *ctx, int n,
+                                const unsigned char *d_in, const uint64_t *d_in_off,
+                                const uint32_t *d_in_size,
+                                unsigned char *d_out, const uint64_t *d_out_off,
+                                const uint32_t *d_out_cap, uint32_t *d_out_size,
+                                int32_t *d_status, uint32_t max_in_size, uint32_t max_out_cap,
+                                void *stream);
+
+/* Bytes of device workspace the context currently holds (grows on demand, never shrinks). */
+size_t rans4x16_hip_workspace_bytes(const rans4x16_hip_ctx *ctx);
+
+/* Timing hook for bench.py / rocprof cross-checks: when enabled, the *_dev calls bracket their
+ * dominant ("chain") kernel with HIP events on the same stream; after synchronising, this
+ * returns the accumulated milliseconds and launch count since the last reset. */
+void rans4x16_hip_timing(rans4x16_hip_ctx *ctx, int enable);
+int  rans4x16_hip_timing_read(rans4x16_hip_ctx *ctx, int which /*0 enc chain, 1 dec chain*/,
+                              double *ms_total, int *launches, int reset);
+
+/* Library/ABI version and the gfx target the code object was built for. */
+const char *rans4x16_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RANS4X16_HIP_H */
