@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: rANS 4x16 order-1 encode + decode of 1 MiB q40 blocks.
+
+One *step* = one pass of the hot path over one batch of blocks that already lives in HBM:
+rans4x16_hip_compress_dev over the whole batch, then rans4x16_hip_uncompress_dev over the result
+(the shape of the reference's own `rans4x16pr -t` loop, tests/rANS_static4x16pr_test.c:180-222,
+with the serial per-block loop replaced by batch calls).
+
+  value      MB/s (1e6 B/s) of UNCOMPRESSED bytes through encode+decode: batch bytes / (t_enc+t_dec)
+  roofline   for the slowest kernel of the step: algorithmic bytes (uncompressed + compressed,
+             SURVEY.md §8d) / its HIP-event time, against the 8 TB/s HBM peak
+  cpu_baseline  the reference C library (oracle/_ref, built from the untouched sources) — or the
+             oracle port when that .so is absent — timed on this host's cores on a bounded sample
+
+Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 under torch.distributed.run
+(one rank per GPU; blocks are independent, so ranks share nothing but the final barrier/max).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def build_batch(torch, dev, name, nblk, blk_size, first_block):
+    """nblk blocks of the cyclic repetition of base text `name`, uploaded to HBM."""
+    import datagen
+    base = datagen.base_text(name)
+    reps = (nblk * blk_size + 2 * len(base)) // len(base) + 2
+    start = (first_block * blk_size) % len(base)
+    host = np.tile(base, reps)[start:start + nblk * blk_size]
+    d_in = torch.from_numpy(np.ascontiguousarray(host)).to(dev)
+    in_off = torch.arange(nblk, dtype=torch.int64, device=dev) * blk_size
+    in_size = torch.full((nblk,), blk_size, dtype=torch.int32, device=dev)
+    return host, d_in, in_off, in_size
+
+
+def cpu_baseline(order, blk_size, name, seconds_target=12.0):
+    """Time the CPU reference on a bounded sample of the same workload (rank 0, N=1 only)."""
+    import cpu_libs
+    import datagen
+    lib = cpu_libs.reference()
+    kind = "reference"
+    if lib is None:
+        lib, kind = cpu_libs.oracle(), "port"
+    # one GPU's share of the host is 16 cores on the bench pool; never oversubscribe beyond that
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("R4X16_CPU_THREADS", 16)))
+    blocks = [np.ascontiguousarray(datagen.tile(name, blk_size, b)) for b in range(cores)]
+    cap = lib.bound(blk_size, order)
+
+    def one(idx, reps):
+        src = blocks[idx % len(blocks)]
+        comp = np.zeros(cap + 16, dtype=np.uint8)
+        back = np.zeros(blk_size + 16, dtype=np.uint8)
+        t_enc = t_dec = 0.0
+        for _ in range(reps):
+            n = C.c_uint(cap)
+            t0 = time.perf_counter()
+            r = lib.compress_to(src.ctypes.data, blk_size, comp.ctypes.data, C.byref(n), order)
+            t1 = time.perf_counter()
+            m = C.c_uint(blk_size)
+            r2 = lib.uncompress_to(comp.ctypes.data, n.value, back.ctypes.data, C.byref(m))
+            t2 = time.perf_counter()
+            assert r and r2 and m.value == blk_size
+            t_enc += t1 - t0
+            t_dec += t2 - t1
+        assert (back[:blk_size] == src).all()
+        return t_enc, t_dec
+
+    te, td = one(0, 3)                                   # calibrate: seconds per block
+    per_blk = (te + td) / 3
+    reps = max(2, int(seconds_target / per_blk / 3))     # ~1/3 of the budget single-threaded
+    te1, td1 = one(0, reps)
+    one_thread = blk_size * reps / (te1 + td1) / 1e6
+    reps_mt = max(2, int(seconds_target / per_blk / 2))  # ~1/2 of the budget (wall) on all threads
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:                # ctypes drops the GIL: real parallelism
+        list(ex.map(lambda i: one(i, reps_mt), range(cores)))
+    wall = time.perf_counter() - t0
+    all_cores = blk_size * reps_mt * cores / wall / 1e6
+    return {
+        "value": round(all_cores, 1), "unit": "MB/s", "cores": cores, "kind": kind,
+        "sample": f"{reps_mt} x {cores} blocks of {blk_size} B ({name}, order {order}), encode+decode, "
+                  f"one thread per core",
+        "value_1thread": round(one_thread, 1), "enc_1thread": round(blk_size * reps / te1 / 1e6, 1),
+        "dec_1thread": round(blk_size * reps / td1 / 1e6, 1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--blocks", type=int, default=int(os.environ.get("R4X16_BLOCKS", 4096)))
+    ap.add_argument("--block-size", type=int, default=1 << 20)
+    ap.add_argument("--data", default="q40+dir")
+    ap.add_argument("--order", type=int, default=1)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import htscodecs_amd as H
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    nblk, bs, order = args.blocks, args.block_size, args.order
+    dc = H.DeviceCodec(local)
+    host, d_in, in_off, in_size = build_batch(torch, dev, args.data, nblk, bs, rank * nblk)
+    cap = H.rans_compress_bound_4x16(bs, order)
+    slot = (cap + 255) // 256 * 256
+    d_comp = torch.zeros(nblk * slot, dtype=torch.uint8, device=dev)
+    comp_off = torch.arange(nblk, dtype=torch.int64, device=dev) * slot
+    comp_cap = torch.full((nblk,), cap, dtype=torch.int32, device=dev)
+    comp_size = torch.zeros(nblk, dtype=torch.int32, device=dev)
+    st_enc = torch.zeros(nblk, dtype=torch.int32, device=dev)
+    d_back = torch.zeros_like(d_in)
+    back_size = torch.zeros(nblk, dtype=torch.int32, device=dev)
+    st_dec = torch.zeros(nblk, dtype=torch.int32, device=dev)
+
+    def step(ev=None):
+        dc.compress(d_in, in_off, in_size, d_comp, comp_off, comp_cap, comp_size, st_enc, order, bs)
+        if ev is not None:
+            ev.record()
+        dc.uncompress(d_comp, comp_off, comp_size, d_back, in_off, in_size, back_size, st_dec, cap, bs)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    dc.timing(True)
+    dc.timing_read(0); dc.timing_read(1)
+    mids = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    begs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        begs[k].record()
+        step(mids[k])
+        ends[k].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dc.timing(False)
+    enc_chain_ms, enc_launches = dc.timing_read(0)
+    dec_chain_ms, dec_launches = dc.timing_read(1)
+    t_enc = sum(b.elapsed_time(m) for b, m in zip(begs, mids)) / 1e3 / args.steps
+    t_dec = sum(m.elapsed_time(e) for m, e in zip(mids, ends)) / 1e3 / args.steps
+
+    # ---- correctness gate: every block decodes to its input; a sample is bit-compared with the CPU
+    assert int((st_enc != 0).sum()) == 0 and int((st_dec != 0).sum()) == 0, "device reported failures"
+    assert torch.equal(d_back, d_in), "round trip mismatch"
+    csz = comp_size.cpu().numpy()
+    if rank == 0:
+        import cpu_libs
+        chk = cpu_libs.reference() or cpu_libs.oracle()
+        for b in (0, nblk // 2, nblk - 1):
+            want = chk.compress(host[b * bs:(b + 1) * bs].tobytes(), order)
+            got = d_comp[b * slot:b * slot + int(csz[b])].cpu().numpy().tobytes()
+            assert got == want, f"block {b}: device stream differs from the CPU reference"
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        total_unc = nblk * bs * world
+        comp_bytes = int(csz.sum())
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_unc / (elapsed / args.steps) / 1e6
+        # dominant kernel = the slower chain kernel; algorithmic bytes = uncompressed + compressed
+        enc_avg = enc_chain_ms / max(enc_launches, 1)
+        dec_avg = dec_chain_ms / max(dec_launches, 1)
+        launches_per_step = max(enc_launches, 1) / args.steps
+        if enc_avg >= dec_avg:
+            kname, kavg = "k_enc_chain", enc_avg
+        else:
+            kname, kavg = "k_dec_chain", dec_avg
+        alg_bytes = (nblk * bs + comp_bytes) / launches_per_step
+        achieved = alg_bytes / (kavg / 1e3) / 1e9
+        out = {
+            "metric": "MB/s uncompressed throughput (encode+decode), rANS4x16 order-1, q40 blocks",
+            "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8/u32", "data": "synthetic",
+            "config": {"workload": f"rANS4x16 order-{order & 1} encode+decode, {nblk} x {bs} B {args.data} "
+                                   f"blocks per GPU (cyclic tiles of tests/dat/{args.data}), device-resident",
+                       "order": order, "blocks_per_gpu": nblk, "block_size": bs,
+                       "ratio": round(comp_bytes / (nblk * bs), 4)},
+            "enc_MBps": round(nblk * bs / t_enc / 1e6, 1), "dec_MBps": round(nblk * bs / t_dec / 1e6, 1),
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": None, "avg_kernel_ms": round(kavg, 3),
+                         "enc_chain_ms": round(enc_avg, 3), "dec_chain_ms": round(dec_avg, 3),
+                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+            "workspace_GB": round(dc.workspace_bytes() / 2**30, 2),
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(order, bs, args.data)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
