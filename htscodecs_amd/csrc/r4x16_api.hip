@@ -18,7 +18,7 @@
 
 extern "C" {
 void r4x16_launch_dec_front(const BatchArgs *, const DecWs *, int, int, hipStream_t);
-void r4x16_launch_dec_chain(const DecWs *, int, int, u32, hipStream_t);
+void r4x16_launch_dec_chain(const DecWs *, int, hipStream_t);
 void r4x16_launch_dec_back(const BatchArgs *, const DecWs *, int, int, hipStream_t);
 void r4x16_launch_enc_front(const BatchArgs *, const EncWs *, int, int, hipStream_t);
 void r4x16_launch_enc_chain(const EncWs *, int, int, hipStream_t);
@@ -272,7 +272,7 @@ extern "C" int rans4x16_hip_uncompress_dev(rans4x16_hip_ctx *c, int n,
         r4x16_launch_dec_front(&a, &w, (int)base, nb, s);
         TimedLaunch t;
         if (c->timing) time_begin(c, 1, s, t);
-        r4x16_launch_dec_chain(&w, 2 * nb, 16, 0, s);
+        r4x16_launch_dec_chain(&w, 2 * nb, s);
         if (c->timing) time_end(c, 1, s, t);
         r4x16_launch_dec_back(&a, &w, (int)base, nb, s);
     }

@@ -46,7 +46,7 @@ typedef int32_t  i32;
 //   +0              u32 hdr      : byte value of this context | ROW_EMPTY flag | nnz << 16
 //   +4              u8  coarse[C]: C = 1 << (look-2); coarse[c] = index r of the entry that owns
 //                                  slot 4*c
-//   +4+C            u32 ent[nnz+4]: ent[r] = start_r | (link_r << 16) for the nnz symbols with a
+//   +4+C            u32 ent[nnz+4]: ent[r] = link_r | (start_r << 16) for the nnz symbols with a
 //                                  non-zero frequency, in symbol order; then a terminal entry
 //                                  with start = 1 << bits, then three pads with start 0xFFFF.
 //                                  link = (offset of that symbol's own row) / 16 for order-1,
@@ -154,7 +154,7 @@ struct EncDesc {
 
 struct DecWs {
     DecDesc *desc;     // [nblk]
-    DecItem *items;    // [2*nblk]   2b = payload stream, 2b+1 = RLE meta stream
+    DecItem *items;    // [2*nblk]   [b] = payload stream of block b, [nblk+b] = its RLE meta stream
     u8 *images;        // [nblk][DEC_IMG_SLOT]
     u8 *tbuf;          // [nblk][TBUF_BYTES]
     u8 *tmp;           // [nblk][tmp_stride]   stage buffer for PACK / RLE
@@ -164,7 +164,7 @@ struct DecWs {
 
 struct EncWs {
     EncDesc *desc;      // [nblk]
-    EncItem *items;     // [2*nblk]  2b = payload stream, 2b+1 = RLE meta stream
+    EncItem *items;     // [2*nblk]  [b] = payload stream of block b, [nblk+b] = its RLE meta stream
     u8 *images;         // [nblk][ENC_IMG_BYTES]
     u8 *tabraw;         // [nblk][TAB_BYTES]  serialised order-1 table before nesting
     u8 *tab;            // [nblk][TAB_BYTES]  table bytes as they go into the stream

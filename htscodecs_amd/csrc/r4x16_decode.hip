@@ -14,9 +14,9 @@
 
 // ---- image access: global memory or LDS ------------------------------------------------------
 struct GImg {
-    const u8 *p;
+    gcu8 *p;
     __device__ __forceinline__ u32 ld8(u32 off) const { return p[off]; }
-    __device__ __forceinline__ u32 ld32(u32 off) const { return *(const u32 *)(p + off); }
+    __device__ __forceinline__ u32 ld32(u32 off) const { return *(gcu32 *)(p + off); }
 };
 struct LImg {
     const u8 *p;     // points into __shared__
@@ -24,9 +24,34 @@ struct LImg {
     __device__ __forceinline__ u32 ld32(u32 off) const { return *(const u32 *)(p + off); }
 };
 
+// One table lookup + state update (rANS_static4x16pr.c:576-579 / :1033-1035).
+//   r = coarse[m>>2]; refine over at most three following entries; x = freq*(x>>look) + m - start
+// Entries carry the start in their HIGH half, so "m >= start_k" is one compare of the whole
+// dword against (m<<16 | 0xffff).  Returns the chosen entry (its low half is the link).
+template <class IMG>
+__device__ __forceinline__ u32 lookup_step(const IMG &img, u32 row, u32 cells, u32 look, u32 mask, u32 &x)
+{
+    const u32 m = x & mask;
+    const u32 r = img.ld8(row + 4 + (m >> 2));
+    const u32 eb = row + 4 + cells + 4 * r;
+    const u32 e0 = img.ld32(eb), e1 = img.ld32(eb + 4), e2 = img.ld32(eb + 8),
+              e3 = img.ld32(eb + 12), e4 = img.ld32(eb + 16);
+    const u32 key = (m << 16) | 0xffffu;
+    u32 e = e0, en = e1;
+    if (key >= e1) { e = e1; en = e2; }
+    if (key >= e2) { e = e2; en = e3; }
+    if (key >= e3) { e = e3; en = e4; }
+    const u32 start = e >> 16;
+    const u32 freq = (en >> 16) - start;
+    x = __umul24(freq, x >> look) + (m - start);      // freq <= 2^15, x>>look < 2^22: exact mod 2^32
+    return e;
+}
+
 // ---------------------------------------------------------------------------------------------
-// The chain decoder.  Every lane of the wave calls this; lane&3 selects the chain, lane>>2 the
-// stream.  Per step and chain (rANS_static4x16pr.c:576-597 / :1033-1059):
+// The chain decoder, general form: image and words read straight from global memory.  Used for
+// the small nested streams inside k_dec_front and for images too large for LDS.
+// Every lane of the wave calls this; lane&3 selects the chain, lane>>2 the stream.
+// Per step and chain (rANS_static4x16pr.c:576-597 / :1033-1059):
 //     m = x & mask;  (start,freq,symbol) = lookup(context, m);
 //     x = freq * (x >> look) + m - start;
 //     if (x < 2^15 and two more bytes exist) x = (x << 16) | next word
@@ -36,7 +61,7 @@ struct LImg {
 // Returns non-zero if a context without a table row was used.
 // ---------------------------------------------------------------------------------------------
 template <int ORDER, class IMG>
-__device__ __forceinline__ u32 chain_decode(IMG img, const u8 *words, u32 words_len, u8 *out,
+__device__ __forceinline__ u32 chain_decode(IMG img, gcu8 *words, u32 words_len, gu8 *out,
                                             u32 out_sz, u32 x, u32 look, bool active, u32 lane)
 {
     const u32 k = lane & 3;
@@ -61,25 +86,12 @@ __device__ __forceinline__ u32 chain_decode(IMG img, const u8 *words, u32 words_
         const bool live = t < count;
         bool want = false;
         if (live) {
-            const u32 m = x & mask;
-            const u32 r = img.ld8(row + 4 + (m >> 2));
-            const u32 eb = row + 4 + cells + 4 * r;
-            const u32 e0 = img.ld32(eb), e1 = img.ld32(eb + 4), e2 = img.ld32(eb + 8),
-                      e3 = img.ld32(eb + 12), e4 = img.ld32(eb + 16);
-            u32 e = e0, en = e1;
-            if (m >= (e1 & 0xffffu)) { e = e1; en = e2; }
-            if (m >= (e2 & 0xffffu)) { e = e2; en = e3; }
-            if (m >= (e3 & 0xffffu)) { e = e3; en = e4; }
-            const u32 start = e & 0xffffu;
-            const u32 freq = (en & 0xffffu) - start;
-            x = freq * (x >> look) + m - start;
-            u32 byte;
+            const u32 e = lookup_step(img, row, cells, look, mask, x);
             if (ORDER == 0) {
-                byte = e >> 16;
-                out[pos] = (u8)byte;
+                out[pos] = (u8)e;
                 pos += 4;
             } else {
-                row = (e >> 16) << 4;
+                row = (e & 0xffffu) << 4;
                 const u32 hdr = img.ld32(row);
                 if (t + 1 < count) bad |= hdr & ROW_EMPTY;
                 out[pos] = (u8)hdr;
@@ -97,6 +109,153 @@ __device__ __forceinline__ u32 chain_decode(IMG img, const u8 *words, u32 words_
         }
         cursor += __popc(quad_ballot(take, lane));
         t++;
+    }
+    return bad;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The chain decoder, hot form.  Same arithmetic; everything on the dependent path lives in LDS:
+//   * the image (copied once per stream),
+//   * a 128-byte ring of the compressed words per stream, refilled 64 bytes at a time with
+//     16-byte global loads issued one refill ahead, so HBM/L2 latency never sits on the chain;
+//     the next four candidate words are read from the ring at the top of each step, in parallel
+//     with the table lookups, and the right one is picked once the quad ballot is known;
+//   * decoded bytes are gathered four at a time per chain and stored as dwords (order-1), so a
+//     wave issues one store per four symbols instead of four.
+// LDS per stream: image, then RING_BYTES.
+// ---------------------------------------------------------------------------------------------
+#define RING_BYTES 144u      // 128-byte ring + 8-byte mirror of its head (+8 pad)
+
+typedef u32 GAS __attribute__((aligned(1))) gu32_unaligned;   // global dword store at any byte address
+
+template <int ORDER>
+__device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u8 *ring, gcu8 *words, u32 words_len,
+                                                gu8 *out, u32 out_sz, u32 x, u32 look, bool active, u32 lane)
+{
+    const LImg img{img_lds};
+    const u32 k = lane & 3;
+    const u32 mask = (1u << look) - 1;
+    const u32 cells = 1u << (look - 2);
+    const u32 nwords = words_len >> 1;
+    const u32 below = (1u << k) - 1u;                      // quad lanes below this one
+    const u32 qshift = lane & ~3u;
+    u32 count;
+    gu8 *op;                                               // next output byte of this chain
+    if (ORDER == 0) {
+        count = (out_sz + 3 - k) >> 2;
+        op = out + k;
+    } else {
+        const u32 q = out_sz >> 2;
+        count = q + (k == 3 ? out_sz - 4 * q : 0);
+        op = out + (u64)k * q;
+    }
+    if (!active) count = 0;
+
+    // ---- word ring: stream bytes relative to the 16-byte aligned address below `words` ----------
+    gcu8 *abase = (gcu8 *)((u64)words & ~15ull);
+    const u32 off0 = (u32)((u64)words & 15ull);
+    const u32 avail = off0 + words_len;                   // bytes of abase[] that belong to the input
+    auto load_chunk = [&](u32 c) -> u32x4 {               // 16-byte chunk c, zeros past the input
+        u32x4 v = {0, 0, 0, 0};
+        if (active && c * 16u < avail) v = *(gcu32x4 *)(abase + (u64)c * 16u);
+        return v;
+    };
+    if (active) {
+        const u32x4 c0 = load_chunk(k), c1 = load_chunk(k + 4);
+        *(u32x4 *)(ring + 16 * k) = c0;
+        *(u32x4 *)(ring + 64 + 16 * k) = c1;
+        if (k == 0) *(u32x2 *)(ring + 128) = c0.xy;
+    }
+    u32x4 pend = load_chunk(8 + k);                       // half 2, written at the first crossing
+    u32 half = 0;                                         // index of the 64-byte half holding the cursor
+    __syncthreads();
+
+    u32 row = 0, cursor = 0, bad = 0, t = 0;
+    u32 acc = 0;                                          // order-1: the last (up to) 4 decoded bytes
+    u32 hdr = 0;                                          // order-1: header of the row entered last step
+    if (ORDER == 1 && count) bad = img.ld32(0) & ROW_EMPTY;
+
+    // Four steps per trip: one loop test, one dword store and one ring check per trip.
+    while (wave_any(t < count)) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool live = (t + u) < count;
+            // next four candidate words (8 bytes at any byte alignment) from the ring; issued
+            // before the table lookups so that their latency hides under them
+            const u32 cb = off0 + 2 * cursor;
+            const u32 ra = cb & 124u;
+            // (volatile: keeps the compiler from sinking these reads into the refill branch, which
+            //  would put their latency back on the dependent path)
+            const u32 d0 = *(const volatile u32 *)(ring + ra), d1 = *(const volatile u32 *)(ring + ra + 4),
+                      d2 = *(const volatile u32 *)(ring + ra + 8);
+            const u32 sh = (cb & 3u) * 8u;
+
+            u32 xn = x;
+            const u32 e = lookup_step(img, row, cells, look, mask, xn);
+            u32 byte0 = 0;
+            if (ORDER == 0) {
+                byte0 = e & 0xffu;
+            } else {
+                // the byte of the symbol decoded one step ago and the flags of the row in use now
+                if (u > 0 || t > 0) {
+                    if (live) bad |= hdr & ROW_EMPTY;
+                    acc = (t + u <= count) ? __builtin_amdgcn_alignbit(hdr, acc, 8) : acc;
+                }
+                // symbols t-4 .. t-1 are now in acc, oldest in the low byte
+                if (u == 0 && t >= 4 && t <= count) { *(gu32_unaligned *)op = acc; op += 4; }
+                const u32 rown = (e & 0xffffu) << 4;
+                const u32 hn = img.ld32(rown);
+                hdr = live ? hn : hdr;
+                row = live ? rown : row;
+            }
+            x = live ? xn : x;
+            const bool want = live && x < RANS_LOW;
+
+            // renormalise: chains refill in order 0..3 from the shared cursor.  After the first
+            // refusal (stream exhausted) no later request can succeed either, so the cursor may
+            // simply advance by the number of requests (rANS_word.h:402-410).
+            const u64 wb = __ballot(want);
+            const u32 wm = (u32)(wb >> qshift) & 0xfu;
+            const u32 pre = __popc(wm & below);
+            const bool take = want && cursor + pre < nwords;
+            const u32 wlo = __builtin_amdgcn_alignbit(d1, d0, sh), whi = __builtin_amdgcn_alignbit(d2, d1, sh);
+            const u32 w2 = (pre & 2u) ? whi : wlo;
+            const u32 w = (w2 >> ((pre & 1u) * 16u)) & 0xffffu;
+            x = take ? ((x << 16) | w) : x;
+            cursor += __popc(wm);
+
+            if (ORDER == 0) {
+                // the quad's four bytes are consecutive: lane 0 stores them as one dword
+                const u32 b1 = quad_bcast1(byte0), b2 = quad_bcast2(byte0), b3 = quad_bcast3(byte0);
+                const u32 l3 = quad_bcast3(live ? 1u : 0u);
+                const u32 dw = byte0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+                if (l3) { if (k == 0) *(gu32_unaligned *)(op + 4 * (u64)(t + u)) = dw; }
+                else if (live) op[4 * (u64)(t + u)] = (u8)byte0;
+            }
+        }
+        t += 4;
+
+        // ring refill when the cursor has entered a new 64-byte half (at most 32 bytes ago)
+        const u32 nh = (off0 + 2 * cursor) >> 6;
+        if (wave_any(nh != half)) {
+            if (nh != half) {
+                // half `nh+1` was requested at the previous crossing: park it in the slots just vacated
+                const u32 slot = ((nh + 1) & 1u) * 64u + 16u * k;
+                *(u32x4 *)(ring + slot) = pend;
+                if (slot == 0) *(u32x2 *)(ring + 128) = pend.xy;
+                pend = load_chunk(4 * (nh + 2) + k);
+                half = nh;
+            }
+            __syncthreads();
+        }
+    }
+    if (ORDER == 1 && count) {
+        // t steps ran.  A chain whose count equals t still has its last byte in hdr and its last
+        // four symbols unstored; any other chain has count%4 symbols left, already in acc.
+        u32 stored = count & ~3u;
+        if (count == t) { acc = __builtin_amdgcn_alignbit(hdr, acc, 8); stored = t - 4; }
+        const u32 rem = count - stored;                    // 0..4, in the top `rem` bytes of acc
+        for (u32 j = 0; j < rem; j++) op[j] = (u8)(acc >> (8 * (4 - rem + j)));
     }
     return bad;
 }
@@ -164,12 +323,12 @@ __device__ bool make_entries(FrontShared &S, const u8 *in_alphabet, u32 total, u
         const u32 f = S.F[j] << sh;
         if (!f) continue;
         if (f > (1u << bits) - x) return false;
-        S.ent[nnz++] = x | (link_of(j) << 16);
+        S.ent[nnz++] = (x << 16) | link_of(j);
         x += f;
     }
     if (x != (1u << bits)) return false;
-    S.ent[nnz] = (1u << bits);
-    S.ent[nnz + 1] = S.ent[nnz + 2] = S.ent[nnz + 3] = 0xffffu;
+    S.ent[nnz] = (1u << bits) << 16;
+    S.ent[nnz + 1] = S.ent[nnz + 2] = S.ent[nnz + 3] = 0xffff0000u;
     S.nnz = nnz;
     return true;
 }
@@ -184,11 +343,11 @@ __device__ void write_row(u8 *rowp, const FrontShared &S, u32 look, u32 lane)
     if (lane == 0) *(u32 *)rowp = S.hdr | (nnz << 16);
     if (nnz == 0) {
         for (u32 c = lane; c < cells; c += WAVE) coarse[c] = 0;
-        if (lane < 4) ent[lane] = lane == 0 ? 0u : 0xffffu;       // in-bounds garbage, flagged EMPTY
+        if (lane < 5) ent[lane] = lane == 0 ? 0u : 0xffff0000u;   // in-bounds filler, row is flagged EMPTY
         return;
     }
     for (u32 r = lane; r < nnz; r += WAVE) {
-        const u32 lo = S.ent[r] & 0xffffu, hi = S.ent[r + 1] & 0xffffu;
+        const u32 lo = S.ent[r] >> 16, hi = S.ent[r + 1] >> 16;
         u32 c0 = (lo + 3) >> 2, c1 = (hi + 3) >> 2;
         if (c1 > cells) c1 = cells;
         for (u32 c = c0; c < c1; c++) coarse[c] = (u8)r;
@@ -260,7 +419,7 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
     const u32 b = blockIdx.x;
     const int i = base + (int)b;
     DecDesc *D = &ws.desc[b];
-    DecItem *I0 = &ws.items[2 * b], *I1 = &ws.items[2 * b + 1];
+    DecItem *I0 = &ws.items[b], *I1 = &ws.items[gridDim.x + b];   // payload items first, meta items after
     const u8 *in = a.in + a.in_off[i];
     const u32 in_size = a.in_size[i];
     const u32 cap = a.out_cap[i];
@@ -371,8 +530,8 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
         o0_front(src, H.tab_pos, H.csz, H.usz, img0, S, lane);
         if (S.status != ST_OK) { if (lane == 0) D->status = S.status; return; }
         __threadfence();
-        GImg g{img0};
-        chain_decode<0>(g, in + S.words_pos, H.tab_pos + H.csz - S.words_pos, tbuf, H.usz,
+        GImg g{to_global((const u8 *)img0)};
+        chain_decode<0>(g, to_global(in + S.words_pos), H.tab_pos + H.csz - S.words_pos, to_global(tbuf), H.usz,
                         S.R[lane & 3], O0_BITS, lane < 4, lane);
         __threadfence();
         __syncthreads();
@@ -476,11 +635,15 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_dec_chain: QPW streams per wave (one per quad).  LDS_IMG: stage each stream's image in LDS.
+// k_dec_chain: QPW streams per wave (one per quad).
+// The host cannot know image sizes without a device->host round trip, so it launches one grid
+// per LDS size class; a stream runs in the launch whose class (lo, hi] contains its LDS need
+// (image + word ring) and every other wave exits at once.  LDS_IMG=false is the catch-all for
+// images too big for LDS (lo = largest class).
 // ---------------------------------------------------------------------------------------------
 template <bool LDS_IMG>
 __global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDesc *desc, int nitems,
-                                                    int qpw, u32 lds_per_item)
+                                                    int qpw, u32 lds_per_item, u32 cls_lo, u32 cls_hi)
 {
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
     const u32 lane = threadIdx.x;
@@ -488,10 +651,15 @@ __global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDes
     const int it = (int)blockIdx.x * qpw + (int)quad;
     const bool mine = quad < (u32)qpw && it < nitems;
     const DecItem *I = &items[mine ? it : 0];
-    const bool active = mine && I->active;
+    bool active = mine && I->active;
+    const u32 img_bytes = active ? I->img_bytes : 0u;
+    const u32 need = img_bytes + RING_BYTES;
+    active = active && need > cls_lo && need <= cls_hi;
+    if (!wave_any(active)) return;
+
     // fields are read one by one (a register copy of the struct indexed by lane would spill)
-    const u8 *words = (const u8 *)I->words;
-    u8 *out = (u8 *)I->out;
+    gcu8 *words = (gcu8 *)I->words;
+    gu8 *out = (gu8 *)I->out;
     const u32 words_len = I->words_len, out_sz = I->out_sz, look = active ? I->look : 12u;
     const u32 order = active ? I->order : 2u;
     const u32 x0 = I->R[lane & 3];
@@ -500,24 +668,24 @@ __global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDes
     if (LDS_IMG) {
         // cooperative copy: the whole wave copies each quad's image in turn (16-byte pieces)
         const u64 my_img = active ? I->image : 0ull;
-        const u32 my_nb = active ? I->img_bytes : 0u;
         for (int qd = 0; qd < qpw; qd++) {
             const u64 src = __shfl(my_img, qd * 4);
-            const u32 nb = __shfl(my_nb, qd * 4);
+            const u32 nb = __shfl(img_bytes, qd * 4);
             if (!src) continue;
-            const uint4 *s = (const uint4 *)src;
-            uint4 *d = (uint4 *)(lds + (u64)qd * lds_per_item);
-            for (u32 j = lane; j < (nb >> 4); j += WAVE) d[j] = s[j];
+            gcu32x4 *s = (gcu32x4 *)src;
+            u32x4 *dd = (u32x4 *)(lds + (u64)qd * lds_per_item);
+            for (u32 j = lane; j < (nb >> 4); j += WAVE) dd[j] = s[j];
         }
         __syncthreads();
-        LImg im{lds + (u64)quad * lds_per_item};
+        const u8 *im = lds + (u64)quad * lds_per_item;
+        u8 *ring = lds + (u64)quad * lds_per_item + (lds_per_item - RING_BYTES);
         // order-0 and order-1 streams may share a wave: run the two loops back to back
-        bad = chain_decode<1>(im, words, words_len, out, out_sz, x0, look, order == 1, lane);
-        bad |= chain_decode<0>(im, words, words_len, out, out_sz, x0, look, order == 0, lane);
+        bad = chain_decode_lds<1>(im, ring, words, words_len, out, out_sz, x0, look, active && order == 1, lane);
+        bad |= chain_decode_lds<0>(im, ring, words, words_len, out, out_sz, x0, look, active && order == 0, lane);
     } else {
-        GImg im{(const u8 *)I->image};
-        bad = chain_decode<1>(im, words, words_len, out, out_sz, x0, look, order == 1, lane);
-        bad |= chain_decode<0>(im, words, words_len, out, out_sz, x0, look, order == 0, lane);
+        GImg im{(gcu8 *)I->image};
+        bad = chain_decode<1>(im, words, words_len, out, out_sz, x0, look, active && order == 1, lane);
+        bad |= chain_decode<0>(im, words, words_len, out, out_sz, x0, look, active && order == 0, lane);
     }
     if (active && bad) desc[I->blk].status = ST_CONTEXT;
 }
@@ -544,15 +712,27 @@ extern "C" void r4x16_launch_dec_front(const BatchArgs *a, const DecWs *ws, int 
 {
     hipLaunchKernelGGL(k_dec_front, dim3(nblk), dim3(WAVE), 0, s, *a, *ws, base);
 }
-extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, int qpw, u32 lds_per_item, hipStream_t s)
+// LDS size classes: {bytes per stream, streams per wave}.  Streams per CU = floor(160 KB / (qpw*bytes)) * qpw.
+static const struct { u32 bytes; int qpw; } DEC_CLASSES[] = {
+    {2560, 16}, {5120, 8}, {10240, 4}, {16384, 1}, {22528, 1}, {40960, 1}, {81920, 1}, {163840, 1},
+};
+extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t s)
 {
-    const int grid = (nitems + qpw - 1) / qpw;
-    if (lds_per_item)
-        hipLaunchKernelGGL(k_dec_chain<true>, dim3(grid), dim3(WAVE), (size_t)qpw * lds_per_item, s,
-                           ws->items, ws->desc, nitems, qpw, lds_per_item);
-    else
-        hipLaunchKernelGGL(k_dec_chain<false>, dim3(grid), dim3(WAVE), 0, s,
-                           ws->items, ws->desc, nitems, qpw, 0u);
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute((const void *)k_dec_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        once = true;
+    }
+    u32 lo = 0;
+    for (const auto &c : DEC_CLASSES) {
+        const int grid = (nitems + c.qpw - 1) / c.qpw;
+        hipLaunchKernelGGL(k_dec_chain<true>, dim3(grid), dim3(WAVE), (size_t)c.qpw * c.bytes, s,
+                           ws->items, ws->desc, nitems, c.qpw, c.bytes, lo, c.bytes);
+        lo = c.bytes;
+    }
+    const int grid = (nitems + 15) / 16;
+    hipLaunchKernelGGL(k_dec_chain<false>, dim3(grid), dim3(WAVE), 0, s,
+                       ws->items, ws->desc, nitems, 16, 0u, lo, 0xffffffffu);
 }
 extern "C" void r4x16_launch_dec_back(const BatchArgs *a, const DecWs *ws, int base, int nblk, hipStream_t s)
 {

@@ -5,6 +5,22 @@
 
 #define WAVE 64
 
+// Pointers rebuilt from 64-bit fields are "generic" to the compiler, which then emits FLAT
+// loads/stores.  FLAT operations count on lgkmcnt as well as vmcnt, so every wait for an LDS
+// read would also wait for outstanding HBM stores.  The hot loops therefore use explicit
+// global-address-space pointers (global_load / global_store, vmcnt only).
+#define GAS __attribute__((address_space(1)))
+typedef GAS u8        gu8;
+typedef GAS const u8  gcu8;
+typedef GAS u16       gu16;
+typedef GAS u32       gu32;
+typedef GAS const u32 gcu32;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef GAS const u32x4 gcu32x4;
+template <class T> __device__ __forceinline__ GAS T *to_global(T *p) { return (GAS T *)p; }
+template <class T> __device__ __forceinline__ GAS const T *to_global(const T *p) { return (GAS const T *)p; }
+
 // Arguments of a device-resident batch (include/rans4x16_hip.h, *_dev entry points).
 struct BatchArgs {
     const u8  *in;

@@ -111,9 +111,12 @@ __device__ __forceinline__ EncEntry make_entry(u32 start, u32 freq, u32 bits)
 // in chain order 3,2,1,0 onto a descending pointer, so chain k's word lands
 // 2 * (1 + #emitting chains above k) below the step's starting pointer.
 // ---------------------------------------------------------------------------------------------
+typedef GAS const EncEntry gcEncEntry;
+typedef GAS const u16 gcu16;
+
 template <int ORDER>
-__device__ __forceinline__ u32 chain_encode(const u8 *data, u32 n, const EncEntry *img,
-                                            const u16 *ctxrow, u32 bits, u8 *scratch_end,
+__device__ __forceinline__ u32 chain_encode(gcu8 *data, u32 n, gcEncEntry *img,
+                                            gcu16 *ctxrow, u32 bits, gu8 *scratch_end,
                                             bool active, u32 lane)
 {
     const u32 k = lane & 3;
@@ -156,7 +159,7 @@ __device__ __forceinline__ u32 chain_encode(const u8 *data, u32 n, const EncEntr
                 if (!at_start) { nextc = data[p - 1]; row = ctxrow[nextc]; }
                 else row = row0;
             }
-            e = img[row * 256u + cur];
+            { const gcEncEntry *ep = &img[row * 256u + cur]; e.rcp = ep->rcp; e.pk = ep->pk; }
             const u32 cmpl = (e.pk >> 13) & 0x1fffu;
             const u32 x_max = ((1u << bits) - cmpl) << (31 - bits);
             emit = x >= x_max;
@@ -164,7 +167,7 @@ __device__ __forceinline__ u32 chain_encode(const u8 *data, u32 n, const EncEntr
         const u32 em = quad_ballot(emit, lane);
         if (emit) {
             const u32 above = __popc(em >> (k + 1));
-            *(u16 *)(scratch_end - 2 * (written + above + 1)) = (u16)x;
+            *(gu16 *)(scratch_end - 2 * (written + above + 1)) = (u16)x;
             x >>= 16;
         }
         written += __popc(em);
@@ -176,7 +179,7 @@ __device__ __forceinline__ u32 chain_encode(const u8 *data, u32 n, const EncEntr
         }
     }
     // RansEncFlush x4 in order 3,2,1,0 (:482-485): R0 ends up lowest in memory
-    if (active) *(u32 *)(scratch_end - 2 * written - 16 + 4 * k) = x;
+    if (active) *(gu32 *)(scratch_end - 2 * written - 16 + 4 * k) = x;
     return active ? 2 * written + 16 : 0;
 }
 
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
     const u32 b = blockIdx.x;
     const int i = base + (int)b;
     EncDesc *D = &ws.desc[b];
-    EncItem *I0 = &ws.items[2 * b], *I1 = &ws.items[2 * b + 1];
+    EncItem *I0 = &ws.items[b], *I1 = &ws.items[gridDim.x + b];   // payload items first, meta items after
     const u8 *in = a.in + a.in_off[i];
     const u32 in_size = a.in_size[i];
     const u32 cap = a.out_cap[i];
@@ -548,7 +551,8 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
         enc_o0_front(tabraw, tlen, ntab, img0, S, lane);
         __threadfence();
         __syncthreads();
-        const u32 npay = chain_encode<0>(tabraw, tlen, img0, nullptr, O0_BITS, scratch_end, lane < 4, lane);
+        const u32 npay = chain_encode<0>(to_global((const u8 *)tabraw), tlen, to_global((const EncEntry *)img0), (gcu16 *)nullptr,
+                                         O0_BITS, to_global(scratch_end), lane < 4, lane);
         const u32 np = __shfl(npay, 0);
         __threadfence();
         __syncthreads();
@@ -597,11 +601,12 @@ __global__ __launch_bounds__(WAVE) void k_enc_chain(EncItem *items, int nitems, 
     EncItem *I = mine ? &items[it] : &items[0];
     const bool active = mine && I->active;
     const u32 order = active ? I->order : 2u;
-    const u8 *data = (const u8 *)I->data;
-    const EncEntry *img = (const EncEntry *)I->image;
-    u8 *send = (u8 *)I->scratch_end;
-    u32 pay = chain_encode<1>(data, I->n, img, I->ctxrow, I->bits, send, order == 1, lane);
-    pay |= chain_encode<0>(data, I->n, img, I->ctxrow, I->bits, send, order == 0, lane);
+    gcu8 *data = (gcu8 *)I->data;
+    gcEncEntry *img = (gcEncEntry *)I->image;
+    gu8 *send = (gu8 *)I->scratch_end;
+    gcu16 *ctxrow = to_global((const u16 *)I->ctxrow);
+    u32 pay = chain_encode<1>(data, I->n, img, ctxrow, I->bits, send, order == 1, lane);
+    pay |= chain_encode<0>(data, I->n, img, ctxrow, I->bits, send, order == 0, lane);
     if (active && (lane & 3) == 0) I->pay_len = pay;
 }
 
@@ -614,7 +619,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_finish(BatchArgs a, EncWs ws, int 
     const u32 b = blockIdx.x;
     const int i = base + (int)b;
     const EncDesc *D = &ws.desc[b];
-    const EncItem *I0 = &ws.items[2 * b];
+    const EncItem *I0 = &ws.items[b];
     u8 *out = a.out + a.out_off[i];
     const i32 st = D->status;
     if (st != ST_OK) {

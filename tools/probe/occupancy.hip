@@ -1,0 +1,29 @@
+// Probe: how many single-wave workgroups with X bytes of dynamic LDS are resident per CU on gfx950?
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+__global__ __launch_bounds__(64) void spin(unsigned long long ticks, unsigned *sink) {
+    extern __shared__ unsigned lds[];
+    lds[threadIdx.x] = threadIdx.x;
+    unsigned long long t0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    if (lds[threadIdx.x] == 12345) sink[0] = 1;
+}
+int main(int argc, char **argv) {
+    unsigned *sink; hipMalloc(&sink, 4);
+    hipFuncSetAttribute((const void *)spin, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    int sizes[] = {2560, 5120, 10240, 16384, 20480, 22528, 24576, 32768, 40960, 65536, 81920, 163840};
+    for (int s : sizes) {
+        int best = 0;
+        for (int k = 1; k <= 40; k++) {
+            hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+            hipEventRecord(a);
+            hipLaunchKernelGGL(spin, dim3(256 * k), dim3(64), s, 0, 200000ull /*2 ms*/, sink);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b);
+            if (ms < 3.2f) best = k; else break;
+        }
+        printf("lds=%6d B  resident WGs/CU >= %d\n", s, best);
+    }
+    return 0;
+}
