@@ -157,7 +157,7 @@ static void time_end(rans4x16_hip_ctx *c, int which, hipStream_t s, TimedLaunch 
 // ---------------------------------------------------------------------------------------------
 // device-resident batches
 // ---------------------------------------------------------------------------------------------
-static size_t enc_ws_layout(u8 *base, size_t nblk, u64 scratch_stride, EncWs *w)
+static size_t enc_ws_layout(u8 *base, size_t nblk, u64 scratch_stride, u64 xf_stride, u64 scratch2_stride, EncWs *w)
 {
     Carver cv(base);
     w->desc = cv.take<EncDesc>(nblk);
@@ -168,6 +168,13 @@ static size_t enc_ws_layout(u8 *base, size_t nblk, u64 scratch_stride, EncWs *w)
     w->scratch = cv.take<u8>(nblk, scratch_stride);
     w->F = cv.take<u32>(nblk * 65536);
     w->scratch_stride = scratch_stride;
+    w->packed = cv.take<u8>(nblk, xf_stride);
+    w->lits = cv.take<u8>(nblk, xf_stride);
+    w->meta = cv.take<u8>(nblk, xf_stride ? xf_stride + 768 : 0);
+    w->metatab = cv.take<u8>(nblk, xf_stride ? META_TAB_BYTES : 0);
+    w->scratch2 = cv.take<u8>(nblk, scratch2_stride);
+    w->xf_stride = xf_stride;
+    w->scratch2_stride = scratch2_stride;
     return align_up(cv.off, 256);
 }
 
@@ -191,14 +198,18 @@ extern "C" int rans4x16_hip_compress_dev(rans4x16_hip_ctx *c, int n,
     // backward-write area per block: the order-1 bound of the largest block (covers the nested
     // table coder and the RLE meta stream as well)
     const u64 scratch_stride = align_up((size_t)r4x16_compress_bound(max_in_size, 0xc1) + 64, 256);
+    // X_PACK / X_RLE staging only when some block may ask for it (per-block orders: assume yes)
+    const bool xf = d_order != nullptr || (order & (X_PACK | X_RLE));
+    const u64 xf_stride = xf ? align_up((size_t)max_in_size + 64, 256) : 0;
+    const u64 scratch2_stride = xf ? align_up((size_t)r4x16_compress_bound(max_in_size + 768, 0) + 64, 256) : 0;
     EncWs w;
-    const size_t per_blk = enc_ws_layout(nullptr, 1, scratch_stride, &w) + 4096;
+    const size_t per_blk = enc_ws_layout(nullptr, 1, scratch_stride, xf_stride, scratch2_stride, &w) + 4096;
     size_t chunk = c->max_ws / per_blk;
     if (chunk < 1) chunk = 1;
     if (chunk > (size_t)n) chunk = (size_t)n;
-    const size_t need = enc_ws_layout(nullptr, chunk, scratch_stride, &w);
+    const size_t need = enc_ws_layout(nullptr, chunk, scratch_stride, xf_stride, scratch2_stride, &w);
     if (ensure_ws(c, need) != 0) return -1;
-    enc_ws_layout(c->ws, chunk, scratch_stride, &w);
+    enc_ws_layout(c->ws, chunk, scratch_stride, xf_stride, scratch2_stride, &w);
     w.logtab = c->logtab;
 
     BatchArgs a;
@@ -251,8 +262,10 @@ extern "C" int rans4x16_hip_uncompress_dev(rans4x16_hip_ctx *c, int n,
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
 
-    const u64 tmp_stride = 0, meta_stride = 0;      // PACK / RLE staging: milestone 2
-    (void)max_out_cap;
+    // PACK / RLE staging: one buffer of the output size, and room for the decoded run-length meta
+    // (rANS_static4x16pr.c:1273: at most in_size + 257 bytes)
+    const u64 tmp_stride = align_up((size_t)max_out_cap + 64, 256);
+    const u64 meta_stride = align_up((size_t)max_out_cap + 512, 256);
     DecWs w;
     const size_t per_blk = dec_ws_layout(nullptr, 1, tmp_stride, meta_stride, &w) + 4096;
     size_t chunk = c->max_ws / per_blk;

@@ -147,9 +147,9 @@ struct EncDesc {
 // Device workspace carved per chunk of blocks by r4x16_api.hip.
 // ---------------------------------------------------------------------------------------------
 #define TBUF_BYTES     204800u                          // an un-nested order-1 table (257*257*3 = 198147 max)
-#define DEC_IMG_SLOT   (IMG_MAX_BYTES + IMG_O0_BYTES)   // payload image + one order-0 image
-#define ENC_IMG_ROWS   257u
-#define ENC_IMG_BYTES  (ENC_IMG_ROWS * 256u * 8u)       // 256 context rows + 1 spare row (nested / meta)
+#define DEC_IMG_SLOT   (IMG_MAX_BYTES + 2u * IMG_O0_BYTES)   // payload image, nested-table image, RLE-meta image
+#define ENC_IMG_ROWS   258u
+#define ENC_IMG_BYTES  (ENC_IMG_ROWS * 256u * 8u)       // 256 context rows + spare rows for the nested table coder and the RLE meta stream
 #define TAB_BYTES      198656u                          // >= 1 + 257*257*3 (assert at rANS_static4x16pr.c:784)
 
 struct DecWs {
@@ -172,4 +172,12 @@ struct EncWs {
     u32 *F;             // [nblk][65536]  order-1 counters when the alphabet is too big for LDS
     const double *logtab;   // [2][257]  log(1024+k), log(4096+k) from the host libm (:651-652)
     u64 scratch_stride;
+    // X_PACK / X_RLE staging (strides are 0 when the batch cannot use them)
+    u8 *packed;         // [nblk][xf_stride]   bit-packed bytes
+    u8 *lits;           // [nblk][xf_stride]   RLE literals (filled from the end)
+    u8 *meta;           // [nblk][xf_stride + 768]  RLE meta: nsyms, syms, run varints (filled from the end)
+    u8 *metatab;        // [nblk][1024]        order-0 table of the meta stream
+    u8 *scratch2;       // [nblk][scratch2_stride]  backward-written meta stream
+    u64 xf_stride, scratch2_stride;
 };
+#define META_TAB_BYTES 1024u

@@ -413,6 +413,7 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
         i32 status;
         u32 order, pay_pos, pay_len, s1_size, compressed, usz, csz, tab_pos, after_table;
         u32 bits;
+        u32 meta_nested, meta_pos, meta_slen, meta_len;
     } H;
 
     const u32 lane = threadIdx.x;
@@ -428,31 +429,93 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
     u8 *tbuf = ws.tbuf + (u64)b * TBUF_BYTES;
     ByteSrc src(in);
 
-    // ---- container header: flags, sizes (:1435-1467) ----------------------------------------
+    // ---- container header: flags, sizes, PACK map, RLE meta (:1435-1572) ---------------------------
+    u8 *tmp = ws.tmp + (u64)b * ws.tmp_stride;
+    u8 *metabuf = ws.meta + (u64)b * ws.meta_stride;
     if (lane == 0) {
         I0->active = 0; I1->active = 0;
         I0->blk = b; I1->blk = b;
         D->status = ST_OK; D->cat_src = 0; D->cat_len = 0; D->osz = 0; D->s1_size = 0;
-        D->pack_per = 1; D->rle_meta_len = 0;
+        D->pack_per = 1; D->rle_meta_len = 0; D->rle_meta = 0;
         i32 st = ST_OK;
         u32 pos = 0, osz = 0, flags = 0;
-        H.pay_len = 0;
+        H.pay_len = 0; H.meta_nested = 0;
         if (in_size == 0) st = ST_EMPTY;                               // :1357
         else {
             flags = src.at(pos++);
             if (flags & X_STRIPE) st = ST_UNSUPPORTED;                 // host entry points split stripes
-            else if (flags & (X_PACK | X_RLE)) st = ST_UNSUPPORTED;    // TODO(milestone 2): k_dec_back transforms
             else {
                 if (!(flags & X_NOSZ)) pos += var_get(src, pos, in_size, &osz);
                 else osz = cap;
                 if (cap < osz) st = ST_CAPACITY;                       // :1464
+                else if ((flags & (X_PACK | X_RLE)) && osz > ws.tmp_stride) st = ST_UNSUPPORTED;
             }
         }
         D->flags = flags;
+        u32 s1_size = osz;
         if (st == ST_OK) {
             D->osz = osz;
-            D->s1 = (u64)out; D->s2 = (u64)out; D->s3 = (u64)out;
-            u32 s1_size = osz;
+            // stage buffers (:1480-1520): rans -> s1, un-RLE -> s2, un-PACK -> s3
+            const bool pk = flags & X_PACK, rl = flags & X_RLE;
+            u8 *s1 = out, *s2 = out, *s3 = out;
+            if (pk && rl) { s1 = out; s2 = tmp; s3 = out; }
+            else if (pk)  { s1 = tmp; s2 = tmp; s3 = out; }
+            else if (rl)  { s1 = tmp; s2 = out; s3 = out; }
+            D->s1 = (u64)s1; D->s2 = (u64)s2; D->s3 = (u64)s3;
+
+            if (pk) {                                                  // hts_unpack_meta, pack.c:165-198
+                const u32 left = in_size - pos;
+                u32 used = 0, per = 1;
+                if (left == 0) st = ST_TRUNCATED;
+                else {
+                    u32 n = src.at(pos);
+                    if (n == 0) n = 256;
+                    if (n <= 1) per = 0; else if (n <= 2) per = 8; else if (n <= 4) per = 4; else if (n <= 16) per = 2;
+                    if (n > 16) { per = 1; used = 1; }
+                    else if (left <= 1) st = ST_TRUNCATED;
+                    else {
+                        u32 j = 1, c = 0;
+                        do { D->pack_map[c++] = src.at(pos + j); j++; } while (c < n && j < left);
+                        if (c < n) st = ST_TRUNCATED; else used = j;
+                    }
+                }
+                if (st == ST_OK) {
+                    D->pack_per = per;
+                    pos += used;
+                    u32 psz;
+                    pos += var_get(src, pos, in_size, &psz);            // :1539-1544
+                    if (psz > s1_size) st = ST_SIZE; else s1_size = psz;
+                }
+            }
+            if (st == ST_OK && rl) {                                   // :1549-1572
+                u32 mlen, lit_len, c_meta, sz;
+                const u32 left = in_size - pos;
+                sz = var_get(src, pos, in_size, &mlen);
+                sz += var_get(src, pos + sz, in_size, &lit_len);
+                if (lit_len > s1_size) st = ST_SIZE;
+                else if (mlen & 1) {                                   // raw meta lives in the input
+                    const u32 avail = left - sz;
+                    mlen = (mlen / 2 > avail) ? avail : mlen / 2;
+                    c_meta = mlen;
+                    D->rle_meta = (u64)(in + pos + sz);
+                    D->rle_meta_len = mlen;
+                } else {                                               // order-0 compressed meta
+                    sz += var_get(src, pos + sz, in_size, &c_meta);
+                    mlen /= 2;
+                    if (mlen > ws.meta_stride) st = ST_UNSUPPORTED;    // larger than any valid meta for this batch
+                    else {
+                        H.meta_nested = 1; H.meta_pos = pos + sz; H.meta_slen = left - sz; H.meta_len = mlen;
+                        D->rle_meta = (u64)metabuf;
+                        D->rle_meta_len = mlen;
+                    }
+                }
+                if (st == ST_OK) {
+                    if (c_meta + sz > left) st = ST_SIZE;              // :1567 (32-bit arithmetic as there)
+                    else { pos += c_meta + sz; s1_size = lit_len; }
+                }
+            }
+        }
+        if (st == ST_OK) {
             const u32 left = in_size - pos;
             if (left == 0) {                                           // :1592-1595
                 s1_size = 0;
@@ -469,7 +532,26 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
         D->status = st;
     }
     __syncthreads();
-    if (H.status != ST_OK || H.pay_len == 0) return;
+    if (H.status != ST_OK) return;
+
+    if (H.meta_nested) {
+        // the RLE meta is itself an order-0 stream: it becomes a second item for the chain kernel
+        u8 *imgm = img + IMG_MAX_BYTES + IMG_O0_BYTES;
+        o0_front(src, H.meta_pos, H.meta_slen, H.meta_len, imgm, S, lane);
+        if (S.status != ST_OK) { if (lane == 0) D->status = S.status; return; }
+        if (lane == 0) {
+            I1->words = (u64)(in + S.words_pos);
+            I1->words_len = H.meta_pos + H.meta_slen - S.words_pos;
+            I1->out = (u64)metabuf; I1->out_sz = H.meta_len; I1->image = (u64)imgm;
+            I1->img_bytes = img_row_bytes(S.nnz, O0_BITS);
+            I1->look = O0_BITS; I1->order = 0;
+            for (int k = 0; k < 4; k++) I1->R[k] = S.R[k];
+            __threadfence();
+            I1->active = H.meta_len != 0;
+        }
+        __syncthreads();
+    }
+    if (H.pay_len == 0) return;
 
     const u32 pay_pos = H.pay_pos, pay_len = H.pay_len, s1_size = H.s1_size;
 
@@ -691,19 +773,178 @@ __global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDes
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_dec_back: CAT copies, final size and status.
+// Run-length expansion, rle.c:142-187, by one wave.  64 literals per trip: the run varints of the
+// RLE-symbol literals are matched to them by rank (k-th RLE literal <-> k-th varint), lengths are
+// prefix-summed, and the output bytes are written balanced over the lanes (each output byte finds
+// its literal by binary search over the trip's 64 prefix sums).
+// ---------------------------------------------------------------------------------------------
+struct BackShared {
+    u8  is_rle[256];
+    u32 vals[WAVE];
+    u32 pfx[WAVE];
+    u8  lb[WAVE];
+    u8  map[16];
+};
+
+__device__ bool rle_expand(const u8 *lit, u32 lit_len, const u8 *runs, u32 run_len, const u8 *syms,
+                           u32 nsyms, u8 *out, u32 cap, u32 &produced, BackShared &B, u32 lane)
+{
+    for (u32 j = lane; j < 256; j += WAVE) B.is_rle[j] = 0;
+    __syncthreads();
+    for (u32 j = lane; j < nsyms; j += WAVE) B.is_rle[syms[j]] = 1;
+    __syncthreads();
+
+    u64 outp = 0;
+    u32 rp = 0;
+    bool err = false;
+    const u64 lane_below = (1ull << lane) - 1ull;
+    for (u32 base = 0; base < lit_len && !err; base += WAVE) {
+        const u32 i = base + lane;
+        const bool valid = i < lit_len;
+        const u32 bval = valid ? lit[i] : 0u;
+        const bool r = valid && B.is_rle[bval];
+        const u64 rmask = __ballot(r);
+        const u32 nr = (u32)__popcll(rmask), myrank = (u32)__popcll(rmask & lane_below);
+        u32 got = 0, runval = 0;
+        while (got < nr && rp < run_len) {                 // past the end a varint reads as 0 (varint.h:136)
+            const u32 p = rp + lane;
+            const bool have = p < run_len;
+            const u32 c = have ? runs[p] : 0u;
+            const bool isend = have && (!(c & 0x80u) || p == run_len - 1);
+            const u64 E = __ballot(isend);
+            if (!E) { err = true; break; }                 // a "varint" of 64+ bytes: never produced by an encoder
+            const u64 prevE = E & lane_below;
+            const u32 start = prevE ? 64u - (u32)__clzll(prevE) : 0u;
+            u32 v = c & 0x7fu;
+#pragma unroll
+            for (int dd = 1; dd <= 4; dd++) {
+                const u32 cd = __shfl_up(c, dd);
+                if (lane >= start + (u32)dd) v |= (cd & 0x7fu) << (7 * dd);
+            }
+            const u32 erank = (u32)__popcll(prevE);
+            const u32 navail = (u32)__popcll(E);
+            const u32 ntake = navail < nr - got ? navail : nr - got;
+            if (isend && erank < ntake) B.vals[erank] = v;
+            __syncthreads();
+            if (r && myrank >= got && myrank < got + ntake) runval = B.vals[myrank - got];
+            const u64 lastm = __ballot(isend && erank == ntake - 1);
+            rp += (u32)__ffsll((unsigned long long)lastm);   // index of that lane + 1
+            got += ntake;
+            __syncthreads();
+        }
+        if (err) break;
+        const u64 len = valid ? 1ull + runval : 0ull;
+        // exclusive prefix of lengths (64-bit: a hostile run can be 4 GiB)
+        u64 incl = len;
+#pragma unroll
+        for (int dd = 1; dd < WAVE; dd <<= 1) {
+            const u64 tt = __shfl_up(incl, dd);
+            if (lane >= (u32)dd) incl += tt;
+        }
+        const u64 excl = incl - len;
+        const u64 total = __shfl(incl, WAVE - 1);
+        const u64 oi = outp + excl;
+        // rle.c:165, :173: every literal needs room, a run needs room for all of it
+        const bool bad = valid && (oi >= cap || (runval && oi + runval >= cap));
+        if (__ballot(bad)) { err = true; break; }
+        B.pfx[lane] = (u32)excl;
+        B.lb[lane] = (u8)bval;
+        const u32 nvalid = (u32)__popcll(__ballot(valid));
+        __syncthreads();
+        u8 *o = out + outp;
+        for (u32 k = lane; k < (u32)total; k += WAVE) {
+            u32 lo = 0, hi = nvalid - 1;                   // largest j with pfx[j] <= k
+            while (lo < hi) {
+                const u32 mid = (lo + hi + 1) >> 1;
+                if (B.pfx[mid] <= k) lo = mid; else hi = mid - 1;
+            }
+            o[k] = B.lb[lo];
+        }
+        __syncthreads();
+        outp += total;
+    }
+    produced = (u32)outp;
+    return !err;
+}
+
+// hts_unpack, pack.c:211-348, by one wave.  Returns false when the packed data is too short.
+__device__ bool unpack(const u8 *data, u32 len, u8 *out, u32 out_len, u32 per, BackShared &B, u32 lane)
+{
+    if (per == 1) { wave_copy(out, data, len, lane); return true; }
+    if (per == 0) {
+        const u8 v = B.map[0];
+        for (u32 i = lane; i < out_len; i += WAVE) out[i] = v;
+        return true;
+    }
+    if ((out_len + per - 1) / per > len) return false;
+    const u32 width = 8 / per, mask = (1u << width) - 1u;
+    const u32 ndw = out_len >> 2;
+    for (u32 w = lane; w < ndw; w += WAVE) {
+        u32 v = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const u32 i = 4 * w + j;
+            v |= (u32)B.map[(data[i / per] >> ((i % per) * width)) & mask] << (8 * j);
+        }
+        *(u32_unaligned *)(out + 4 * (u64)w) = v;
+    }
+    const u32 i = 4 * ndw + lane;
+    if (i < out_len) out[i] = B.map[(data[i / per] >> ((i % per) * width)) & mask];
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_dec_back: CAT copies, un-RLE, un-PACK, final size and status (:1576-1629).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WAVE) void k_dec_back(BatchArgs a, DecWs ws, int base)
 {
+    __shared__ BackShared B;
     const u32 lane = threadIdx.x;
     const u32 b = blockIdx.x;
     const int i = base + (int)b;
     const DecDesc *D = &ws.desc[b];
-    const i32 st = D->status;
-    if (st == ST_OK && D->cat_src) wave_copy((u8 *)D->s1, (const u8 *)D->cat_src, D->cat_len, lane);
+    i32 st = D->status;
+    u32 size = 0;
+    if (st == ST_OK) {
+        const u32 flags = D->flags;
+        u8 *s1 = (u8 *)D->s1, *s2 = (u8 *)D->s2, *s3 = (u8 *)D->s3;
+        u32 s1_size = D->s1_size;
+        if (D->cat_src) wave_copy(s1, (const u8 *)D->cat_src, D->cat_len, lane);
+        if (flags & (X_PACK | X_RLE)) { __threadfence(); __syncthreads(); }
+        u32 s2_size = s1_size;
+        if (flags & X_RLE) {                                           // :1598-1613
+            const u8 *meta = (const u8 *)D->rle_meta;
+            const u32 mlen = D->rle_meta_len;
+            u32 nsyms = 0;
+            if (mlen == 0) st = ST_RLE;
+            else {
+                nsyms = meta[0] ? meta[0] : 256u;
+                if (mlen < 1 + nsyms) st = ST_RLE;
+            }
+            if (st == ST_OK) {
+                u32 produced = 0;
+                if (!rle_expand(s1, s1_size, meta + 1 + nsyms, mlen - (1 + nsyms), meta + 1, nsyms,
+                                s2, D->osz, produced, B, lane))
+                    st = ST_RLE;
+                else
+                    s2_size = produced;
+            }
+            __threadfence();
+            __syncthreads();
+        }
+        size = s2_size;
+        if (st == ST_OK && (flags & X_PACK)) {                         // :1614-1623
+            if (lane < 16) B.map[lane] = D->pack_map[lane];
+            __syncthreads();
+            const u32 per = D->pack_per;
+            const u32 unpacked = per == 1 ? s2_size : D->osz;
+            if (!unpack(s2, s2_size, s3, unpacked, per, B, lane)) st = ST_SIZE;
+            size = unpacked;
+        }
+    }
     if (lane == 0) {
         a.status[i] = st;
-        a.out_size[i] = st == ST_OK ? D->s1_size : 0;
+        a.out_size[i] = st == ST_OK ? size : 0;
     }
 }
 

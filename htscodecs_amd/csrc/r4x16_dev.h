@@ -18,6 +18,7 @@ typedef GAS const u32 gcu32;
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 typedef GAS const u32x4 gcu32x4;
+typedef u32 __attribute__((aligned(1))) u32_unaligned;          // dword access at any byte address
 template <class T> __device__ __forceinline__ GAS T *to_global(T *p) { return (GAS T *)p; }
 template <class T> __device__ __forceinline__ GAS const T *to_global(const T *p) { return (GAS const T *)p; }
 

@@ -198,6 +198,8 @@ struct EncShared {
     u8  pmask[256];      // terms present in this row
     u32 nsym, tab_len, bits;
     i32 status;
+    u32 pk_n, pk_meta_len, pk_len;       // wave_pack results
+    u32 rl_nsyms, rl_lits, rl_runs;      // wave_rle_split results
 };
 
 // ---- wave histogram of bytes (hist8, utils.h:80-102) into S.F ---------------------------------
@@ -279,6 +281,112 @@ __device__ void enc_o0_front(const u8 *data, u32 n, u8 *tab, EncEntry *imgrow, E
 }
 
 // ---------------------------------------------------------------------------------------------
+// hts_pack, pack.c:56-151, by one wave.  S.F must hold the byte histogram of data[0..n).
+// Writes the map to meta (meta[0] = symbol count, 256 wraps to 0) and, when 2..16 symbols occur,
+// the packed bytes to `out` (first symbol in the low bits).  Results through the shared scalars:
+//   S.pk_n (symbol count), S.pk_meta_len, S.pk_len (packed length; n for the copy cases).
+// ---------------------------------------------------------------------------------------------
+__device__ void wave_pack(const u8 *data, u32 n, u8 *meta, u8 *out, EncShared &S, u32 lane)
+{
+    if (lane == 0) {
+        u32 ns = 0;
+        for (u32 j = 0; j < 256; j++)
+            if (S.F[j]) { S.idx_of[j] = (u8)ns; S.alpha[ns] = (u8)j; ns++; }
+        meta[0] = (u8)ns;                                 // 256 wraps to 0 (pack.c:74)
+        if (ns <= 16) for (u32 j = 0; j < ns; j++) meta[1 + j] = S.alpha[j];
+        S.pk_n = ns;
+        S.pk_meta_len = ns > 16 ? 1 : ns + 1;
+    }
+    __syncthreads();
+    const u32 ns = S.pk_n;
+    if (ns > 16) { if (lane == 0) S.pk_len = n; return; }     // copy case: caller keeps `data`
+    const u32 per = ns > 4 ? 2 : ns > 2 ? 4 : ns > 1 ? 8 : 0;
+    if (per == 0) { if (lane == 0) S.pk_len = 0; __syncthreads(); return; }
+    const u32 width = 8 / per;
+    const u32 nout = (n + per - 1) / per;
+    for (u32 ob = lane; ob < nout; ob += WAVE) {
+        u32 v = 0;
+        const u32 i0 = ob * per;
+        for (u32 k = 0; k < per && i0 + k < n; k++) v |= (u32)S.idx_of[data[i0 + k]] << (k * width);
+        out[ob] = (u8)v;
+    }
+    if (lane == 0) S.pk_len = nout;
+    __threadfence();
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// rle_encode with automatic symbol choice, rle.c:48-138, by one wave.
+// A symbol is run-length coded when it repeats its predecessor more often than not
+// (score = sum over its occurrences of +1 / -1 > 0, i.e. 2 * repeats > count).  The input is swept
+// from the end in 64-byte steps: a literal's run is the distance to the next literal above it, so
+// literals and run varints are produced back to front into lits_end[-..] and runs_end[-..].
+// Results: S.rl_nsyms, S.rl_lits, S.rl_runs (bytes); symbols in S.alpha[0..nsyms).
+// S.F must hold the byte histogram of data[0..n).
+// ---------------------------------------------------------------------------------------------
+__device__ void wave_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, EncShared &S, u32 lane)
+{
+    u32 *rep = S.T;                                      // repeats per symbol
+    for (u32 j = lane; j < 256; j += WAVE) rep[j] = 0;
+    __syncthreads();
+    {
+        u32 carry = 256;                                 // byte before this trip (none at the start)
+        for (u32 base = 0; base < n; base += WAVE) {
+            const u32 i = base + lane;
+            const u32 cur = i < n ? data[i] : 257u;
+            u32 prev = __shfl_up(cur, 1);
+            if (lane == 0) prev = carry;
+            carry = __shfl(cur, WAVE - 1);
+            if (i < n && cur == prev) atomicAdd(&rep[cur], 1u);
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        u32 ns = 0;
+        for (u32 j = 0; j < 256; j++) {
+            const bool use = 2 * (u64)rep[j] > (u64)S.F[j];
+            S.present[j] = use;
+            if (use) S.alpha[ns++] = (u8)j;
+        }
+        S.rl_nsyms = ns;
+    }
+    __syncthreads();
+
+    u32 next_lit = n, nl = 0, nrb = 0;
+    for (u32 top = n; top > 0; ) {
+        const u32 base = top > WAVE ? top - WAVE : 0;
+        const u32 cnt = top - base;
+        const u32 i = base + lane;
+        const bool valid = lane < cnt;
+        const u32 cur = valid ? data[i] : 0u;
+        const u32 prev = (valid && i > 0) ? data[i - 1] : 256u;
+        const bool isl = valid && !(S.present[cur] && cur == prev);
+        const u64 L = __ballot(isl);
+        const u64 above = lane == WAVE - 1 ? 0ull : (L >> (lane + 1));
+        const u32 nxt = above ? i + (u32)__ffsll((unsigned long long)above) : next_lit;
+        const bool isr = isl && S.present[cur];
+        const u32 run = nxt - i - 1;
+        const u32 vl = isr ? var_len(run) : 0u;
+        // bytes of run varints produced by the lanes above this one (suffix sum)
+        u32 suf = vl;
+#pragma unroll
+        for (int dd = 1; dd < WAVE; dd <<= 1) {
+            const u32 tt = __shfl_down(suf, dd);
+            if (lane + (u32)dd < WAVE) suf += tt;
+        }
+        if (isl) lits_end[-(long)(nl + (u32)__popcll(above) + 1)] = (u8)cur;
+        if (isr) var_put(runs_end - (nrb + suf), run);
+        nl += (u32)__popcll(L);
+        nrb += __shfl(suf, 0);
+        if (L) next_lit = base + (u32)__ffsll((unsigned long long)L) - 1;
+        top = base;
+    }
+    if (lane == 0) { S.rl_lits = nl; S.rl_runs = nrb; }
+    __threadfence();
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_enc_front
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double approx_log(double a)            // fast_log :620-623
@@ -291,7 +399,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
 {
     extern __shared__ __attribute__((aligned(16))) u8 dyn[];
     __shared__ EncShared S;
-    __shared__ struct { i32 status; u32 go, order, dlen, nested_len; double e10, e12; int max_tot; } H;
+    __shared__ struct { i32 status; u32 go, order, dlen, nested_len, flags, hl; double e10, e12; int max_tot; } H;
 
     const u32 lane = threadIdx.x;
     const u32 b = blockIdx.x;
@@ -315,6 +423,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
         D->cat = 0; D->rle_on = 0; D->tab_len = 0; D->hdr_len = 0; D->dlen = 0; D->tab = (u64)tab;
         i32 st = ST_OK;
         u32 go = 0;
+        H.flags = 0; H.hl = 0;
         if (cap < compress_bound(in_size, order)) st = ST_CAPACITY;
         else {
             if (in_size <= 20) order &= ~X_STRIPE;                         // :1151
@@ -323,19 +432,15 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
                 D->hdr[0] = X_CAT;
                 D->hdr_len = 1 + var_put(D->hdr + 1, in_size);
                 D->cat = 1; D->data = (u64)in; D->dlen = in_size; D->flags = X_CAT;
-            } else if (order & (X_PACK | X_RLE)) {
-                st = ST_UNSUPPORTED;                                       // TODO(milestone 2)
+            } else if ((order & (X_PACK | X_RLE)) && (in_size > ws.xf_stride)) {
+                st = ST_UNSUPPORTED;                                       // batch was sized without transform staging
             } else {
                 u32 flags = (u32)order & 0xff;
                 u32 hl = 1;
                 D->nosz = flags & X_NOSZ;
                 if (!(flags & X_NOSZ)) hl += var_put(D->hdr + 1, in_size); // :1234-1235
-                u32 o = order & 1;
-                if (o && in_size < 8) { flags &= ~1u; o = 0; }             // :1322-1325
-                D->flags = flags; D->hdr[0] = (u8)flags; D->hdr_len = hl;
-                D->data = (u64)in; D->dlen = in_size;
-                H.order = o; H.dlen = in_size;
-                go = in_size != 0;
+                H.flags = flags; H.hl = hl;
+                go = 1;
             }
         }
         D->status = st;
@@ -345,7 +450,81 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
     if (H.status != ST_OK || !H.go) return;
 
     const u8 *data = in;
-    const u32 n = H.dlen;
+    u32 n = in_size;
+    u32 flags = H.flags, hl = H.hl;
+
+    // ---- X_PACK (:1244-1267) ----------------------------------------------------------------------
+    if (flags & X_PACK) {
+        if (n == 0) flags &= ~(u32)X_PACK;
+        else {
+            u8 *pbuf = ws.packed + (u64)b * ws.xf_stride;
+            wave_hist8(data, n, S.F, lane);
+            wave_pack(data, n, D->hdr + hl, pbuf, S, lane);
+            __syncthreads();
+            if (S.pk_meta_len == 1 && S.pk_n != 256) flags &= ~(u32)X_PACK;    // > 16 symbols (:1249); 256 wraps to 0 and stays
+            else {
+                if (S.pk_n <= 16) data = pbuf;
+                n = S.pk_len;
+                hl += S.pk_meta_len;
+                if (lane == 0) H.hl = hl + var_put(D->hdr + hl, n);
+                __syncthreads();
+                hl = H.hl;
+            }
+        }
+    }
+
+    // ---- X_RLE (:1269-1319) -----------------------------------------------------------------------
+    if (flags & X_RLE) {
+        if (n == 0) flags &= ~(u32)X_RLE;
+        else {
+            u8 *lits_end = ws.lits + (u64)b * ws.xf_stride + ws.xf_stride;
+            u8 *meta_end = ws.meta + (u64)b * (ws.xf_stride + 768) + (ws.xf_stride + 768);
+            __threadfence();
+            __syncthreads();
+            wave_hist8(data, n, S.F, lane);
+            wave_rle_split(data, n, lits_end, meta_end, S, lane);
+            const u32 nsy = S.rl_nsyms, nlits = S.rl_lits, nruns = S.rl_runs;
+            const u32 mlen = nruns + nsy + 1;                              // :1282-1285
+            if ((double)((u64)nlits + mlen) >= .99 * (double)n) {          // :1287
+                flags &= ~(u32)X_RLE;
+            } else {
+                u8 *m = meta_end - mlen;
+                if (lane == 0) m[0] = (u8)nsy;
+                for (u32 j = lane; j < nsy; j += WAVE) m[1 + j] = S.alpha[j];
+                __threadfence();
+                __syncthreads();
+                // the meta is coded as an order-0 stream by the chain kernel (item I1)
+                u8 *mtab = ws.metatab + (u64)b * META_TAB_BYTES;
+                EncEntry *imgm = img + 257u * 256u;
+                enc_o0_front(m, mlen, mtab, imgm, S, lane);
+                if (lane == 0) {
+                    D->rle_on = 1; D->rle_mlen = mlen; D->rle_lits = nlits;
+                    D->rle_meta = (u64)m; D->meta_tab = (u64)mtab; D->meta_tab_len = S.tab_len;
+                    if (S.status != ST_OK) D->status = S.status;
+                    I1->data = (u64)m; I1->n = mlen; I1->image = (u64)imgm; I1->bits = O0_BITS; I1->order = 0;
+                    I1->scratch_end = (u64)(ws.scratch2 + (u64)b * ws.scratch2_stride + ws.scratch2_stride);
+                    __threadfence();
+                    I1->active = S.status == ST_OK;
+                }
+                __syncthreads();
+                if (S.status != ST_OK) return;
+                data = lits_end - nlits;
+                n = nlits;
+            }
+        }
+    }
+
+    {
+        u32 o = order & 1;
+        if (o && n < 8) { flags &= ~1u; o = 0; }                           // :1322-1325
+        if (lane == 0) {
+            D->flags = flags; D->hdr[0] = (u8)flags; D->hdr_len = hl;
+            D->data = (u64)data; D->dlen = n;
+            H.order = o;
+        }
+        __syncthreads();
+    }
+    if (n == 0) return;
 
     if (H.order == 0) {
         enc_o0_front(data, n, tab, img, S, lane);
@@ -615,11 +794,13 @@ __global__ __launch_bounds__(WAVE) void k_enc_chain(EncItem *items, int nitems, 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WAVE) void k_enc_finish(BatchArgs a, EncWs ws, int base)
 {
+    __shared__ u8 vbuf[16];
+    __shared__ u32 vlen;
     const u32 lane = threadIdx.x;
     const u32 b = blockIdx.x;
     const int i = base + (int)b;
     const EncDesc *D = &ws.desc[b];
-    const EncItem *I0 = &ws.items[b];
+    const EncItem *I0 = &ws.items[b], *I1 = &ws.items[gridDim.x + b];
     u8 *out = a.out + a.out_off[i];
     const i32 st = D->status;
     if (st != ST_OK) {
@@ -629,10 +810,35 @@ __global__ __launch_bounds__(WAVE) void k_enc_finish(BatchArgs a, EncWs ws, int 
     u32 pos = D->hdr_len;
     const u32 dlen = D->dlen;
     u32 flags = D->hdr[0];
+    if (lane >= 1 && lane < D->hdr_len) out[lane] = D->hdr[lane];
     if (D->cat) {
         wave_copy(out + pos, (const u8 *)D->data, dlen, lane);
         pos += dlen;
     } else {
+        if (D->rle_on) {                                              // :1294-1310
+            const u32 mlen = D->rle_mlen;
+            const u32 mpay = I1->pay_len;
+            const u32 clen = D->meta_tab_len + mpay;
+            const bool comp = clen < mlen;
+            if (lane == 0) {
+                u32 l = var_put(vbuf, comp ? mlen * 2 : mlen * 2 + 1);
+                l += var_put(vbuf + l, D->rle_lits);
+                if (comp) l += var_put(vbuf + l, clen);
+                vlen = l;
+            }
+            __syncthreads();
+            if (lane < vlen) out[pos + lane] = vbuf[lane];
+            pos += vlen;
+            if (comp) {
+                wave_copy(out + pos, (const u8 *)D->meta_tab, D->meta_tab_len, lane);
+                pos += D->meta_tab_len;
+                wave_copy(out + pos, (const u8 *)I1->scratch_end - mpay, mpay, lane);
+                pos += mpay;
+            } else {
+                wave_copy(out + pos, (const u8 *)D->rle_meta, mlen, lane);
+                pos += mlen;
+            }
+        }
         const u32 pay = I0->active ? I0->pay_len : 0;
         const u32 plen = D->tab_len + pay;
         if (plen >= dlen) {                                           // :1332-1337
@@ -651,7 +857,6 @@ __global__ __launch_bounds__(WAVE) void k_enc_finish(BatchArgs a, EncWs ws, int 
         a.status[i] = ST_OK;
         a.out_size[i] = pos;
     }
-    if (lane >= 1 && lane < D->hdr_len) out[lane] = D->hdr[lane];
 }
 
 // ---- host-callable launchers -------------------------------------------------------------------
