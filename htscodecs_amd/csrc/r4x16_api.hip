@@ -24,6 +24,7 @@ void r4x16_launch_enc_front(const BatchArgs *, const EncWs *, int, int, hipStrea
 void r4x16_launch_enc_chain(const EncWs *, int, int, hipStream_t);
 void r4x16_launch_enc_finish(const BatchArgs *, const EncWs *, int, int, hipStream_t);
 u32  r4x16_compress_bound(u32 size, int order);
+void r4x16_launch_stripe(const u8 *, u8 *, u32, u32, int, hipStream_t);
 }
 
 struct TimedLaunch { hipEvent_t a, b; };
@@ -305,6 +306,19 @@ static int ensure_stage(rans4x16_hip_ctx *c, size_t bytes)
     return 0;
 }
 
+static int stripe_compress(rans4x16_hip_ctx *, const unsigned char *, unsigned int, unsigned char *, unsigned int *, int);
+static int stripe_uncompress(rans4x16_hip_ctx *, const unsigned char *, unsigned int, unsigned char *, unsigned int *);
+
+static int run_plain_batch(rans4x16_hip_ctx *c, int n, bool decode,
+                           const unsigned char *const *in, const unsigned int *in_size,
+                           unsigned char *const *out, unsigned int *out_size, const int *order, int *status);
+
+static bool is_stripe(bool decode, const unsigned char *in, unsigned int in_size, int order)
+{
+    if (decode) return in_size > 0 && (in[0] & X_STRIPE);
+    return (order & X_STRIPE) && in_size > 20;                         // :1151
+}
+
 static int run_host_batch(rans4x16_hip_ctx *c, int n, bool decode,
                           const unsigned char *const *in, const unsigned int *in_size,
                           unsigned char *const *out, unsigned int *out_size, const int *order, int *status)
@@ -312,6 +326,45 @@ static int run_host_batch(rans4x16_hip_ctx *c, int n, bool decode,
     if (!c) return -1;
     if (n <= 0) return n == 0 ? 0 : -1;
     HIPCHK(c, hipSetDevice(c->device));
+    // stripe blocks are expanded into their own device batches, one block at a time
+    std::vector<int> plain;
+    int failed = 0;
+    for (int i = 0; i < n; i++) {
+        const int o = order ? order[i] : 0;
+        if (!is_stripe(decode, in[i], in_size[i], o)) { plain.push_back(i); continue; }
+        const int rc = decode ? stripe_uncompress(c, in[i], in_size[i], out[i], &out_size[i])
+                              : stripe_compress(c, in[i], in_size[i], out[i], &out_size[i], o);
+        if (rc < 0) return -1;
+        if (status) status[i] = rc ? R4X16_E_SIZE : 0;
+        if (rc) { out_size[i] = 0; failed++; }
+    }
+    if (plain.empty()) return failed;
+    if ((int)plain.size() == n) {
+        const int f = run_plain_batch(c, n, decode, in, in_size, out, out_size, order, status);
+        return f < 0 ? -1 : failed + f;
+    }
+    const int m = (int)plain.size();
+    std::vector<const unsigned char *> pin(m);
+    std::vector<unsigned char *> pout(m);
+    std::vector<unsigned int> pis(m), pos(m);
+    std::vector<int> pord(m), pst(m);
+    for (int k = 0; k < m; k++) {
+        const int i = plain[k];
+        pin[k] = in[i]; pout[k] = out[i]; pis[k] = in_size[i]; pos[k] = out_size[i]; pord[k] = order ? order[i] : 0;
+    }
+    const int f = run_plain_batch(c, m, decode, pin.data(), pis.data(), pout.data(), pos.data(), pord.data(), pst.data());
+    if (f < 0) return -1;
+    for (int k = 0; k < m; k++) {
+        out_size[plain[k]] = pos[k];
+        if (status) status[plain[k]] = pst[k];
+    }
+    return failed + f;
+}
+
+static int run_plain_batch(rans4x16_hip_ctx *c, int n, bool decode,
+                           const unsigned char *const *in, const unsigned int *in_size,
+                           unsigned char *const *out, unsigned int *out_size, const int *order, int *status)
+{
 
     // arena: [in blocks][out slots][offset/size/status arrays]
     std::vector<u64> in_off(n), out_off(n);
@@ -366,6 +419,163 @@ static int run_host_batch(rans4x16_hip_ctx *c, int n, bool decode,
     }
     HIPCHK(c, hipStreamSynchronize(0));
     return failed;
+}
+
+// ---------------------------------------------------------------------------------------------
+// X_STRIPE (rANS_static4x16pr.c:1154-1216, :1360-1433) is orchestration around N ordinary
+// sub-blocks, so it lives on the host side of the batch machinery: the byte planes are split /
+// joined by a device kernel, every (plane, candidate method) pair is one block of a device batch,
+// and the host only compares the resulting sizes and lays out the header.
+// ---------------------------------------------------------------------------------------------
+static int var_put_host(unsigned char *cp, u32 v)
+{
+    int groups = 1;
+    for (u32 t = v >> 7; t; t >>= 7) groups++;
+    for (int g = groups - 1; g >= 0; g--) *cp++ = (unsigned char)(((v >> (7 * g)) & 0x7f) | (g ? 0x80 : 0));
+    return groups;
+}
+static int var_get_host(const unsigned char *cp, const unsigned char *endp, u32 *v)
+{
+    const unsigned char *op = cp;
+    u32 j = 0;
+    unsigned char ch;
+    if (cp >= endp) { *v = 0; return 0; }
+    do { ch = *cp++; j = (j << 7) | (ch & 0x7f); } while ((ch & 0x80) && cp < endp);
+    *v = j;
+    return (int)(cp - op);
+}
+
+// returns 0 on success (out/out_size filled), 1 if the block failed, -1 on runtime errors
+static int stripe_compress(rans4x16_hip_ctx *c, const unsigned char *in, unsigned int n,
+                           unsigned char *out, unsigned int *out_size, int order)
+{
+    int N = order >> 8;
+    if (N == 0) N = 4;
+    if (N > 255) return 1;                                             // :1158
+    if (*out_size < r4x16_compress_bound(n, order)) return 1;
+    static const int methods[4] = {1, 64, 128, 0};                     // :1192
+    int cand[4], K = 0;
+    for (int j = 0; j < 4; j++) if ((order & methods[j]) == methods[j]) cand[K++] = methods[j];
+    const int items = N * K;
+
+    std::vector<u64> in_off(items), out_off(items);
+    std::vector<u32> isz(items), cap(items);
+    std::vector<i32> ord(items);
+    std::vector<u32> part(N), first(N);
+    for (int j = 0; j < N; j++) {
+        part[j] = n / N + ((n % N) > (u32)j);
+        first[j] = j ? first[j - 1] + part[j - 1] : 0;
+    }
+    size_t out_tot = 0;
+    u32 max_in = 0;
+    for (int j = 0; j < N; j++)
+        for (int k = 0; k < K; k++) {
+            const int it = j * K + k;
+            in_off[it] = first[j]; isz[it] = part[j]; ord[it] = cand[k] | X_NOSZ;
+            cap[it] = r4x16_compress_bound(part[j], ord[it]);
+            out_off[it] = out_tot; out_tot += align_up((size_t)cap[it] + 16, 256);
+            if (part[j] > max_in) max_in = part[j];
+        }
+    const size_t in_al = align_up((size_t)n + 16, 256);
+    const size_t arr = align_up((size_t)items * 8, 256);
+    if (ensure_stage(c, 2 * in_al + out_tot + 6 * arr) != 0) return -1;
+    u8 *d_in = c->stage, *d_pl = d_in + in_al, *d_out = d_pl + in_al, *meta = d_out + out_tot;
+    u64 *d_in_off = (u64 *)meta, *d_out_off = (u64 *)(meta + arr);
+    u32 *d_isz = (u32 *)(meta + 2 * arr), *d_cap = (u32 *)(meta + 3 * arr), *d_osz = (u32 *)(meta + 4 * arr);
+    i32 *d_st = (i32 *)(meta + 5 * arr), *d_ord = (i32 *)(meta + 5 * arr + arr / 2);
+    HIPCHK(c, hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, 0));
+    r4x16_launch_stripe(d_in, d_pl, n, (u32)N, 0, 0);
+    HIPCHK(c, hipMemcpyAsync(d_in_off, in_off.data(), (size_t)items * 8, hipMemcpyHostToDevice, 0));
+    HIPCHK(c, hipMemcpyAsync(d_out_off, out_off.data(), (size_t)items * 8, hipMemcpyHostToDevice, 0));
+    HIPCHK(c, hipMemcpyAsync(d_isz, isz.data(), (size_t)items * 4, hipMemcpyHostToDevice, 0));
+    HIPCHK(c, hipMemcpyAsync(d_cap, cap.data(), (size_t)items * 4, hipMemcpyHostToDevice, 0));
+    HIPCHK(c, hipMemcpyAsync(d_ord, ord.data(), (size_t)items * 4, hipMemcpyHostToDevice, 0));
+    if (rans4x16_hip_compress_dev(c, items, d_pl, d_in_off, d_isz, d_out, d_out_off, d_cap, d_osz, d_st,
+                                  0, d_ord, max_in, nullptr) != 0) return -1;
+    std::vector<u32> osz(items);
+    std::vector<i32> st(items);
+    HIPCHK(c, hipMemcpy(osz.data(), d_osz, (size_t)items * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(st.data(), d_st, (size_t)items * 4, hipMemcpyDeviceToHost));
+    for (int it = 0; it < items; it++) if (st[it] != 0) return 1;
+
+    unsigned int hdr = 1;
+    out[0] = (unsigned char)(order & ~X_NOSZ);                         // :1185
+    hdr += var_put_host(out + hdr, n);
+    out[hdr++] = (unsigned char)N;
+    std::vector<int> best(N);
+    for (int j = 0; j < N; j++) {                                      // smallest wins, first on ties (:1199)
+        u32 best_sz = n + 10;
+        best[j] = 0;
+        for (int k = 0; k < K; k++)
+            if (best_sz > osz[j * K + k]) { best_sz = osz[j * K + k]; best[j] = k; }
+        hdr += var_put_host(out + hdr, osz[j * K + best[j]]);
+    }
+    unsigned int pos = hdr;
+    for (int j = 0; j < N; j++) {
+        const int it = j * K + best[j];
+        HIPCHK(c, hipMemcpyAsync(out + pos, d_out + out_off[it], osz[it], hipMemcpyDeviceToHost, 0));
+        pos += osz[it];
+    }
+    HIPCHK(c, hipStreamSynchronize(0));
+    *out_size = pos;
+    return 0;
+}
+
+static int stripe_uncompress(rans4x16_hip_ctx *c, const unsigned char *in, unsigned int in_size,
+                             unsigned char *out, unsigned int *out_size)
+{
+    const unsigned char *end = in + in_size;
+    u32 ulen, hdr = 1;
+    hdr += var_get_host(in + hdr, end, &ulen);
+    if (hdr >= in_size) return 1;                                      // :1367
+    const u32 N = in[hdr++];
+    if (ulen != *out_size) return 1;                                   // :1379 (caller sized the buffer)
+    if (N == 0) return ulen ? 1 : 0;                                   // the reference spins forever here
+    std::vector<u32> clen(N), plen(N), first(N);
+    u64 ctot = 0;
+    for (u32 j = 0; j < N; j++) {
+        plen[j] = ulen / N + ((ulen % N) > j);
+        first[j] = j ? first[j - 1] + plen[j - 1] : 0;
+        hdr += var_get_host(in + hdr, end, &clen[j]);
+        ctot += clen[j];
+        if (hdr > in_size || clen[j] > in_size || clen[j] < 1) return 1;   // :1389
+    }
+    if (hdr + ctot > in_size) return 1;                                // :1398
+    in_size = (unsigned int)(hdr + ctot);
+
+    // sub-block j starts at hdr + sum(clen[<j]) and may read to the end of the stripe block (:1419)
+    std::vector<u64> in_off(N), out_off(N);
+    std::vector<u32> isz(N), cap(N);
+    u32 off = hdr, max_in = 0, max_cap = 0;
+    for (u32 j = 0; j < N; j++) {
+        in_off[j] = off; isz[j] = in_size - off; cap[j] = plen[j]; out_off[j] = first[j];
+        if (isz[j] > max_in) max_in = isz[j];
+        if (cap[j] > max_cap) max_cap = cap[j];
+        off += clen[j];
+    }
+    const size_t in_al = align_up((size_t)in_size + 16, 256), pl_al = align_up((size_t)ulen + 16, 256);
+    const size_t arr = align_up((size_t)N * 8, 256);
+    if (ensure_stage(c, in_al + 2 * pl_al + 6 * arr) != 0) return -1;
+    u8 *d_in = c->stage, *d_pl = d_in + in_al, *d_out = d_pl + pl_al, *meta = d_out + pl_al;
+    u64 *d_in_off = (u64 *)meta, *d_out_off = (u64 *)(meta + arr);
+    u32 *d_isz = (u32 *)(meta + 2 * arr), *d_cap = (u32 *)(meta + 3 * arr), *d_osz = (u32 *)(meta + 4 * arr);
+    i32 *d_st = (i32 *)(meta + 5 * arr);
+    HIPCHK(c, hipMemcpyAsync(d_in, in, in_size, hipMemcpyHostToDevice, 0));
+    HIPCHK(c, hipMemcpyAsync(d_in_off, in_off.data(), (size_t)N * 8, hipMemcpyHostToDevice, 0));
+    HIPCHK(c, hipMemcpyAsync(d_out_off, out_off.data(), (size_t)N * 8, hipMemcpyHostToDevice, 0));
+    HIPCHK(c, hipMemcpyAsync(d_isz, isz.data(), (size_t)N * 4, hipMemcpyHostToDevice, 0));
+    HIPCHK(c, hipMemcpyAsync(d_cap, cap.data(), (size_t)N * 4, hipMemcpyHostToDevice, 0));
+    if (rans4x16_hip_uncompress_dev(c, (int)N, d_in, d_in_off, d_isz, d_pl, d_out_off, d_cap, d_osz, d_st,
+                                    max_in, max_cap, nullptr) != 0) return -1;
+    std::vector<u32> osz(N);
+    std::vector<i32> st(N);
+    HIPCHK(c, hipMemcpy(osz.data(), d_osz, (size_t)N * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(st.data(), d_st, (size_t)N * 4, hipMemcpyDeviceToHost));
+    for (u32 j = 0; j < N; j++) if (st[j] != 0 || osz[j] != plen[j]) return 1;   // :1419-1420
+    r4x16_launch_stripe(d_pl, d_out, ulen, N, 1, 0);
+    if (ulen) HIPCHK(c, hipMemcpy(out, d_out, ulen, hipMemcpyDeviceToHost));
+    *out_size = ulen;
+    return 0;
 }
 
 extern "C" int rans4x16_hip_compress_batch(rans4x16_hip_ctx *c, int n,

@@ -979,3 +979,33 @@ extern "C" void r4x16_launch_dec_back(const BatchArgs *a, const DecWs *ws, int b
 {
     hipLaunchKernelGGL(k_dec_back, dim3(nblk), dim3(WAVE), 0, s, *a, *ws, base);
 }
+
+// ---------------------------------------------------------------------------------------------
+// X_STRIPE byte-plane transposition (rANS_static4x16pr.c:1168-1180 and unstripe, utils.h:41-73).
+// Plane j holds bytes j, j+N, j+2N, ...; first[j] is its offset in the plane buffer.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_stripe_split(const u8 *in, u8 *planes, u32 n, u32 N)
+{
+    const u32 base = n / N, extra = n % N;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const u32 j = i % N, x = i / N;
+        const u32 first = j * base + (j < extra ? j : extra);
+        planes[first + x] = in[i];
+    }
+}
+__global__ void k_stripe_join(const u8 *planes, u8 *out, u32 n, u32 N)
+{
+    const u32 base = n / N, extra = n % N;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const u32 j = i % N, x = i / N;
+        const u32 first = j * base + (j < extra ? j : extra);
+        out[i] = planes[first + x];
+    }
+}
+extern "C" void r4x16_launch_stripe(const u8 *src, u8 *dst, u32 n, u32 N, int join, hipStream_t s)
+{
+    if (!n) return;
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    if (join) hipLaunchKernelGGL(k_stripe_join, dim3(grid), dim3(256), 0, s, src, dst, n, N);
+    else      hipLaunchKernelGGL(k_stripe_split, dim3(grid), dim3(256), 0, s, src, dst, n, N);
+}
