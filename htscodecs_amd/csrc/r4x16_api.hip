@@ -21,7 +21,7 @@ void r4x16_launch_dec_front(const BatchArgs *, const DecWs *, int, int, hipStrea
 void r4x16_launch_dec_chain(const DecWs *, int, hipStream_t);
 void r4x16_launch_dec_back(const BatchArgs *, const DecWs *, int, int, hipStream_t);
 void r4x16_launch_enc_front(const BatchArgs *, const EncWs *, int, int, hipStream_t);
-void r4x16_launch_enc_chain(const EncWs *, int, int, hipStream_t);
+void r4x16_launch_enc_chain(const EncWs *, int, hipStream_t);
 void r4x16_launch_enc_finish(const BatchArgs *, const EncWs *, int, int, hipStream_t);
 u32  r4x16_compress_bound(u32 size, int order);
 void r4x16_launch_stripe(const u8 *, u8 *, u32, u32, int, hipStream_t);
@@ -223,7 +223,7 @@ extern "C" int rans4x16_hip_compress_dev(rans4x16_hip_ctx *c, int n,
         r4x16_launch_enc_front(&a, &w, (int)base, nb, s);
         TimedLaunch t;
         if (c->timing) time_begin(c, 0, s, t);
-        r4x16_launch_enc_chain(&w, 2 * nb, 16, s);
+        r4x16_launch_enc_chain(&w, 2 * nb, s);
         if (c->timing) time_end(c, 0, s, t);
         r4x16_launch_enc_finish(&a, &w, (int)base, nb, s);
     }

@@ -103,18 +103,27 @@ struct DecDesc {
 };
 
 // ---------------------------------------------------------------------------------------------
-// Encode image (per item): one 8-byte entry per (context row, byte value):
-//   u32 rcp   reciprocal (rANS_word.h:252, or ~0 for freq 1)
-//   u32 pk    bias[0:13) | cmpl_freq[13:26) | rcp_shift[26:31)     (rANS_word.h:190-266)
-//   x_max is (M - cmpl_freq) << (31 - bits).
-// Rows are indexed by byte value directly (256 entries, 2 KB per row); order-1 uses rows only
-// for contexts that occur, addressed through ctxrow[256] (u16 row number per context byte).
+// Encode image (per item), compact:
+//   [0,256)            u8 idx_of[256] : byte value -> compact symbol index (order-0: identity)
+//   [256, 256+8*R*ns)  EncEntry ent[R][ns] : entry of (context row r, symbol index s) at r*ns + s;
+//                      order-1: R = ns = size of the alphabet (byte 0 included, index 0);
+//                      order-0: R = 1, ns = 256.
+//   EncEntry = { u32 rcp; u32 pk } : reciprocal (rANS_word.h:252, or ~0 for freq 1) and
+//              bias[0:13) | cmpl_freq[13:26) | rcp_shift[26:31)      (rANS_word.h:190-266);
+//              x_max is (M - cmpl_freq) << (31 - bits).
+// An order-1 image for a 46-symbol alphabet is 17 KB, so nine streams' tables fit one CU's LDS.
 // ---------------------------------------------------------------------------------------------
 struct EncEntry { u32 rcp; u32 pk; };
+#define ENC_IMG_IDX    256u
+#define ENC_IMG_MAIN   (ENC_IMG_IDX + 8u * 256u * 256u + 0u)      // 524,544
+#define ENC_IMG_O0     (ENC_IMG_IDX + 8u * 256u)                  // 2,304
+#define ENC_IMG_NESTED 524800u                                    // offset of the nested-table image
+#define ENC_IMG_META   (ENC_IMG_NESTED + 2304u)                   // offset of the RLE-meta image
+#define ENC_IMG_BYTES  (ENC_IMG_META + 2304u)                     // 529,408 per block
 
 struct EncItem {
     u64 data;        // device address of the bytes to code
-    u64 image;       // device address of EncEntry rows
+    u64 image;       // device address of the image
     u64 scratch_end; // device address one past the end of this item's backward-write area (even)
     u32 n;           // number of bytes
     u32 bits;        // 12 (order-0) or 10/12
@@ -122,7 +131,9 @@ struct EncItem {
     u32 active;
     u32 pay_len;     // OUT: bytes written backwards (states + words)
     u32 blk;
-    u16 ctxrow[256]; // order-1: context byte -> row number in image (order-0: unused)
+    u32 ns;          // symbols per image row
+    u32 img_bytes;   // bytes of the image (what must sit in LDS)
+    u32 pad[2];
 };
 
 // Per-block record of the encode pipeline.
@@ -148,8 +159,6 @@ struct EncDesc {
 // ---------------------------------------------------------------------------------------------
 #define TBUF_BYTES     204800u                          // an un-nested order-1 table (257*257*3 = 198147 max)
 #define DEC_IMG_SLOT   (IMG_MAX_BYTES + 2u * IMG_O0_BYTES)   // payload image, nested-table image, RLE-meta image
-#define ENC_IMG_ROWS   258u
-#define ENC_IMG_BYTES  (ENC_IMG_ROWS * 256u * 8u)       // 256 context rows + spare rows for the nested table coder and the RLE meta stream
 #define TAB_BYTES      198656u                          // >= 1 + 257*257*3 (assert at rANS_static4x16pr.c:784)
 
 struct DecWs {

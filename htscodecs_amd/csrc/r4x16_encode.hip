@@ -110,16 +110,37 @@ __device__ __forceinline__ EncEntry make_entry(u32 start, u32 freq, u32 bits)
 // then x += bias + ((x * rcp) >> rcp_shift) * cmpl_freq.  Within one step the reference emits
 // in chain order 3,2,1,0 onto a descending pointer, so chain k's word lands
 // 2 * (1 + #emitting chains above k) below the step's starting pointer.
+//
+// Step schedule of a stream of n bytes (lock-step for its four chains):
+//   order-0 (:442-459): step s codes group g = gtop - s, chain k takes byte 4g+k; the top group
+//                       may be partial.
+//   order-1 (:794-834): chain k owns quarter k; chain 3 first codes the n - 4q tail bytes alone,
+//                       then all four walk their quarters backwards with the previous byte as
+//                       context, and the first byte of each quarter is coded in context 0.
 // ---------------------------------------------------------------------------------------------
 typedef GAS const EncEntry gcEncEntry;
-typedef GAS const u16 gcu16;
 
+// One coding step given the entry; returns the emit flag (for the caller's ballot).
+__device__ __forceinline__ bool enc_wants_emit(u32 x, u32 pk, u32 bits)
+{
+    const u32 cmpl = (pk >> 13) & 0x1fffu;
+    const u32 x_max = ((1u << bits) - cmpl) << (31 - bits);
+    return x >= x_max;
+}
+__device__ __forceinline__ u32 enc_advance(u32 x, u32 rcp, u32 pk)
+{
+    const u32 qq = __umulhi(x, rcp) >> (pk >> 26);
+    return x + (pk & 0x1fffu) + qq * ((pk >> 13) & 0x1fffu);
+}
+
+// General form: image in global memory, byte loads.  Used for the small nested streams inside
+// k_enc_front and for alphabets whose tables do not fit LDS.
 template <int ORDER>
-__device__ __forceinline__ u32 chain_encode(gcu8 *data, u32 n, gcEncEntry *img,
-                                            gcu16 *ctxrow, u32 bits, gu8 *scratch_end,
-                                            bool active, u32 lane)
+__device__ __forceinline__ u32 chain_encode(gcu8 *data, u32 n, gcu8 *image, u32 ns, u32 bits,
+                                            gu8 *scratch_end, bool active, u32 lane)
 {
     const u32 k = lane & 3;
+    gcEncEntry *ent = (gcEncEntry *)(image + ENC_IMG_IDX);
     u32 x = RANS_LOW;
     u32 written = 0;                 // words emitted by the quad so far
     u32 nsteps, first;               // this lane takes part in steps [first, nsteps)
@@ -138,31 +159,24 @@ __device__ __forceinline__ u32 chain_encode(gcu8 *data, u32 n, gcEncEntry *img,
     }
     if (!active) { nsteps = 0; first = 0; }
 
-    u32 cur = 0;
-    if (nsteps > first) cur = data[p];
-    const u32 row0 = (ORDER == 1 && active) ? (u32)ctxrow[0] : 0u;
+    u32 cur = 0;                                 // compact index of the symbol coded next
+    if (nsteps > first) cur = image[data[p]];
 
     for (u32 s = 0; wave_any(s < nsteps); s++) {
         const bool live = s >= first && s < nsteps;
         bool emit = false;
-        EncEntry e;
-        e.rcp = 0; e.pk = 0;
-        u32 nextc = 0;
+        u32 rcp = 0, pk = 0, nextc = 0;
         if (live) {
-            u32 row;
+            u32 row = 0;
             if (ORDER == 0) {
-                row = 0;
-                if (p >= 4) nextc = data[p - 4];
-            } else {
-                // context = previous byte, except at the start of the quarter (:831-834)
-                const bool at_start = (s == nsteps - 1);
-                if (!at_start) { nextc = data[p - 1]; row = ctxrow[nextc]; }
-                else row = row0;
+                if (p >= 4) nextc = image[data[p - 4]];
+            } else if (s != nsteps - 1) {        // context = previous byte; quarter start: context 0
+                nextc = image[data[p - 1]];
+                row = nextc;
             }
-            { const gcEncEntry *ep = &img[row * 256u + cur]; e.rcp = ep->rcp; e.pk = ep->pk; }
-            const u32 cmpl = (e.pk >> 13) & 0x1fffu;
-            const u32 x_max = ((1u << bits) - cmpl) << (31 - bits);
-            emit = x >= x_max;
+            gcEncEntry *ep = &ent[row * ns + cur];
+            rcp = ep->rcp; pk = ep->pk;
+            emit = enc_wants_emit(x, pk, bits);
         }
         const u32 em = quad_ballot(emit, lane);
         if (emit) {
@@ -172,13 +186,164 @@ __device__ __forceinline__ u32 chain_encode(gcu8 *data, u32 n, gcEncEntry *img,
         }
         written += __popc(em);
         if (live) {
-            const u32 qq = (u32)(((u64)x * e.rcp) >> (32 + (e.pk >> 26)));
-            x = x + (e.pk & 0x1fffu) + qq * ((e.pk >> 13) & 0x1fffu);
+            x = enc_advance(x, rcp, pk);
             cur = nextc;
             p -= (ORDER == 0) ? 4 : 1;
         }
     }
     // RansEncFlush x4 in order 3,2,1,0 (:482-485): R0 ends up lowest in memory
+    if (active) *(gu32 *)(scratch_end - 2 * written - 16 + 4 * k) = x;
+    return active ? 2 * written + 16 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Hot form, order-1: the image sits in LDS and nothing on the dependent path (the state x)
+// touches memory.  Symbols are known in advance, so their table entries are fetched one trip
+// (four steps) ahead: a trip issues the global load of the input dword two trips ahead, the LDS
+// index lookups of the next trip's bytes and their entry reads, and then runs four state updates
+// on entries that were loaded during the previous trip.
+// The schedule is phased per wave: (A) up to three tail steps, chain 3 only; (B) whole trips of
+// the backward walk; (B') its last 0..3 steps; (C) the quarter starts in context 0.  Streams of
+// different lengths in one wave simply drop out of (B) at different trips.
+// ---------------------------------------------------------------------------------------------
+struct EncLds {
+    const u8 *idx;                  // u8  idx_of[256]
+    const u32x2 *ent;               // {rcp, pk}[ns*ns]
+};
+
+__device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, gcu8 *data, u32 n, u32 ns, u32 bits,
+                                                   gu8 *scratch_end, bool active, u32 lane)
+{
+    const u32 k = lane & 3;
+    const u32 qshift = lane & ~3u;
+    const u8 *idx = img_lds;
+    const u32x2 *ent = (const u32x2 *)(img_lds + ENC_IMG_IDX);
+    u32 x = RANS_LOW, written = 0;
+    const u32 q = active ? n >> 2 : 0;
+    const u32 tail = active ? n - 4 * q : 0;
+
+    auto step = [&](bool live, u32 rcp, u32 pk) {
+        const bool emit = live && enc_wants_emit(x, pk, bits);
+        const u32 em = (u32)(__ballot(emit) >> qshift) & 0xfu;
+        if (emit) {
+            const u32 above = __popc(em >> (k + 1));
+            *(gu16 *)(scratch_end - 2 * (written + above + 1)) = (u16)x;
+            x >>= 16;
+        }
+        written += __popc(em);
+        const u32 xn = enc_advance(x, rcp, pk);
+        x = live ? xn : x;
+    };
+
+    // (A) tail bytes n-1 .. 4q on chain 3, context = previous byte (:806-811)
+    u32 cur = 0;
+    if (active && k == 3 && tail) cur = idx[data[n - 1]];
+    for (u32 s = 0; wave_any(s < tail); s++) {
+        const bool live = k == 3 && s < tail;
+        u32 rcp = 0, pk = 0;
+        if (live) {
+            const u32 ci = idx[data[n - 2 - s]];
+            const u32x2 e = ent[ci * ns + cur];
+            rcp = e.x; pk = e.y;
+            cur = ci;
+        }
+        step(live, rcp, pk);
+    }
+
+    // (B) backward walk over offsets q-1 .. 1 of each quarter (:813-829); chain k codes byte
+    // k*q + r in context byte k*q + r - 1.
+    gcu8 *qbase = data + (u64)k * q;
+    u32 r = q ? q - 1 : 0;                      // offset of the next symbol to code; stops at 0
+    const u32 main = q ? q - 1 : 0;              // steps in (B)+(B')
+    u32 done = 0;
+    cur = (active && q) ? idx[qbase[r]] : 0u;
+    if (wave_any(main >= 4)) {
+        // bytes r-1 .. r-4 are the next four contexts (and the following four symbols)
+        auto load4 = [&](u32 rr) -> u32 {        // dword holding bytes rr-4 .. rr-1, 0 when out of range
+            return (main >= 4 && rr >= 4) ? *(GAS const u32_unaligned *)(qbase + rr - 4) : 0u;
+        };
+        u32 w = load4(r);                        // contexts of trip 0
+        u32 wn = (r >= 4) ? load4(r - 4) : 0u;   // contexts of trip 1
+        // entries of trip 0
+        u32x2 E0, E1, E2, E3;
+        u32 c0, c1, c2, c3;
+        auto lookup = [&](u32 ww, u32 sym, u32x2 &e0, u32x2 &e1, u32x2 &e2, u32x2 &e3, u32 &last) {
+            c0 = idx[ww >> 24]; c1 = idx[(ww >> 16) & 0xff]; c2 = idx[(ww >> 8) & 0xff]; c3 = idx[ww & 0xff];
+            e0 = ent[c0 * ns + sym]; e1 = ent[c1 * ns + c0]; e2 = ent[c2 * ns + c1]; e3 = ent[c3 * ns + c2];
+            last = c3;
+        };
+        u32 nxt_cur = 0;
+        lookup(w, cur, E0, E1, E2, E3, nxt_cur);
+        while (wave_any(done + 4 <= main)) {
+            const bool live = done + 4 <= main;
+            // prefetch for the next trip (entries) and the one after (input dword)
+            const u32 rn = r - 4;                               // symbol offset at the next trip
+            const bool more = live && done + 8 <= main;
+            u32x2 N0 = {0, 0}, N1 = {0, 0}, N2 = {0, 0}, N3 = {0, 0};
+            u32 ncur2 = 0;
+            const u32 wnn = (more && rn >= 8) ? load4(rn - 4) : 0u;
+            if (more) lookup(wn, nxt_cur, N0, N1, N2, N3, ncur2);
+            step(live, E0.x, E0.y);
+            step(live, E1.x, E1.y);
+            step(live, E2.x, E2.y);
+            step(live, E3.x, E3.y);
+            if (live) { done += 4; r = rn; cur = nxt_cur; }
+            E0 = N0; E1 = N1; E2 = N2; E3 = N3;
+            nxt_cur = ncur2; wn = wnn;
+        }
+    }
+    // (B') remaining walk steps, one at a time
+    for (; wave_any(done < main); ) {
+        const bool live = done < main;
+        u32 rcp = 0, pk = 0;
+        if (live) {
+            const u32 ci = idx[qbase[r - 1]];
+            const u32x2 e = ent[ci * ns + cur];
+            rcp = e.x; pk = e.y;
+            cur = ci; r--; done++;
+        }
+        step(live, rcp, pk);
+    }
+    // (C) first byte of each quarter in context 0 (:831-834)
+    {
+        const bool live = active && q > 0;
+        u32 rcp = 0, pk = 0;
+        if (live) { const u32x2 e = ent[0 * ns + cur]; rcp = e.x; pk = e.y; }
+        step(live, rcp, pk);
+    }
+    if (active) *(gu32 *)(scratch_end - 2 * written - 16 + 4 * k) = x;
+    return active ? 2 * written + 16 : 0;
+}
+
+// Hot form, order-0: one row of entries in LDS; chain k takes bytes 4g+k for descending g.
+__device__ __forceinline__ u32 chain_encode_o0_lds(const u8 *img_lds, gcu8 *data, u32 n, u32 bits,
+                                                   gu8 *scratch_end, bool active, u32 lane)
+{
+    const u32 k = lane & 3;
+    const u32 qshift = lane & ~3u;
+    const u8 *idx = img_lds;
+    const u32x2 *ent = (const u32x2 *)(img_lds + ENC_IMG_IDX);
+    u32 x = RANS_LOW, written = 0;
+    const u32 gtop = (active && n) ? (n - 1) >> 2 : 0;
+    u32 nsteps = (active && n) ? gtop + 1 : 0;
+    const u32 first = (active && n && 4 * gtop + k >= n) ? 1 : 0;    // top group may be partial
+    u32 p = 4 * (gtop - first) + k;
+    u32 byte = (nsteps > first) ? data[p] : 0u;
+    for (u32 s = 0; wave_any(s < nsteps); s++) {
+        const bool live = s >= first && s < nsteps;
+        const u32x2 e = ent[idx[byte]];
+        const u32 nb = (live && p >= 4) ? data[p - 4] : 0u;          // next group's byte, a step ahead
+        const bool emit = live && enc_wants_emit(x, e.y, bits);
+        const u32 em = (u32)(__ballot(emit) >> qshift) & 0xfu;
+        if (emit) {
+            const u32 above = __popc(em >> (k + 1));
+            *(gu16 *)(scratch_end - 2 * (written + above + 1)) = (u16)x;
+            x >>= 16;
+        }
+        written += __popc(em);
+        const u32 xn = enc_advance(x, e.x, e.y);
+        if (live) { x = xn; byte = nb; p -= 4; }
+    }
     if (active) *(gu32 *)(scratch_end - 2 * written - 16 + 4 * k) = x;
     return active ? 2 * written + 16 : 0;
 }
@@ -250,8 +415,10 @@ __device__ u32 put_alphabet(u8 *cp, const u8 *present)
 
 // Order-0 stream front end (rANS_static4x16pr.c:405-435): histogram, two normalisations, table
 // bytes to `tab`, encoder row to `imgrow`.  All lanes call.  Sets S.tab_len / S.status.
-__device__ void enc_o0_front(const u8 *data, u32 n, u8 *tab, EncEntry *imgrow, EncShared &S, u32 lane)
+__device__ void enc_o0_front(const u8 *data, u32 n, u8 *tab, u8 *image, EncShared &S, u32 lane)
 {
+    EncEntry *imgrow = (EncEntry *)(image + ENC_IMG_IDX);
+    for (u32 j = lane; j < 256; j += WAVE) image[j] = (u8)j;       // order-0: symbols index the row directly
     wave_hist8(data, n, S.F, lane);
     if (lane == 0) {
         u32 target = pow2_ceil(n);
@@ -410,7 +577,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
     const u32 in_size = a.in_size[i];
     const u32 cap = a.out_cap[i];
     int order = a.d_order ? a.d_order[i] : a.order;
-    EncEntry *img = (EncEntry *)(ws.images + (u64)b * ENC_IMG_BYTES);
+    u8 *img = ws.images + (u64)b * ENC_IMG_BYTES;
     u8 *tab = ws.tab + (u64)b * TAB_BYTES;
     u8 *tabraw = ws.tabraw + (u64)b * TAB_BYTES;
     u8 *scratch = ws.scratch + (u64)b * ws.scratch_stride;
@@ -495,13 +662,14 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
                 __syncthreads();
                 // the meta is coded as an order-0 stream by the chain kernel (item I1)
                 u8 *mtab = ws.metatab + (u64)b * META_TAB_BYTES;
-                EncEntry *imgm = img + 257u * 256u;
+                u8 *imgm = img + ENC_IMG_META;
                 enc_o0_front(m, mlen, mtab, imgm, S, lane);
                 if (lane == 0) {
                     D->rle_on = 1; D->rle_mlen = mlen; D->rle_lits = nlits;
                     D->rle_meta = (u64)m; D->meta_tab = (u64)mtab; D->meta_tab_len = S.tab_len;
                     if (S.status != ST_OK) D->status = S.status;
                     I1->data = (u64)m; I1->n = mlen; I1->image = (u64)imgm; I1->bits = O0_BITS; I1->order = 0;
+                    I1->ns = 256; I1->img_bytes = ENC_IMG_O0;
                     I1->scratch_end = (u64)(ws.scratch2 + (u64)b * ws.scratch2_stride + ws.scratch2_stride);
                     __threadfence();
                     I1->active = S.status == ST_OK;
@@ -532,6 +700,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
             D->status = S.status;
             D->tab_len = S.tab_len;
             I0->data = (u64)data; I0->n = n; I0->image = (u64)img; I0->bits = O0_BITS; I0->order = 0;
+            I0->ns = 256; I0->img_bytes = ENC_IMG_O0;
             I0->scratch_end = (u64)scratch_end;
             __threadfence();
             I0->active = S.status == ST_OK;
@@ -704,7 +873,8 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
     const u32 tlen = S.tab_len;
 
     // ---- encoder image: scale each row up to 1<<bits (:756) and build entries (:759-762) -----------
-    for (u32 j = lane; j < 256; j += WAVE) I0->ctxrow[j] = S.present[j] ? (u16)S.idx_of[j] : (u16)0;
+    for (u32 j = lane; j < 256; j += WAVE) img[j] = S.present[j] ? S.idx_of[j] : (u8)0;
+    EncEntry *ent = (EncEntry *)(img + ENC_IMG_IDX);
     for (u32 r = 0; r < ns; r++) {
         u32 sh = 0;
         const u32 tgt = (u32)S.S[r];
@@ -714,7 +884,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
             const u32 j = jb + lane;
             const u32 f = (j < ns) ? (Fp[r * ns + j] << sh) : 0u;
             const u32 incl = wave_incl_scan(f, lane);
-            if (f) img[r * 256u + S.alpha[j]] = make_entry(carry + incl - f, f, bits);
+            if (f) ent[r * ns + j] = make_entry(carry + incl - f, f, bits);
             carry += __shfl(incl, WAVE - 1);
         }
     }
@@ -725,12 +895,12 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
     u32 final_len = 0;
     bool nested = false;
     if (1 + tlen > 1000) {
-        EncEntry *img0 = img + 256u * 256u;
+        u8 *img0 = img + ENC_IMG_NESTED;
         u8 *ntab = scratch;                                           // nested table bytes, staged low
         enc_o0_front(tabraw, tlen, ntab, img0, S, lane);
         __threadfence();
         __syncthreads();
-        const u32 npay = chain_encode<0>(to_global((const u8 *)tabraw), tlen, to_global((const EncEntry *)img0), (gcu16 *)nullptr,
+        const u32 npay = chain_encode<0>(to_global((const u8 *)tabraw), tlen, to_global((const u8 *)img0), 256u,
                                          O0_BITS, to_global(scratch_end), lane < 4, lane);
         const u32 np = __shfl(npay, 0);
         __threadfence();
@@ -762,6 +932,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
     if (lane == 0) {
         D->tab_len = final_len;
         I0->data = (u64)data; I0->n = n; I0->image = (u64)img; I0->bits = bits; I0->order = 1;
+        I0->ns = ns; I0->img_bytes = ENC_IMG_IDX + 8u * ns * ns;
         I0->scratch_end = (u64)scratch_end;
         __threadfence();
         I0->active = 1;
@@ -769,23 +940,47 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_enc_chain: QPW streams per wave.
+// k_enc_chain: QPW streams per wave, one launch per LDS size class (see k_dec_chain).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVE) void k_enc_chain(EncItem *items, int nitems, int qpw)
+template <bool LDS_IMG>
+__global__ __launch_bounds__(WAVE) void k_enc_chain(EncItem *items, int nitems, int qpw, u32 lds_per_item,
+                                                    u32 cls_lo, u32 cls_hi)
 {
+    extern __shared__ __attribute__((aligned(16))) u8 lds[];
     const u32 lane = threadIdx.x;
     const u32 quad = lane >> 2;
     const int it = (int)blockIdx.x * qpw + (int)quad;
     const bool mine = quad < (u32)qpw && it < nitems;
-    EncItem *I = mine ? &items[it] : &items[0];
-    const bool active = mine && I->active;
+    EncItem *I = &items[mine ? it : 0];
+    bool active = mine && I->active;
+    const u32 img_bytes = active ? I->img_bytes : 0u;
+    active = active && img_bytes > cls_lo && img_bytes <= cls_hi;
+    if (!wave_any(active)) return;
+
     const u32 order = active ? I->order : 2u;
     gcu8 *data = (gcu8 *)I->data;
-    gcEncEntry *img = (gcEncEntry *)I->image;
     gu8 *send = (gu8 *)I->scratch_end;
-    gcu16 *ctxrow = to_global((const u16 *)I->ctxrow);
-    u32 pay = chain_encode<1>(data, I->n, img, ctxrow, I->bits, send, order == 1, lane);
-    pay |= chain_encode<0>(data, I->n, img, ctxrow, I->bits, send, order == 0, lane);
+    const u32 n = I->n, ns = I->ns, bits = active ? I->bits : 12u;
+    u32 pay;
+    if (LDS_IMG) {
+        const u64 my_img = active ? I->image : 0ull;
+        for (int qd = 0; qd < qpw; qd++) {
+            const u64 src = __shfl(my_img, qd * 4);
+            const u32 nb = __shfl(img_bytes, qd * 4);
+            if (!src) continue;
+            gcu32x4 *s = (gcu32x4 *)src;
+            u32x4 *dd = (u32x4 *)(lds + (u64)qd * lds_per_item);
+            for (u32 j = lane; j < ((nb + 15) >> 4); j += WAVE) dd[j] = s[j];
+        }
+        __syncthreads();
+        const u8 *im = lds + (u64)quad * lds_per_item;
+        pay = chain_encode_o1_lds(im, data, n, ns, bits, send, order == 1, lane);
+        pay |= chain_encode_o0_lds(im, data, n, bits, send, order == 0, lane);
+    } else {
+        gcu8 *im = (gcu8 *)I->image;
+        pay = chain_encode<1>(data, n, im, ns, bits, send, order == 1, lane);
+        pay |= chain_encode<0>(data, n, im, ns, bits, send, order == 0, lane);
+    }
     if (active && (lane & 3) == 0) I->pay_len = pay;
 }
 
@@ -870,10 +1065,25 @@ extern "C" void r4x16_launch_enc_front(const BatchArgs *a, const EncWs *ws, int 
     }
     hipLaunchKernelGGL(k_enc_front, dim3(nblk), dim3(WAVE), FRONT_DYN_LDS, s, *a, *ws, base);
 }
-extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, int qpw, hipStream_t s)
+static const struct { u32 bytes; int qpw; } ENC_CLASSES[] = {
+    {2560, 16}, {5120, 8}, {10240, 4}, {18432, 1}, {40960, 1}, {81920, 1}, {163840, 1},
+};
+extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t s)
 {
-    const int grid = (nitems + qpw - 1) / qpw;
-    hipLaunchKernelGGL(k_enc_chain, dim3(grid), dim3(WAVE), 0, s, ws->items, nitems, qpw);
+    static bool once = false;
+    if (!once) {
+        (void)hipFuncSetAttribute((const void *)k_enc_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        once = true;
+    }
+    u32 lo = 0;
+    for (const auto &c : ENC_CLASSES) {
+        const int grid = (nitems + c.qpw - 1) / c.qpw;
+        hipLaunchKernelGGL(k_enc_chain<true>, dim3(grid), dim3(WAVE), (size_t)c.qpw * c.bytes, s,
+                           ws->items, nitems, c.qpw, c.bytes, lo, c.bytes);
+        lo = c.bytes;
+    }
+    const int grid = (nitems + 15) / 16;
+    hipLaunchKernelGGL(k_enc_chain<false>, dim3(grid), dim3(WAVE), 0, s, ws->items, nitems, 16, 0u, lo, 0xffffffffu);
 }
 extern "C" void r4x16_launch_enc_finish(const BatchArgs *a, const EncWs *ws, int base, int nblk, hipStream_t s)
 {
