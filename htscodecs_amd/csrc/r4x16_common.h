@@ -40,33 +40,39 @@ typedef int32_t  i32;
 #define ST_EMPTY 9
 
 // ---------------------------------------------------------------------------------------------
-// Decode image (per item).  A sequence of rows, each 16-byte aligned, one per context
-// (order-0: a single row).  Row layout, all little-endian:
+// Decode image (per item): a 5-ary search tree over the cumulative frequencies of each context.
 //
-//   +0              u32 hdr      : byte value of this context | ROW_EMPTY flag | nnz << 16
-//   +4              u8  coarse[C]: C = 1 << (look-2); coarse[c] = index r of the entry that owns
-//                                  slot 4*c
-//   +4+C            u32 ent[nnz+4]: ent[r] = link_r | (start_r << 16) for the nnz symbols with a
-//                                  non-zero frequency, in symbol order; then a terminal entry
-//                                  with start = 1 << bits, then three pads with start 0xFFFF.
-//                                  link = (offset of that symbol's own row) / 16 for order-1,
-//                                       = the symbol's byte value for order-0.
+//   [0, A)          u16 alpha[n]   : compact symbol index -> byte value | ROW_EMPTY (that symbol's
+//                                    own context row has no table), A = 2n rounded up to 16
+//   [A, A + R*W)    one row of W bytes per context (order-0: R = 1; order-1: R = n, row of symbol s
+//                   at A + s*W).  A row holds, as u16, for cum[0..n] = cumulative starts
+//                   (cum[0] = 0, cum[n] = 1 << bits, cum[i > n] = 0xFFFF):
+//       3 levels (n <= 50):  root  : cum[10], cum[20], cum[30], cum[40]
+//                            node b: cum[10b+2], cum[10b+4], cum[10b+6], cum[10b+8]      (b = 0..4)
+//                            leaf  : cum[0 .. n+3]
+//       4 levels (n <= 256): top   : cum[50], cum[100], .., cum[400]                  (8 separators)
+//                            mid a : cum[50a+10], .., cum[50a+40]                        (a = 0..5)
+//                            low ab: cum[50a+10b+2], .., cum[50a+10b+8]                 (30 nodes)
+//                            leaf  : cum[0 .. n+3]
 //
-// Lookup of slot m (m < 1<<look): r = coarse[m>>2]; r += #(k in 1..3 : m >= start[r+k]);
-// start = start[r], freq = start[r+1] - start[r].  Four slots hold at most four symbols, so
-// three comparisons always suffice.  This gives the same answers as the reference's 4096- or
-// 1024-entry reverse tables (rANS_static4x16pr.c:538-549, :985-995) in about a third of the
-// bytes — which is what limits how many streams a CU can keep in its 160 KB LDS — and the
-// link field removes the context->row multiply from the dependent chain.
+// Lookup of slot m: at each inner level count the separators <= m (one 8-byte LDS read and four
+// compares), which narrows the symbol to a pair e, e+1; one more read of cum[e..e+2] settles it:
+// s = e + (m >= cum[e+1]), start = cum[s], freq = cum[s+1] - cum[s].  Symbols of zero frequency
+// have equal neighbours and are skipped by construction.
+//
+// The reference's reverse tables (rANS_static4x16pr.c:538-549, :985-995) take 1-4 KB per context;
+// this takes ~150 bytes for a 46-symbol alphabet whatever the table precision, so a CU's 160 KB of
+// LDS holds the tables of ~20 such streams instead of 2 — and resident streams are what the
+// decoder's throughput is made of (each stream is only four dependent chains wide).
 // ---------------------------------------------------------------------------------------------
-#define ROW_EMPTY 0x100u      // hdr flag: context has no table row (T == 0): using it is an error
-static inline __host__ __device__ u32 img_cells(u32 look) { return 1u << (look - 2); }
-static inline __host__ __device__ u32 img_row_bytes(u32 nnz, u32 look)
-{
-    return (4u + img_cells(look) + 4u * (nnz + 4u) + 15u) & ~15u;
-}
-#define IMG_O0_BYTES  2080u                       // one 12-bit row, 256 symbols
-#define IMG_MAX_BYTES (256u * 2080u)              // 256 rows, 12-bit, 256 symbols each
+#define ROW_EMPTY 0x100u
+static inline __host__ __device__ u32 img_levels(u32 n) { return n <= 50 ? 3u : 4u; }
+static inline __host__ __device__ u32 img_alpha_bytes(u32 n) { return (2u * n + 15u) & ~15u; }
+static inline __host__ __device__ u32 img_leaf_off(u32 lv) { return lv == 3 ? 48u : 304u; }
+static inline __host__ __device__ u32 img_row_bytes(u32 n) { return (img_leaf_off(img_levels(n)) + 2u * (n + 4u) + 7u) & ~7u; }
+static inline __host__ __device__ u32 img_bytes(u32 n, u32 rows) { return img_alpha_bytes(n) + rows * img_row_bytes(n); }
+#define IMG_O0_BYTES  1344u                       // 256 symbols, one row
+#define IMG_MAX_BYTES (512u + 256u * 824u)        // 256 symbols, 256 rows
 
 // One stream for the chain decoder.  80 bytes.
 struct DecItem {
@@ -77,11 +83,12 @@ struct DecItem {
     u32 out_sz;      // symbols to produce
     u32 R[4];        // initial states
     u32 img_bytes;   // size of the image
-    u32 look;        // bits looked up per symbol: 12, or 10
+    u32 look;        // bits looked up per symbol: 12, or 10 (rANS_static4x16pr.c:1027, :1071)
     u32 order;       // 0: byte i on chain i&3;  1: chain k owns quarter k (+tail on chain 3)
     u32 active;      // 0 = nothing to do (failed block, CAT, empty)
     u32 blk;         // owning block (errors are reported there)
-    u32 pad[3];
+    u32 nsym;        // compact alphabet size n (decides the tree depth and the row size)
+    u32 pad[2];
 };
 
 // Per-block record of the decode pipeline.

@@ -15,36 +15,49 @@
 // ---- image access: global memory or LDS ------------------------------------------------------
 struct GImg {
     gcu8 *p;
-    __device__ __forceinline__ u32 ld8(u32 off) const { return p[off]; }
+    __device__ __forceinline__ u32 ld16(u32 off) const { return *(GAS const u16 *)(p + off); }
     __device__ __forceinline__ u32 ld32(u32 off) const { return *(gcu32 *)(p + off); }
+    __device__ __forceinline__ u32x2 ld64(u32 off) const { return *(GAS const u32x2 *)(p + off); }
 };
 struct LImg {
     const u8 *p;     // points into __shared__
-    __device__ __forceinline__ u32 ld8(u32 off) const { return p[off]; }
+    __device__ __forceinline__ u32 ld16(u32 off) const { return *(const u16 *)(p + off); }
     __device__ __forceinline__ u32 ld32(u32 off) const { return *(const u32 *)(p + off); }
+    __device__ __forceinline__ u32x2 ld64(u32 off) const { return *(const u32x2 *)(p + off); }
 };
 
-// One table lookup + state update (rANS_static4x16pr.c:576-579 / :1033-1035).
-//   r = coarse[m>>2]; refine over at most three following entries; x = freq*(x>>look) + m - start
-// Entries carry the start in their HIGH half, so "m >= start_k" is one compare of the whole
-// dword against (m<<16 | 0xffff).  Returns the chosen entry (its low half is the link).
-template <class IMG>
-__device__ __forceinline__ u32 lookup_step(const IMG &img, u32 row, u32 cells, u32 look, u32 mask, u32 &x)
+// number of the four u16 separators in v that are <= m
+__device__ __forceinline__ u32 count_le(u32 m, u32x2 v)
+{
+    return (u32)(m >= (v.x & 0xffffu)) + (u32)(m >= (v.x >> 16)) + (u32)(m >= (v.y & 0xffffu)) + (u32)(m >= (v.y >> 16));
+}
+
+// One table lookup + state update (rANS_static4x16pr.c:576-579 / :1033-1035) on the search tree
+// described in r4x16_common.h.  `row` is the byte offset of the context's row in the image.
+// Returns the compact symbol index; x becomes freq * (x >> look) + m - start.
+template <int LV, class IMG>
+__device__ __forceinline__ u32 lookup_step(const IMG &img, u32 row, u32 look, u32 mask, u32 &x)
 {
     const u32 m = x & mask;
-    const u32 r = img.ld8(row + 4 + (m >> 2));
-    const u32 eb = row + 4 + cells + 4 * r;
-    const u32 e0 = img.ld32(eb), e1 = img.ld32(eb + 4), e2 = img.ld32(eb + 8),
-              e3 = img.ld32(eb + 12), e4 = img.ld32(eb + 16);
-    const u32 key = (m << 16) | 0xffffu;
-    u32 e = e0, en = e1;
-    if (key >= e1) { e = e1; en = e2; }
-    if (key >= e2) { e = e2; en = e3; }
-    if (key >= e3) { e = e3; en = e4; }
-    const u32 start = e >> 16;
-    const u32 freq = (en >> 16) - start;
-    x = __umul24(freq, x >> look) + (m - start);      // freq <= 2^15, x>>look < 2^22: exact mod 2^32
-    return e;
+    u32 e;
+    if (LV == 4) {
+        const u32 a = count_le(m, img.ld64(row)) + count_le(m, img.ld64(row + 8));
+        const u32 b = count_le(m, img.ld64(row + 16 + 8 * a));
+        const u32 dd = count_le(m, img.ld64(row + 64 + 8 * (5 * a + b)));
+        e = 50 * a + 10 * b + 2 * dd;
+    } else {
+        const u32 b = count_le(m, img.ld64(row));
+        const u32 dd = count_le(m, img.ld64(row + 8 + 8 * b));
+        e = 10 * b + 2 * dd;
+    }
+    const u32 lo = row + (LV == 4 ? 304u : 48u) + 2 * e;
+    const u32 c01 = img.ld32(lo), c23 = img.ld32(lo + 4);
+    const u32 c0 = c01 & 0xffffu, c1 = c01 >> 16, c2 = c23 & 0xffffu;
+    const bool up = m >= c1;
+    const u32 start = up ? c1 : c0;
+    const u32 next = up ? c2 : c1;
+    x = __umul24(next - start, x >> look) + (m - start);   // freq <= 2^15, x>>look < 2^22: exact mod 2^32
+    return e + (up ? 1u : 0u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -60,14 +73,14 @@ __device__ __forceinline__ u32 lookup_step(const IMG &img, u32 row, u32 cells, u
 // (4-bit ballot inside the quad) — the "prefix-sum compaction" of the renormalisation.
 // Returns non-zero if a context without a table row was used.
 // ---------------------------------------------------------------------------------------------
-template <int ORDER, class IMG>
-__device__ __forceinline__ u32 chain_decode(IMG img, gcu8 *words, u32 words_len, gu8 *out,
+template <int ORDER, int LV, class IMG>
+__device__ __forceinline__ u32 chain_decode(IMG img, u32 nsym, gcu8 *words, u32 words_len, gu8 *out,
                                             u32 out_sz, u32 x, u32 look, bool active, u32 lane)
 {
     const u32 k = lane & 3;
     const u32 mask = (1u << look) - 1;
-    const u32 cells = 1u << (look - 2);
     const u32 nwords = words_len >> 1;
+    const u32 rows = img_alpha_bytes(nsym), roww = img_row_bytes(nsym);
     u32 count, pos;
     if (ORDER == 0) {
         count = (out_sz + 3 - k) >> 2;            // bytes i with i%4 == k
@@ -79,22 +92,22 @@ __device__ __forceinline__ u32 chain_decode(IMG img, gcu8 *words, u32 words_len,
     }
     if (!active) count = 0;
 
-    u32 row = 0, cursor = 0, bad = 0, t = 0;
-    if (ORDER == 1 && count) bad = img.ld32(0) & ROW_EMPTY;
+    u32 row = rows, cursor = 0, bad = 0, t = 0;
+    if (ORDER == 1 && count) bad = img.ld16(0) & ROW_EMPTY;
 
     while (wave_any(t < count)) {
         const bool live = t < count;
         bool want = false;
         if (live) {
-            const u32 e = lookup_step(img, row, cells, look, mask, x);
+            const u32 s = lookup_step<LV>(img, row, look, mask, x);
+            const u32 al = img.ld16(2 * s);
             if (ORDER == 0) {
-                out[pos] = (u8)e;
+                out[pos] = (u8)al;
                 pos += 4;
             } else {
-                row = (e & 0xffffu) << 4;
-                const u32 hdr = img.ld32(row);
-                if (t + 1 < count) bad |= hdr & ROW_EMPTY;
-                out[pos] = (u8)hdr;
+                row = rows + s * roww;
+                if (t + 1 < count) bad |= al & ROW_EMPTY;
+                out[pos] = (u8)al;
                 pos += 1;
             }
             want = x < RANS_LOW;
@@ -128,14 +141,14 @@ __device__ __forceinline__ u32 chain_decode(IMG img, gcu8 *words, u32 words_len,
 
 typedef u32 GAS __attribute__((aligned(1))) gu32_unaligned;   // global dword store at any byte address
 
-template <int ORDER>
-__device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u8 *ring, gcu8 *words, u32 words_len,
+template <int ORDER, int LV>
+__device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 *ring, gcu8 *words, u32 words_len,
                                                 gu8 *out, u32 out_sz, u32 x, u32 look, bool active, u32 lane)
 {
     const LImg img{img_lds};
     const u32 k = lane & 3;
     const u32 mask = (1u << look) - 1;
-    const u32 cells = 1u << (look - 2);
+    const u32 rows = img_alpha_bytes(nsym), roww = img_row_bytes(nsym);
     const u32 nwords = words_len >> 1;
     const u32 below = (1u << k) - 1u;                      // quad lanes below this one
     const u32 qshift = lane & ~3u;
@@ -170,10 +183,10 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u8 *ring, gcu
     u32 half = 0;                                         // index of the 64-byte half holding the cursor
     __syncthreads();
 
-    u32 row = 0, cursor = 0, bad = 0, t = 0;
+    u32 row = rows, cursor = 0, bad = 0, t = 0;
     u32 acc = 0;                                          // order-1: the last (up to) 4 decoded bytes
-    u32 hdr = 0;                                          // order-1: header of the row entered last step
-    if (ORDER == 1 && count) bad = img.ld32(0) & ROW_EMPTY;
+    u32 hdr = 0;                                          // order-1: alpha[] word of the symbol decoded last step
+    if (ORDER == 1 && count) bad = img.ld16(0) & ROW_EMPTY;
 
     // Four steps per trip: one loop test, one dword store and one ring check per trip.
     while (wave_any(t < count)) {
@@ -191,10 +204,11 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u8 *ring, gcu
             const u32 sh = (cb & 3u) * 8u;
 
             u32 xn = x;
-            const u32 e = lookup_step(img, row, cells, look, mask, xn);
+            const u32 s = lookup_step<LV>(img, row, look, mask, xn);
+            const u32 hn = img.ld16(2 * s);               // byte value | ROW_EMPTY of the new context
             u32 byte0 = 0;
             if (ORDER == 0) {
-                byte0 = e & 0xffu;
+                byte0 = hn & 0xffu;
             } else {
                 // the byte of the symbol decoded one step ago and the flags of the row in use now
                 if (u > 0 || t > 0) {
@@ -203,8 +217,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u8 *ring, gcu
                 }
                 // symbols t-4 .. t-1 are now in acc, oldest in the low byte
                 if (u == 0 && t >= 4 && t <= count) { *(gu32_unaligned *)op = acc; op += 4; }
-                const u32 rown = (e & 0xffffu) << 4;
-                const u32 hn = img.ld32(rown);
+                const u32 rown = rows + __umul24(s, roww);
                 hdr = live ? hn : hdr;
                 row = live ? rown : row;
             }
@@ -265,13 +278,13 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u8 *ring, gcu
 // ---------------------------------------------------------------------------------------------
 struct FrontShared {
     u32 F[256];        // frequencies of the row being parsed, by byte value
-    u32 ent[264];      // entries of the row being built
+    u16 cum[264];      // cum[0..n+3] of the row being built (cum[n] = total, then 0xFFFF)
     u8  present[256];  // alphabet of the stream (order-1: F0)
     u8  idx_of[256];   // byte -> compact index        (order-1)
     u8  alpha[256];    // compact index -> byte        (order-1)
     // scalars handed from lane 0 to the wave
     i32 status;
-    u32 nnz, hdr, pos, nsym, bits, look, go;
+    u32 empty, pos, nsym, bits, look, go;
     u32 R[4];
     u32 words_pos;
 };
@@ -306,53 +319,60 @@ __device__ u32 get_alphabet(ByteSrc &s, u32 pos, u32 end, u8 *present)
     return p - pos;
 }
 
-// Turn S.F[] (by byte) into S.ent[] for one row.  `link_of(byte)` is the high half of an entry.
-// Lane 0 only.  Mirrors the checks at :538-552 / :985-997.  Returns false on a bad table.
-template <class LINK>
-__device__ bool make_entries(FrontShared &S, const u8 *in_alphabet, u32 total, u32 bits, LINK link_of)
+// Turn S.F[] (by byte) into the cumulative starts S.cum[0..n] of one row over the compact alphabet
+// S.alpha[0..n).  Lane 0 only.  Mirrors normalise_freq_shift (:168-179) and the checks at
+// :538-552 / :985-997.  Returns false on a bad table.
+__device__ bool make_cum(FrontShared &S, u32 n, u32 total, u32 bits)
 {
-    // normalise_freq_shift :168-179
     u32 sh = 0;
     if (total != 0 && total != (1u << bits)) {
         u32 size = total;
         while (size < (1u << bits)) { size *= 2; sh++; }
     }
-    u32 x = 0, nnz = 0;
-    for (u32 j = 0; j < 256; j++) {
-        if (!in_alphabet[j]) continue;
-        const u32 f = S.F[j] << sh;
+    u32 x = 0;
+    for (u32 ci = 0; ci < n; ci++) {
+        S.cum[ci] = (u16)x;
+        const u32 f = S.F[S.alpha[ci]] << sh;
         if (!f) continue;
         if (f > (1u << bits) - x) return false;
-        S.ent[nnz++] = (x << 16) | link_of(j);
         x += f;
     }
     if (x != (1u << bits)) return false;
-    S.ent[nnz] = (1u << bits) << 16;
-    S.ent[nnz + 1] = S.ent[nnz + 2] = S.ent[nnz + 3] = 0xffff0000u;
-    S.nnz = nnz;
+    S.cum[n] = (u16)x;                                   // 1 << bits <= 32768
+    S.cum[n + 1] = S.cum[n + 2] = S.cum[n + 3] = 0xffffu;
     return true;
 }
 
-// Whole wave: write one row (header, coarse map, entries) from S.ent / S.nnz / S.hdr.
-__device__ void write_row(u8 *rowp, const FrontShared &S, u32 look, u32 lane)
+// Whole wave: write one row of the search tree (r4x16_common.h) from S.cum.  An empty row
+// (context without a table) gets cum[0] = 0 and sentinels: any lookup lands on symbol 0 and the
+// stream is failed through the ROW_EMPTY flag of that context.
+__device__ void write_row(u8 *rowp, const FrontShared &S, u32 n, bool empty, u32 lane)
 {
-    const u32 cells = 1u << (look - 2);
-    const u32 nnz = S.nnz;
-    u8 *coarse = rowp + 4;
-    u32 *ent = (u32 *)(rowp + 4 + cells);
-    if (lane == 0) *(u32 *)rowp = S.hdr | (nnz << 16);
-    if (nnz == 0) {
-        for (u32 c = lane; c < cells; c += WAVE) coarse[c] = 0;
-        if (lane < 5) ent[lane] = lane == 0 ? 0u : 0xffff0000u;   // in-bounds filler, row is flagged EMPTY
-        return;
+    const u32 lv = img_levels(n);
+    auto C = [&](u32 r) -> u16 {
+        if (empty) return r == 0 ? (u16)0 : (u16)0xffffu;
+        return r <= n + 3 ? S.cum[r] : (u16)0xffffu;
+    };
+    u16 *w = (u16 *)rowp;
+    if (lv == 3) {
+        // 4 root separators, 5 x 4 node separators
+        for (u32 t = lane; t < 24; t += WAVE) {
+            u16 v;
+            if (t < 4) v = C(10 * (t + 1));
+            else { const u32 b = (t - 4) >> 2, i = (t - 4) & 3; v = C(10 * b + 2 * (i + 1)); }
+            w[t] = v;
+        }
+        for (u32 t = lane; t < n + 4; t += WAVE) w[24 + t] = C(t);
+    } else {
+        for (u32 t = lane; t < 152; t += WAVE) {
+            u16 v;
+            if (t < 8) v = C(50 * (t + 1));
+            else if (t < 32) { const u32 a = (t - 8) >> 2, i = (t - 8) & 3; v = C(50 * a + 10 * (i + 1)); }
+            else { const u32 ab = (t - 32) >> 2, i = (t - 32) & 3; v = C(50 * (ab / 5) + 10 * (ab % 5) + 2 * (i + 1)); }
+            w[t] = v;
+        }
+        for (u32 t = lane; t < n + 4; t += WAVE) w[152 + t] = C(t);
     }
-    for (u32 r = lane; r < nnz; r += WAVE) {
-        const u32 lo = S.ent[r] >> 16, hi = S.ent[r + 1] >> 16;
-        u32 c0 = (lo + 3) >> 2, c1 = (hi + 3) >> 2;
-        if (c1 > cells) c1 = cells;
-        for (u32 c = c0; c < c1; c++) coarse[c] = (u8)r;
-    }
-    for (u32 r = lane; r < nnz + 4; r += WAVE) ent[r] = S.ent[r];
 }
 
 // Order-0 stream front end: src[pos, pos+len) holds table, states, words.
@@ -364,7 +384,7 @@ __device__ void o0_front(ByteSrc &src, u32 pos, u32 len, u32 out_sz, u8 *img, Fr
     __syncthreads();
     if (lane == 0) {
         S.status = ST_OK;
-        S.hdr = 0;
+        S.nsym = 0;
         if (len < 16) S.status = ST_TRUNCATED;                        // :503
         else if (out_sz >= 0x7fffffffu) S.status = ST_SIZE;           // :506
         else {
@@ -382,9 +402,11 @@ __device__ void o0_front(ByteSrc &src, u32 pos, u32 len, u32 out_sz, u8 *img, Fr
                     S.F[j] = f;
                     total += f;
                 }
+                u32 ns = 0;                                           // compact alphabet = listed symbols
+                for (u32 j = 0; j < 256; j++) if (S.present[j]) S.alpha[ns++] = (u8)j;
+                S.nsym = ns;
                 if (p == pos) S.status = ST_TABLE;                    // fsz == 0 :531
-                else if (!make_entries(S, S.present, total, O0_BITS, [](u32 j) { return j; }))
-                    S.status = ST_TABLE;
+                else if (!make_cum(S, ns, total, O0_BITS)) S.status = ST_TABLE;
                 else if (p + 16 > end) S.status = ST_TRUNCATED;       // :554
                 else {
                     for (u32 k = 0; k < 4; k++, p += 4) {
@@ -399,7 +421,11 @@ __device__ void o0_front(ByteSrc &src, u32 pos, u32 len, u32 out_sz, u8 *img, Fr
         }
     }
     __syncthreads();
-    if (S.status == ST_OK) write_row(img, S, O0_BITS, lane);
+    if (S.status == ST_OK) {
+        const u32 ns = S.nsym;
+        for (u32 j = lane; j < ns; j += WAVE) ((u16 *)img)[j] = S.alpha[j];
+        write_row(img + img_alpha_bytes(ns), S, ns, false, lane);
+    }
     __syncthreads();
 }
 
@@ -543,7 +569,7 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
             I1->words = (u64)(in + S.words_pos);
             I1->words_len = H.meta_pos + H.meta_slen - S.words_pos;
             I1->out = (u64)metabuf; I1->out_sz = H.meta_len; I1->image = (u64)imgm;
-            I1->img_bytes = img_row_bytes(S.nnz, O0_BITS);
+            I1->img_bytes = img_bytes(S.nsym, 1); I1->nsym = S.nsym;
             I1->look = O0_BITS; I1->order = 0;
             for (int k = 0; k < 4; k++) I1->R[k] = S.R[k];
             __threadfence();
@@ -564,7 +590,7 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
                 I0->words = (u64)(in + S.words_pos);
                 I0->words_len = pay_pos + pay_len - S.words_pos;
                 I0->out = D->s1; I0->out_sz = s1_size; I0->image = (u64)img;
-                I0->img_bytes = img_row_bytes(S.nnz, O0_BITS);
+                I0->img_bytes = img_bytes(S.nsym, 1); I0->nsym = S.nsym;
                 I0->look = O0_BITS; I0->order = 0;
                 for (int k = 0; k < 4; k++) I0->R[k] = S.R[k];
                 __threadfence();
@@ -613,8 +639,12 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
         if (S.status != ST_OK) { if (lane == 0) D->status = S.status; return; }
         __threadfence();
         GImg g{to_global((const u8 *)img0)};
-        chain_decode<0>(g, to_global(in + S.words_pos), H.tab_pos + H.csz - S.words_pos, to_global(tbuf), H.usz,
-                        S.R[lane & 3], O0_BITS, lane < 4, lane);
+        if (img_levels(S.nsym) == 3)
+            chain_decode<0, 3>(g, S.nsym, to_global(in + S.words_pos), H.tab_pos + H.csz - S.words_pos, to_global(tbuf),
+                               H.usz, S.R[lane & 3], O0_BITS, lane < 4, lane);
+        else
+            chain_decode<0, 4>(g, S.nsym, to_global(in + S.words_pos), H.tab_pos + H.csz - S.words_pos, to_global(tbuf),
+                               H.usz, S.R[lane & 3], O0_BITS, lane < 4, lane);
         __threadfence();
         __syncthreads();
     }
@@ -642,17 +672,17 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
     if (H.status != ST_OK) { if (lane == 0) D->status = H.status; return; }
 
     const u32 nsym = S.nsym;
-    const u32 stride = img_row_bytes(nsym, look);
+    const u32 stride = img_row_bytes(nsym);
+    u8 *rows0 = img + img_alpha_bytes(nsym);
 
     // rows, in byte order of the compact alphabet (:967-998)
     for (u32 ci = 0; ci < nsym; ci++) {
         if (lane == 0) {
             const u32 ctx = S.alpha[ci];
-            S.hdr = ctx;
-            S.nnz = 0;
+            S.empty = 0;
             S.go = 1;
             if (!S.present[ctx]) {
-                S.hdr |= ROW_EMPTY;                                    // byte 0 outside F0
+                S.empty = 1;                                           // byte 0 outside F0
             } else {
                 // decode_freq_d :327-358
                 u32 p = S.pos, total = 0, zeros = 0;
@@ -675,17 +705,15 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
                 if (!ok || p == S.pos) { H.status = ST_TABLE; S.go = 0; }
                 else {
                     S.pos = p;
-                    if (total == 0) S.hdr |= ROW_EMPTY;                // :977-980
-                    else if (!make_entries(S, S.present, total, bits,
-                                           [&](u32 j) { return (u32)S.idx_of[j] * (stride >> 4); })) {
-                        H.status = ST_TABLE; S.go = 0;
-                    }
+                    if (total == 0) S.empty = 1;                       // :977-980
+                    else if (!make_cum(S, nsym, total, bits)) { H.status = ST_TABLE; S.go = 0; }
                 }
             }
+            ((u16 *)img)[ci] = (u16)(ctx | (S.empty ? ROW_EMPTY : 0u));
         }
         __syncthreads();
         if (!S.go) break;
-        write_row(img + (u64)ci * stride, S, look, lane);
+        write_row(rows0 + (u64)ci * stride, S, nsym, S.empty != 0, lane);
         __syncthreads();
     }
     if (H.status != ST_OK) { if (lane == 0) D->status = H.status; return; }
@@ -708,7 +736,7 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
             I0->words = (u64)(in + p);
             I0->words_len = end - p;
             I0->out = D->s1; I0->out_sz = s1_size; I0->image = (u64)img;
-            I0->img_bytes = nsym * stride;
+            I0->img_bytes = img_bytes(nsym, nsym); I0->nsym = nsym;
             I0->look = look; I0->order = 1;
             __threadfence();
             I0->active = s1_size != 0;
@@ -723,7 +751,7 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
 // (image + word ring) and every other wave exits at once.  LDS_IMG=false is the catch-all for
 // images too big for LDS (lo = largest class).
 // ---------------------------------------------------------------------------------------------
-template <bool LDS_IMG>
+template <bool LDS_IMG, int LV>
 __global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDesc *desc, int nitems,
                                                     int qpw, u32 lds_per_item, u32 cls_lo, u32 cls_hi)
 {
@@ -734,9 +762,10 @@ __global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDes
     const bool mine = quad < (u32)qpw && it < nitems;
     const DecItem *I = &items[mine ? it : 0];
     bool active = mine && I->active;
+    const u32 nsym = active ? I->nsym : 1u;
     const u32 img_bytes = active ? I->img_bytes : 0u;
     const u32 need = img_bytes + RING_BYTES;
-    active = active && need > cls_lo && need <= cls_hi;
+    active = active && need > cls_lo && need <= cls_hi && img_levels(nsym) == (u32)LV;
     if (!wave_any(active)) return;
 
     // fields are read one by one (a register copy of the struct indexed by lane would spill)
@@ -756,18 +785,18 @@ __global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDes
             if (!src) continue;
             gcu32x4 *s = (gcu32x4 *)src;
             u32x4 *dd = (u32x4 *)(lds + (u64)qd * lds_per_item);
-            for (u32 j = lane; j < (nb >> 4); j += WAVE) dd[j] = s[j];
+            for (u32 j = lane; j < ((nb + 15) >> 4); j += WAVE) dd[j] = s[j];
         }
         __syncthreads();
         const u8 *im = lds + (u64)quad * lds_per_item;
         u8 *ring = lds + (u64)quad * lds_per_item + (lds_per_item - RING_BYTES);
         // order-0 and order-1 streams may share a wave: run the two loops back to back
-        bad = chain_decode_lds<1>(im, ring, words, words_len, out, out_sz, x0, look, active && order == 1, lane);
-        bad |= chain_decode_lds<0>(im, ring, words, words_len, out, out_sz, x0, look, active && order == 0, lane);
+        bad = chain_decode_lds<1, LV>(im, nsym, ring, words, words_len, out, out_sz, x0, look, active && order == 1, lane);
+        bad |= chain_decode_lds<0, LV>(im, nsym, ring, words, words_len, out, out_sz, x0, look, active && order == 0, lane);
     } else {
         GImg im{(gcu8 *)I->image};
-        bad = chain_decode<1>(im, words, words_len, out, out_sz, x0, look, active && order == 1, lane);
-        bad |= chain_decode<0>(im, words, words_len, out, out_sz, x0, look, active && order == 0, lane);
+        bad = chain_decode<1, LV>(im, nsym, words, words_len, out, out_sz, x0, look, active && order == 1, lane);
+        bad |= chain_decode<0, LV>(im, nsym, words, words_len, out, out_sz, x0, look, active && order == 0, lane);
     }
     if (active && bad) desc[I->blk].status = ST_CONTEXT;
 }
@@ -953,27 +982,37 @@ extern "C" void r4x16_launch_dec_front(const BatchArgs *a, const DecWs *ws, int 
 {
     hipLaunchKernelGGL(k_dec_front, dim3(nblk), dim3(WAVE), 0, s, *a, *ws, base);
 }
-// LDS size classes: {bytes per stream, streams per wave}.  Streams per CU = floor(160 KB / (qpw*bytes)) * qpw.
-static const struct { u32 bytes; int qpw; } DEC_CLASSES[] = {
-    {2560, 16}, {5120, 8}, {10240, 4}, {16384, 1}, {22528, 1}, {40960, 1}, {81920, 1}, {163840, 1},
+// LDS size classes: {bytes per stream (image + word ring), streams per wave, tree depth}.
+// Streams per CU = floor(160 KB / (qpw * bytes)) * qpw.  3-level images are at most 8.3 KB, 4-level
+// images at least 21 KB (or the lone 1.3 KB row of a large order-0 alphabet), so the two groups of
+// classes are walked separately.
+static const struct { u32 bytes; int qpw; int lv; } DEC_CLASSES[] = {
+    {1024, 16, 3}, {2560, 16, 3}, {5120, 8, 3}, {7680, 4, 3}, {8448, 4, 3},
+    {22528, 1, 4}, {32768, 1, 4}, {53248, 1, 4}, {81920, 1, 4}, {163840, 1, 4},
 };
 extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t s)
 {
     static bool once = false;
     if (!once) {
-        (void)hipFuncSetAttribute((const void *)k_dec_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void *)k_dec_chain<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void *)k_dec_chain<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         once = true;
     }
     u32 lo = 0;
     for (const auto &c : DEC_CLASSES) {
         const int grid = (nitems + c.qpw - 1) / c.qpw;
-        hipLaunchKernelGGL(k_dec_chain<true>, dim3(grid), dim3(WAVE), (size_t)c.qpw * c.bytes, s,
-                           ws->items, ws->desc, nitems, c.qpw, c.bytes, lo, c.bytes);
-        lo = c.bytes;
+        if (c.lv == 3)
+            hipLaunchKernelGGL((k_dec_chain<true, 3>), dim3(grid), dim3(WAVE), (size_t)c.qpw * c.bytes, s,
+                               ws->items, ws->desc, nitems, c.qpw, c.bytes, lo, c.bytes);
+        else
+            hipLaunchKernelGGL((k_dec_chain<true, 4>), dim3(grid), dim3(WAVE), (size_t)c.qpw * c.bytes, s,
+                               ws->items, ws->desc, nitems, c.qpw, c.bytes, lo, c.bytes);
+        if (c.bytes == 8448) lo = 0; else lo = c.bytes;       // the 4-level classes start again from 0
     }
+    // images that fit no LDS class: tables stay in global memory (L2)
     const int grid = (nitems + 15) / 16;
-    hipLaunchKernelGGL(k_dec_chain<false>, dim3(grid), dim3(WAVE), 0, s,
-                       ws->items, ws->desc, nitems, 16, 0u, lo, 0xffffffffu);
+    hipLaunchKernelGGL((k_dec_chain<false, 3>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, nitems, 16, 0u, 8448u, 0xffffffffu);
+    hipLaunchKernelGGL((k_dec_chain<false, 4>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, nitems, 16, 0u, 163840u, 0xffffffffu);
 }
 extern "C" void r4x16_launch_dec_back(const BatchArgs *a, const DecWs *ws, int base, int nblk, hipStream_t s)
 {
