@@ -22,6 +22,15 @@ typedef u32 __attribute__((aligned(1))) u32_unaligned;          // dword access 
 template <class T> __device__ __forceinline__ GAS T *to_global(T *p) { return (GAS T *)p; }
 template <class T> __device__ __forceinline__ GAS const T *to_global(const T *p) { return (GAS const T *)p; }
 
+// Ordering point for code that one wave runs on its own inside a larger workgroup: the lanes of a
+// wave execute in lock-step, so all that is needed is that earlier LDS/global accesses have
+// completed and that the compiler does not move accesses across this point.
+__device__ __forceinline__ void wsync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Arguments of a device-resident batch (include/rans4x16_hip.h, *_dev entry points).
 struct BatchArgs {
     const u8  *in;
@@ -138,6 +147,43 @@ __device__ __forceinline__ u32 pow2_ceil(u32 v)      // rANS_static4x16pr.c:105-
     v--;
     v |= v >> 1; v |= v >> 2; v |= v >> 4; v |= v >> 8; v |= v >> 16;
     return v + 1;
+}
+
+// byte-granular copy by NT threads (thread index t), any alignment, 16-byte pieces when possible
+template <u32 NT>
+__device__ __forceinline__ void group_copy(u8 *dst, const u8 *src, u32 n, u32 t)
+{
+    if ((((u64)dst ^ (u64)src) & 15) == 0 && n >= 64) {
+        u32 head = (u32)((16 - ((u64)dst & 15)) & 15);
+        for (u32 i = t; i < head; i += NT) dst[i] = src[i];
+        const u32 body = (n - head) >> 4;
+        const u32x4 *s16 = (const u32x4 *)(src + head);
+        u32x4 *d16 = (u32x4 *)(dst + head);
+        for (u32 i = t; i < body; i += NT) d16[i] = s16[i];
+        const u32 done = head + body * 16;
+        for (u32 i = done + t; i < n; i += NT) dst[i] = src[i];
+    } else if ((((u64)dst ^ (u64)src) & 3) == 0) {
+        u32 head = (u32)((4 - ((u64)dst & 3)) & 3);
+        if (head > n) head = n;
+        for (u32 i = t; i < head; i += NT) dst[i] = src[i];
+        const u32 body = (n - head) >> 2;
+        const u32 *s4 = (const u32 *)(src + head);
+        u32 *d4 = (u32 *)(dst + head);
+        for (u32 i = t; i < body; i += NT) d4[i] = s4[i];
+        const u32 done = head + body * 4;
+        for (u32 i = done + t; i < n; i += NT) dst[i] = src[i];
+    } else {
+        // misaligned pair: aligned dword stores assembled from two unaligned-source dwords
+        u32 head = (u32)((4 - ((u64)dst & 3)) & 3);
+        if (head > n) head = n;
+        for (u32 i = t; i < head; i += NT) dst[i] = src[i];
+        const u32 body = (n - head) >> 2;
+        u32 *d4 = (u32 *)(dst + head);
+        const u8 *sp = src + head;
+        for (u32 i = t; i < body; i += NT) d4[i] = *(const u32_unaligned *)(sp + 4 * (u64)i);
+        const u32 done = head + body * 4;
+        for (u32 i = done + t; i < n; i += NT) dst[i] = src[i];
+    }
 }
 
 // byte-granular copy by one wave, any alignment (header / table / payload assembly)

@@ -371,7 +371,7 @@ struct EncShared {
 __device__ void wave_hist8(const u8 *data, u32 n, u32 *F, u32 lane)
 {
     for (u32 j = lane; j < 256; j += WAVE) F[j] = 0;
-    __syncthreads();
+    wsync();
     u32 head = (u32)((16 - ((u64)data & 15)) & 15);
     if (head > n) head = n;
     if (lane < head) atomicAdd(&F[data[lane]], 1u);
@@ -390,7 +390,7 @@ __device__ void wave_hist8(const u8 *data, u32 n, u32 *F, u32 lane)
     }
     const u32 done = head + body * 16;
     if (done + lane < n) atomicAdd(&F[data[done + lane]], 1u);
-    __syncthreads();
+    wsync();
 }
 
 // put_alphabet, rANS_static4x16pr.c:182-206.  One lane.
@@ -415,11 +415,11 @@ __device__ u32 put_alphabet(u8 *cp, const u8 *present)
 
 // Order-0 stream front end (rANS_static4x16pr.c:405-435): histogram, two normalisations, table
 // bytes to `tab`, encoder row to `imgrow`.  All lanes call.  Sets S.tab_len / S.status.
-__device__ void enc_o0_front(const u8 *data, u32 n, u8 *tab, u8 *image, EncShared &S, u32 lane)
+// enc_o0_tables expects the byte histogram of the data in S.F.
+__device__ void enc_o0_tables(u32 n, u8 *tab, u8 *image, EncShared &S, u32 lane)
 {
     EncEntry *imgrow = (EncEntry *)(image + ENC_IMG_IDX);
     for (u32 j = lane; j < 256; j += WAVE) image[j] = (u8)j;       // order-0: symbols index the row directly
-    wave_hist8(data, n, S.F, lane);
     if (lane == 0) {
         u32 target = pow2_ceil(n);
         if (target > (1u << O0_BITS)) target = 1u << O0_BITS;
@@ -433,7 +433,7 @@ __device__ void enc_o0_front(const u8 *data, u32 n, u8 *tab, u8 *image, EncShare
         S.tab_len = (u32)(cp - tab);
         if (normalise_freq(S.F, 256, (int)target, 1u << O0_BITS) < 0) S.status = ST_TABLE;   // :426
     }
-    __syncthreads();
+    wsync();
     // cumulative starts by a wave scan, 4 symbols per lane
     u32 f[4], sum = 0;
 #pragma unroll
@@ -444,6 +444,80 @@ __device__ void enc_o0_front(const u8 *data, u32 n, u8 *tab, u8 *image, EncShare
         if (f[c]) imgrow[lane * 4 + c] = make_entry(start, f[c], O0_BITS);
         start += f[c];
     }
+    wsync();
+}
+
+__device__ void enc_o0_front(const u8 *data, u32 n, u8 *tab, u8 *image, EncShared &S, u32 lane)
+{
+    wave_hist8(data, n, S.F, lane);
+    enc_o0_tables(n, tab, image, S, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Histograms of a whole block by all FRONT_THREADS threads of the workgroup (LDS counters).
+// hist8: utils.h:80-102.  hist1_4: utils.h:136-202 — every adjacent pair, the first byte seen in
+// context 0 — on compact symbol indices, so that an alphabet of n symbols needs n*n counters.
+// ---------------------------------------------------------------------------------------------
+#define FRONT_THREADS 256u
+
+__device__ void wg_hist8(const u8 *data, u32 n, u32 *F, u32 tid)
+{
+    for (u32 j = tid; j < 256; j += FRONT_THREADS) F[j] = 0;
+    __syncthreads();
+    u32 head = (u32)((16 - ((u64)data & 15)) & 15);
+    if (head > n) head = n;
+    if (tid < head) atomicAdd(&F[data[tid]], 1u);
+    const u32 body = (n - head) >> 4;
+    const uint4 *v = (const uint4 *)(data + head);
+    for (u32 i = tid; i < body; i += FRONT_THREADS) {
+        const uint4 w = v[i];
+        const u32 ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            atomicAdd(&F[ww[c] & 0xff], 1u);
+            atomicAdd(&F[(ww[c] >> 8) & 0xff], 1u);
+            atomicAdd(&F[(ww[c] >> 16) & 0xff], 1u);
+            atomicAdd(&F[ww[c] >> 24], 1u);
+        }
+    }
+    const u32 done = head + body * 16;
+    if (done + tid < n) atomicAdd(&F[data[done + tid]], 1u);
+    __syncthreads();
+}
+
+// FP points at ns*ns zeroed counters (LDS when IN_LDS, else global).
+template <class FP>
+__device__ void wg_hist1(const u8 *data, u32 n, FP Fp, u32 ns, const u8 *idx_of, u32 tid)
+{
+    const u32 pieces = (n + 15) >> 4;
+    for (u32 pi = tid; pi < pieces; pi += FRONT_THREADS) {
+        const u32 off = pi * 16;
+        const u32 cnt = (n - off < 16) ? n - off : 16;
+        u32 ci[16];                                  // compact indices of this thread's bytes
+        if (cnt == 16 && ((u64)(data + off) & 3) == 0) {
+            const u32 *w = (const u32 *)(data + off);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const u32 ww = w[c];
+                ci[4 * c] = idx_of[ww & 0xff]; ci[4 * c + 1] = idx_of[(ww >> 8) & 0xff];
+                ci[4 * c + 2] = idx_of[(ww >> 16) & 0xff]; ci[4 * c + 3] = idx_of[ww >> 24];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 16; c++) ci[c] = (c < (int)cnt) ? idx_of[data[off + c]] : 0u;
+        }
+        u32 prev = off ? idx_of[data[off - 1]] : 0u;     // the first byte of the block is seen in context 0
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            if (c < (int)cnt) {
+                atomicAdd(&Fp[prev * ns + ci[c]], 1u);
+                prev = ci[c];
+            }
+        }
+    }
+    __syncthreads();
+    // the three quarter starts are coded in context 0 (rANS_static4x16pr.c:720-723)
+    if (tid >= 1 && tid < 4) atomicAdd(&Fp[idx_of[data[tid * (n >> 2)]]], 1u);
     __syncthreads();
 }
 
@@ -464,11 +538,11 @@ __device__ void wave_pack(const u8 *data, u32 n, u8 *meta, u8 *out, EncShared &S
         S.pk_n = ns;
         S.pk_meta_len = ns > 16 ? 1 : ns + 1;
     }
-    __syncthreads();
+    wsync();
     const u32 ns = S.pk_n;
     if (ns > 16) { if (lane == 0) S.pk_len = n; return; }     // copy case: caller keeps `data`
     const u32 per = ns > 4 ? 2 : ns > 2 ? 4 : ns > 1 ? 8 : 0;
-    if (per == 0) { if (lane == 0) S.pk_len = 0; __syncthreads(); return; }
+    if (per == 0) { if (lane == 0) S.pk_len = 0; wsync(); return; }
     const u32 width = 8 / per;
     const u32 nout = (n + per - 1) / per;
     for (u32 ob = lane; ob < nout; ob += WAVE) {
@@ -479,7 +553,7 @@ __device__ void wave_pack(const u8 *data, u32 n, u8 *meta, u8 *out, EncShared &S
     }
     if (lane == 0) S.pk_len = nout;
     __threadfence();
-    __syncthreads();
+    wsync();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -495,7 +569,7 @@ __device__ void wave_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end
 {
     u32 *rep = S.T;                                      // repeats per symbol
     for (u32 j = lane; j < 256; j += WAVE) rep[j] = 0;
-    __syncthreads();
+    wsync();
     {
         u32 carry = 256;                                 // byte before this trip (none at the start)
         for (u32 base = 0; base < n; base += WAVE) {
@@ -507,7 +581,7 @@ __device__ void wave_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end
             if (i < n && cur == prev) atomicAdd(&rep[cur], 1u);
         }
     }
-    __syncthreads();
+    wsync();
     if (lane == 0) {
         u32 ns = 0;
         for (u32 j = 0; j < 256; j++) {
@@ -517,7 +591,7 @@ __device__ void wave_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end
         }
         S.rl_nsyms = ns;
     }
-    __syncthreads();
+    wsync();
 
     u32 next_lit = n, nl = 0, nrb = 0;
     for (u32 top = n; top > 0; ) {
@@ -550,7 +624,7 @@ __device__ void wave_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end
     }
     if (lane == 0) { S.rl_lits = nl; S.rl_runs = nrb; }
     __threadfence();
-    __syncthreads();
+    wsync();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -562,13 +636,18 @@ __device__ __forceinline__ double approx_log(double a)            // fast_log :6
     return (double)(bits - 4606921278410026770LL) * 1.539095918623324e-16;
 }
 
-__global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int base)
+__global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs ws, int base)
 {
     extern __shared__ __attribute__((aligned(16))) u8 dyn[];
     __shared__ EncShared S;
-    __shared__ struct { i32 status; u32 go, order, dlen, nested_len, flags, hl; double e10, e12; int max_tot; } H;
+    __shared__ struct { i32 status; u32 go, order, dlen, nested_len, flags, hl, run; u64 data; double e10, e12; int max_tot; } H;
 
-    const u32 lane = threadIdx.x;
+    // Wave 0 runs the whole front end; waves 1..3 join only for the two histogram passes over the
+    // block (the bulk of the memory traffic).  Inside wave-0-only code the ordering points are
+    // wsync(); __syncthreads() appears only where all four waves meet.
+    const u32 tid = threadIdx.x;
+    const u32 lane = tid & (WAVE - 1);
+    const bool w0 = tid < WAVE;
     const u32 b = blockIdx.x;
     const int i = base + (int)b;
     EncDesc *D = &ws.desc[b];
@@ -583,8 +662,10 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
     u8 *scratch = ws.scratch + (u64)b * ws.scratch_stride;
     u8 *scratch_end = scratch + ws.scratch_stride;
 
+    if (w0) do {
     // ---- container header (:1144-1237) ---------------------------------------------------------
     if (lane == 0) {
+        H.run = 0;
         I0->active = 0; I1->active = 0; I0->pay_len = 0; I1->pay_len = 0;
         I0->blk = b; I1->blk = b;
         D->cat = 0; D->rle_on = 0; D->tab_len = 0; D->hdr_len = 0; D->dlen = 0; D->tab = (u64)tab;
@@ -613,8 +694,8 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
         D->status = st;
         H.status = st; H.go = go;
     }
-    __syncthreads();
-    if (H.status != ST_OK || !H.go) return;
+    wsync();
+    if (H.status != ST_OK || !H.go) break;
 
     const u8 *data = in;
     u32 n = in_size;
@@ -627,14 +708,14 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
             u8 *pbuf = ws.packed + (u64)b * ws.xf_stride;
             wave_hist8(data, n, S.F, lane);
             wave_pack(data, n, D->hdr + hl, pbuf, S, lane);
-            __syncthreads();
+            wsync();
             if (S.pk_meta_len == 1 && S.pk_n != 256) flags &= ~(u32)X_PACK;    // > 16 symbols (:1249); 256 wraps to 0 and stays
             else {
                 if (S.pk_n <= 16) data = pbuf;
                 n = S.pk_len;
                 hl += S.pk_meta_len;
                 if (lane == 0) H.hl = hl + var_put(D->hdr + hl, n);
-                __syncthreads();
+                wsync();
                 hl = H.hl;
             }
         }
@@ -647,7 +728,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
             u8 *lits_end = ws.lits + (u64)b * ws.xf_stride + ws.xf_stride;
             u8 *meta_end = ws.meta + (u64)b * (ws.xf_stride + 768) + (ws.xf_stride + 768);
             __threadfence();
-            __syncthreads();
+            wsync();
             wave_hist8(data, n, S.F, lane);
             wave_rle_split(data, n, lits_end, meta_end, S, lane);
             const u32 nsy = S.rl_nsyms, nlits = S.rl_lits, nruns = S.rl_runs;
@@ -659,7 +740,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
                 if (lane == 0) m[0] = (u8)nsy;
                 for (u32 j = lane; j < nsy; j += WAVE) m[1 + j] = S.alpha[j];
                 __threadfence();
-                __syncthreads();
+                wsync();
                 // the meta is coded as an order-0 stream by the chain kernel (item I1)
                 u8 *mtab = ws.metatab + (u64)b * META_TAB_BYTES;
                 u8 *imgm = img + ENC_IMG_META;
@@ -674,8 +755,8 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
                     __threadfence();
                     I1->active = S.status == ST_OK;
                 }
-                __syncthreads();
-                if (S.status != ST_OK) return;
+                wsync();
+                if (S.status != ST_OK) break;
                 data = lits_end - nlits;
                 n = nlits;
             }
@@ -688,14 +769,23 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
         if (lane == 0) {
             D->flags = flags; D->hdr[0] = (u8)flags; D->hdr_len = hl;
             D->data = (u64)data; D->dlen = n;
-            H.order = o;
+            H.order = o; H.data = (u64)data; H.dlen = n;
+            H.run = n != 0;
         }
-        __syncthreads();
     }
-    if (n == 0) return;
+    } while (0);
+    __syncthreads();                                                      // all four waves meet here
+    if (!H.run) return;
+
+    const u8 *data = (const u8 *)H.data;
+    const u32 n = H.dlen;
+
+    // pass 1 over the block: byte histogram (hist8 / present8, utils.h:80-131), all waves
+    wg_hist8(data, n, S.F, tid);
 
     if (H.order == 0) {
-        enc_o0_front(data, n, tab, img, S, lane);
+        if (!w0) return;
+        enc_o0_tables(n, tab, img, S, lane);
         if (lane == 0) {
             D->status = S.status;
             D->tab_len = S.tab_len;
@@ -709,9 +799,8 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
     }
 
     // ---- order-1 (:694-780) ---------------------------------------------------------------------
-    // pass 1: which bytes occur (present8, utils.h:108-131) -> compact alphabet F0 (0 forced in :731)
-    wave_hist8(data, n, S.F, lane);
-    if (lane == 0) {
+    // compact alphabet F0 from the byte histogram (0 forced in, :731)
+    if (tid == 0) {
         u32 ns = 0;
         for (u32 j = 0; j < 256; j++) {
             S.present[j] = (S.F[j] != 0) || j == 0;
@@ -721,65 +810,29 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
     }
     __syncthreads();
     const u32 ns = S.nsym;
-    u32 *Fp = (ns <= FRONT_LDS_NSYM) ? (u32 *)dyn : ws.F + (u64)b * 65536u;
-    for (u32 j = lane; j < ns * ns; j += WAVE) Fp[j] = 0;
+    const bool f_in_lds = ns <= FRONT_LDS_NSYM;
+    u32 *Fg = ws.F + (u64)b * 65536u;
+    if (f_in_lds) { for (u32 j = tid; j < ns * ns; j += FRONT_THREADS) ((u32 *)dyn)[j] = 0; }
+    else          { for (u32 j = tid; j < ns * ns; j += FRONT_THREADS) Fg[j] = 0; }
     __syncthreads();
+    // pass 2 over the block: order-1 pair histogram, all waves
+    if (f_in_lds) wg_hist1(data, n, (u32 *)dyn, ns, S.idx_of, tid);
+    else          wg_hist1(data, n, Fg, ns, S.idx_of, tid);
+    if (!w0) return;
 
-    // pass 2: hist1_4 (utils.h:136-202): every adjacent pair, the first byte in context 0
-    {
-        const u32 pieces = (n + 15) >> 4;
-        u32 carry = 0;                                   // compact index of the byte before this piece row
-        for (u32 pb = 0; pb < pieces; pb += WAVE) {
-            const u32 pi = pb + lane;
-            const u32 off = pi * 16;
-            u32 cnt = 0;
-            if (pi < pieces) cnt = (n - off < 16) ? n - off : 16;
-            u32 ci[16];                                  // compact indices of this lane's bytes
-            u32 last = 0;
-            if (cnt == 16 && ((u64)(data + off) & 3) == 0) {
-                const u32 *w = (const u32 *)(data + off);
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const u32 ww = w[c];
-                    ci[4 * c] = S.idx_of[ww & 0xff]; ci[4 * c + 1] = S.idx_of[(ww >> 8) & 0xff];
-                    ci[4 * c + 2] = S.idx_of[(ww >> 16) & 0xff]; ci[4 * c + 3] = S.idx_of[ww >> 24];
-                }
-                last = ci[15];
-            } else {
-#pragma unroll
-                for (int c = 0; c < 16; c++) {
-                    ci[c] = 0;
-                    if (c < (int)cnt) { ci[c] = S.idx_of[data[off + c]]; last = ci[c]; }
-                }
-            }
-            u32 prev = __shfl_up(last, 1);
-            const u32 wrap = __shfl(last, WAVE - 1);     // lane 63 always holds a full piece unless at the end
-            if (lane == 0) prev = carry;
-            carry = wrap;
-#pragma unroll
-            for (int c = 0; c < 16; c++) {
-                if (c < (int)cnt) {
-                    atomicAdd(&Fp[prev * ns + ci[c]], 1u);
-                    prev = ci[c];
-                }
-            }
-        }
-        __syncthreads();
-        // the three quarter starts are coded in context 0 (:720-723)
-        if (lane >= 1 && lane < 4) atomicAdd(&Fp[0 * ns + S.idx_of[data[lane * (n >> 2)]]], 1u);
-        __syncthreads();
-        // context totals = row sums
-        for (u32 r = lane; r < ns; r += WAVE) {
-            u32 t = 0;
-            for (u32 j = 0; j < ns; j++) t += Fp[r * ns + j];
-            S.T[r] = t;
-        }
-        __syncthreads();
+    u32 *Fp = f_in_lds ? (u32 *)dyn : Fg;
+    if (!f_in_lds) __threadfence();
+    // context totals = row sums
+    for (u32 r = lane; r < ns; r += WAVE) {
+        u32 t = 0;
+        for (u32 j = 0; j < ns; j++) t += Fp[r * ns + j];
+        S.T[r] = t;
     }
+    wsync();
 
     // ---- compute_shift (:629-691): row by row; terms in parallel, sums in reference order ------
     if (lane == 0) { H.e10 = 0; H.e12 = 0; H.max_tot = 0; }
-    __syncthreads();
+    wsync();
     for (u32 r = 0; r < ns; r++) {
         const u32 Tr = S.T[r];
         const int target0 = (int)pow2_ceil(Tr);
@@ -804,7 +857,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
                 S.t12[j] = (double)f * (approx_log((double)(x > 1 ? x : 1)) - l12);
             }
         }
-        __syncthreads();
+        wsync();
         if (lane == 0) {
             double e10 = H.e10, e12 = H.e12;
             for (u32 j = 0; j < ns; j++) {
@@ -822,7 +875,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
             S.S[r] = target;
             if (H.max_tot < target) H.max_tot = target;
         }
-        __syncthreads();
+        wsync();
     }
     const u32 bits = (H.e10 / H.e12 < 1.01 || H.max_tot <= 1024) ? 10u : 12u;      // :685
 
@@ -845,7 +898,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
             S.rowlen[r] = len;
         }
     }
-    __syncthreads();
+    wsync();
     if (H.status != ST_OK) { if (lane == 0) D->status = H.status; return; }
 
     // ---- serialise: alphabet, then rows at their prefix offsets -----------------------------------
@@ -854,7 +907,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
         for (u32 r = 0; r < ns; r++) { const u32 l = S.rowlen[r]; S.rowlen[r] = off; off += l; }
         S.tab_len = off;
     }
-    __syncthreads();
+    wsync();
     for (u32 rb = 0; rb < ns; rb += WAVE) {
         const u32 r = rb + lane;
         if (r < ns) {
@@ -889,7 +942,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
         }
     }
     __threadfence();
-    __syncthreads();
+    wsync();
 
     // ---- table into the stream, nested order-0 if it pays (:766-780) ------------------------------
     u32 final_len = 0;
@@ -899,12 +952,12 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
         u8 *ntab = scratch;                                           // nested table bytes, staged low
         enc_o0_front(tabraw, tlen, ntab, img0, S, lane);
         __threadfence();
-        __syncthreads();
+        wsync();
         const u32 npay = chain_encode<0>(to_global((const u8 *)tabraw), tlen, to_global((const u8 *)img0), 256u,
                                          O0_BITS, to_global(scratch_end), lane < 4, lane);
         const u32 np = __shfl(npay, 0);
         __threadfence();
-        __syncthreads();
+        wsync();
         const u32 nlen = S.tab_len + np;
         if (S.status == ST_OK && nlen + 6 < 1 + tlen) {               // :772
             nested = true;
@@ -916,7 +969,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
                 hl += var_put(tab + hl, nlen);
                 H.nested_len = hl;
             }
-            __syncthreads();
+            wsync();
             hl = H.nested_len;
             wave_copy(tab + hl, ntab, S.tab_len, lane);
             wave_copy(tab + hl + S.tab_len, scratch_end - np, np, lane);
@@ -928,7 +981,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_front(BatchArgs a, EncWs ws, int b
         wave_copy(tab + 1, tabraw, tlen, lane);
         final_len = 1 + tlen;
     }
-    __syncthreads();
+    wsync();
     if (lane == 0) {
         D->tab_len = final_len;
         I0->data = (u64)data; I0->n = n; I0->image = (u64)img; I0->bits = bits; I0->order = 1;
@@ -987,7 +1040,8 @@ __global__ __launch_bounds__(WAVE) void k_enc_chain(EncItem *items, int nitems, 
 // ---------------------------------------------------------------------------------------------
 // k_enc_finish
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVE) void k_enc_finish(BatchArgs a, EncWs ws, int base)
+#define FINISH_THREADS 256u
+__global__ __launch_bounds__(FINISH_THREADS) void k_enc_finish(BatchArgs a, EncWs ws, int base)
 {
     __shared__ u8 vbuf[16];
     __shared__ u32 vlen;
@@ -1007,7 +1061,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_finish(BatchArgs a, EncWs ws, int 
     u32 flags = D->hdr[0];
     if (lane >= 1 && lane < D->hdr_len) out[lane] = D->hdr[lane];
     if (D->cat) {
-        wave_copy(out + pos, (const u8 *)D->data, dlen, lane);
+        group_copy<FINISH_THREADS>(out + pos, (const u8 *)D->data, dlen, lane);
         pos += dlen;
     } else {
         if (D->rle_on) {                                              // :1294-1310
@@ -1025,12 +1079,12 @@ __global__ __launch_bounds__(WAVE) void k_enc_finish(BatchArgs a, EncWs ws, int 
             if (lane < vlen) out[pos + lane] = vbuf[lane];
             pos += vlen;
             if (comp) {
-                wave_copy(out + pos, (const u8 *)D->meta_tab, D->meta_tab_len, lane);
+                group_copy<FINISH_THREADS>(out + pos, (const u8 *)D->meta_tab, D->meta_tab_len, lane);
                 pos += D->meta_tab_len;
-                wave_copy(out + pos, (const u8 *)I1->scratch_end - mpay, mpay, lane);
+                group_copy<FINISH_THREADS>(out + pos, (const u8 *)I1->scratch_end - mpay, mpay, lane);
                 pos += mpay;
             } else {
-                wave_copy(out + pos, (const u8 *)D->rle_meta, mlen, lane);
+                group_copy<FINISH_THREADS>(out + pos, (const u8 *)D->rle_meta, mlen, lane);
                 pos += mlen;
             }
         }
@@ -1038,12 +1092,12 @@ __global__ __launch_bounds__(WAVE) void k_enc_finish(BatchArgs a, EncWs ws, int 
         const u32 plen = D->tab_len + pay;
         if (plen >= dlen) {                                           // :1332-1337
             flags = (flags & ~3u) | X_CAT | D->nosz;
-            wave_copy(out + pos, (const u8 *)D->data, dlen, lane);
+            group_copy<FINISH_THREADS>(out + pos, (const u8 *)D->data, dlen, lane);
             pos += dlen;
         } else {
-            wave_copy(out + pos, (const u8 *)D->tab, D->tab_len, lane);
+            group_copy<FINISH_THREADS>(out + pos, (const u8 *)D->tab, D->tab_len, lane);
             pos += D->tab_len;
-            wave_copy(out + pos, (const u8 *)I0->scratch_end - pay, pay, lane);
+            group_copy<FINISH_THREADS>(out + pos, (const u8 *)I0->scratch_end - pay, pay, lane);
             pos += pay;
         }
     }
@@ -1063,7 +1117,7 @@ extern "C" void r4x16_launch_enc_front(const BatchArgs *a, const EncWs *ws, int 
         (void)hipFuncSetAttribute((const void *)k_enc_front, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_DYN_LDS);
         once = true;
     }
-    hipLaunchKernelGGL(k_enc_front, dim3(nblk), dim3(WAVE), FRONT_DYN_LDS, s, *a, *ws, base);
+    hipLaunchKernelGGL(k_enc_front, dim3(nblk), dim3(FRONT_THREADS), FRONT_DYN_LDS, s, *a, *ws, base);
 }
 static const struct { u32 bytes; int qpw; } ENC_CLASSES[] = {
     {2560, 16}, {5120, 8}, {10240, 4}, {18432, 1}, {40960, 1}, {81920, 1}, {163840, 1},
@@ -1087,6 +1141,6 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
 }
 extern "C" void r4x16_launch_enc_finish(const BatchArgs *a, const EncWs *ws, int base, int nblk, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_enc_finish, dim3(nblk), dim3(WAVE), 0, s, *a, *ws, base);
+    hipLaunchKernelGGL(k_enc_finish, dim3(nblk), dim3(FINISH_THREADS), 0, s, *a, *ws, base);
 }
 extern "C" u32 r4x16_compress_bound(u32 size, int order) { return compress_bound(size, order); }

@@ -10,7 +10,7 @@ import bench
 def run(nblk, bs, name, order, reps=2):
     dev = torch.device("cuda", 0)
     dc = H.DeviceCodec(0)
-    host, d_in, in_off, in_size = bench.build_batch(torch, dev, name, nblk, bs, 0)
+    d_in, in_off, in_size = bench.build_batch(torch, dev, name, nblk, bs, 0)
     cap = H.rans_compress_bound_4x16(bs, order); slot = (cap + 255) // 256 * 256
     d_comp = torch.zeros(nblk * slot, dtype=torch.uint8, device=dev)
     comp_off = torch.arange(nblk, dtype=torch.int64, device=dev) * slot
