@@ -115,16 +115,11 @@ def main():
     import torch
     import htscodecs_amd as H
 
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    from htscodecs_amd import shard
+    rank, world, local = shard.env_rank()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    dist = shard.init("nccl", device_id=dev)        # RCCL; used for the barrier and the max only
 
     nblk, bs, order = args.blocks, args.block_size, args.order
     dc = H.DeviceCodec(local)
@@ -186,10 +181,7 @@ def main():
             got = d_comp[b * slot:b * slot + int(csz[b])].cpu().numpy().tobytes()
             assert got == want, f"block {b}: device stream differs from the CPU reference"
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(dist, elapsed, dev)
 
     if rank == 0:
         total_unc = nblk * bs * world

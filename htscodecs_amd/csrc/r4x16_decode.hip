@@ -289,8 +289,10 @@ struct FrontShared {
     u32 words_pos;
 };
 
-// rANS_static4x16pr.c:208-255 (see oracle/rans4x16_oracle.c get_alphabet for the derivation of
-// the single-loop form).  Marks present[]; returns bytes consumed, 0 on failure.
+// rANS_static4x16pr.c:208-255.  The reference has an unchecked fast loop (a do/while, so with three
+// or more bytes left the FIRST symbol is accepted even when it is 0) followed by a checked loop
+// with the same body; this is the checked body with that entry rule.  Marks present[]; returns
+// bytes consumed, 0 on failure.
 __device__ u32 get_alphabet(ByteSrc &s, u32 pos, u32 end, u8 *present)
 {
     if (pos >= end) return 0;
