@@ -26,10 +26,13 @@ struct LImg {
     __device__ __forceinline__ u32x2 ld64(u32 off) const { return *(const u32x2 *)(p + off); }
 };
 
-// number of the four u16 separators in v that are <= m
-__device__ __forceinline__ u32 count_le(u32 m, u32x2 v)
+// number of the four u16 separators in v that are <= m, without compares: separators are stored
+// clamped to 0x7FFF (m < 4096, so the clamp changes no answer), hence in each 16-bit half
+// (m | 0x8000) - sep cannot borrow from its neighbour and keeps bit 15 exactly when sep <= m.
+__device__ __forceinline__ u32 count_le(u32 mmh /* (m | m << 16) | 0x80008000 */, u32x2 v)
 {
-    return (u32)(m >= (v.x & 0xffffu)) + (u32)(m >= (v.x >> 16)) + (u32)(m >= (v.y & 0xffffu)) + (u32)(m >= (v.y >> 16));
+    const u32 vx = v.x, vy = v.y;
+    return __popc((mmh - vx) & 0x80008000u) + __popc((mmh - vy) & 0x80008000u);
 }
 
 // One table lookup + state update (rANS_static4x16pr.c:576-579 / :1033-1035) on the search tree
@@ -39,15 +42,16 @@ template <int LV, class IMG>
 __device__ __forceinline__ u32 lookup_step(const IMG &img, u32 row, u32 look, u32 mask, u32 &x)
 {
     const u32 m = x & mask;
+    const u32 mm = m | (m << 16) | 0x80008000u;
     u32 e;
     if (LV == 4) {
-        const u32 a = count_le(m, img.ld64(row)) + count_le(m, img.ld64(row + 8));
-        const u32 b = count_le(m, img.ld64(row + 16 + 8 * a));
-        const u32 dd = count_le(m, img.ld64(row + 64 + 8 * (5 * a + b)));
+        const u32 a = count_le(mm, img.ld64(row)) + count_le(mm, img.ld64(row + 8));
+        const u32 b = count_le(mm, img.ld64(row + 16 + 8 * a));
+        const u32 dd = count_le(mm, img.ld64(row + 64 + 8 * (5 * a + b)));
         e = 50 * a + 10 * b + 2 * dd;
     } else {
-        const u32 b = count_le(m, img.ld64(row));
-        const u32 dd = count_le(m, img.ld64(row + 8 + 8 * b));
+        const u32 b = count_le(mm, img.ld64(row));
+        const u32 dd = count_le(mm, img.ld64(row + 8 + 8 * b));
         e = 10 * b + 2 * dd;
     }
     const u32 lo = row + (LV == 4 ? 304u : 48u) + 2 * e;
@@ -151,7 +155,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     const u32 rows = img_alpha_bytes(nsym), roww = img_row_bytes(nsym);
     const u32 nwords = words_len >> 1;
     const u32 below = (1u << k) - 1u;                      // quad lanes below this one
-    const u32 qshift = lane & ~3u;
+    const u32 mybit = 1u << k;
     u32 count;
     gu8 *op;                                               // next output byte of this chain
     if (ORDER == 0) {
@@ -186,7 +190,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     u32 row = rows, cursor = 0, bad = 0, t = 0;
     u32 acc = 0;                                          // order-1: the last (up to) 4 decoded bytes
     u32 hdr = 0;                                          // order-1: alpha[] word of the symbol decoded last step
-    if (ORDER == 1 && count) bad = img.ld16(0) & ROW_EMPTY;
+    if (ORDER == 1 && count) bad = img.ld16(0);
 
     // Four steps per trip: one loop test, one dword store and one ring check per trip.
     while (wave_any(t < count)) {
@@ -199,8 +203,8 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             const u32 ra = cb & 124u;
             // (volatile: keeps the compiler from sinking these reads into the refill branch, which
             //  would put their latency back on the dependent path)
-            const u32 d0 = *(const volatile u32 *)(ring + ra), d1 = *(const volatile u32 *)(ring + ra + 4),
-                      d2 = *(const volatile u32 *)(ring + ra + 8);
+            lvcu32 *rp = (lvcu32 *)(ring + ra);       // explicit LDS pointer: a volatile generic access would go FLAT
+            const u32 d0 = rp[0], d1 = rp[1], d2 = rp[2];
             const u32 sh = (cb & 3u) * 8u;
 
             u32 xn = x;
@@ -212,7 +216,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             } else {
                 // the byte of the symbol decoded one step ago and the flags of the row in use now
                 if (u > 0 || t > 0) {
-                    if (live) bad |= hdr & ROW_EMPTY;
+                    bad |= live ? hdr : 0u;               // ROW_EMPTY bit is tested after the loop
                     acc = (t + u <= count) ? __builtin_amdgcn_alignbit(hdr, acc, 8) : acc;
                 }
                 // symbols t-4 .. t-1 are now in acc, oldest in the low byte
@@ -227,14 +231,14 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             // renormalise: chains refill in order 0..3 from the shared cursor.  After the first
             // refusal (stream exhausted) no later request can succeed either, so the cursor may
             // simply advance by the number of requests (rANS_word.h:402-410).
-            const u64 wb = __ballot(want);
-            const u32 wm = (u32)(wb >> qshift) & 0xfu;
+            const u32 wm = quad_mask_dpp(want, mybit);
             const u32 pre = __popc(wm & below);
             const bool take = want && cursor + pre < nwords;
             const u32 wlo = __builtin_amdgcn_alignbit(d1, d0, sh), whi = __builtin_amdgcn_alignbit(d2, d1, sh);
             const u32 w2 = (pre & 2u) ? whi : wlo;
             const u32 w = (w2 >> ((pre & 1u) * 16u)) & 0xffffu;
-            x = take ? ((x << 16) | w) : x;
+            const u32 xr = (x << 16) | w;
+            x = __builtin_unpredictable(take) ? xr : x;
             cursor += __popc(wm);
 
             if (ORDER == 0) {
@@ -270,7 +274,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
         const u32 rem = count - stored;                    // 0..4, in the top `rem` bytes of acc
         for (u32 j = 0; j < rem; j++) op[j] = (u8)(acc >> (8 * (4 - rem + j)));
     }
-    return bad;
+    return bad & ROW_EMPTY;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -341,7 +345,7 @@ __device__ bool make_cum(FrontShared &S, u32 n, u32 total, u32 bits)
     }
     if (x != (1u << bits)) return false;
     S.cum[n] = (u16)x;                                   // 1 << bits <= 32768
-    S.cum[n + 1] = S.cum[n + 2] = S.cum[n + 3] = 0xffffu;
+    S.cum[n + 1] = S.cum[n + 2] = S.cum[n + 3] = 0x7fffu;
     return true;
 }
 
@@ -352,25 +356,26 @@ __device__ void write_row(u8 *rowp, const FrontShared &S, u32 n, bool empty, u32
 {
     const u32 lv = img_levels(n);
     auto C = [&](u32 r) -> u16 {
-        if (empty) return r == 0 ? (u16)0 : (u16)0xffffu;
-        return r <= n + 3 ? S.cum[r] : (u16)0xffffu;
+        if (empty) return r == 0 ? (u16)0 : (u16)0x7fffu;
+        return r <= n + 3 ? S.cum[r] : (u16)0x7fffu;
     };
+    auto N = [&](u32 r) -> u16 { const u16 v = C(r); return v > 0x7fffu ? (u16)0x7fffu : v; };   // node separator
     u16 *w = (u16 *)rowp;
     if (lv == 3) {
         // 4 root separators, 5 x 4 node separators
         for (u32 t = lane; t < 24; t += WAVE) {
             u16 v;
-            if (t < 4) v = C(10 * (t + 1));
-            else { const u32 b = (t - 4) >> 2, i = (t - 4) & 3; v = C(10 * b + 2 * (i + 1)); }
+            if (t < 4) v = N(10 * (t + 1));
+            else { const u32 b = (t - 4) >> 2, i = (t - 4) & 3; v = N(10 * b + 2 * (i + 1)); }
             w[t] = v;
         }
         for (u32 t = lane; t < n + 4; t += WAVE) w[24 + t] = C(t);
     } else {
         for (u32 t = lane; t < 152; t += WAVE) {
             u16 v;
-            if (t < 8) v = C(50 * (t + 1));
-            else if (t < 32) { const u32 a = (t - 8) >> 2, i = (t - 8) & 3; v = C(50 * a + 10 * (i + 1)); }
-            else { const u32 ab = (t - 32) >> 2, i = (t - 32) & 3; v = C(50 * (ab / 5) + 10 * (ab % 5) + 2 * (i + 1)); }
+            if (t < 8) v = N(50 * (t + 1));
+            else if (t < 32) { const u32 a = (t - 8) >> 2, i = (t - 8) & 3; v = N(50 * a + 10 * (i + 1)); }
+            else { const u32 ab = (t - 32) >> 2, i = (t - 32) & 3; v = N(50 * (ab / 5) + 10 * (ab % 5) + 2 * (i + 1)); }
             w[t] = v;
         }
         for (u32 t = lane; t < n + 4; t += WAVE) w[152 + t] = C(t);

@@ -18,7 +18,9 @@ typedef GAS const u32 gcu32;
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 typedef GAS const u32x4 gcu32x4;
-typedef u32 __attribute__((aligned(1))) u32_unaligned;          // dword access at any byte address
+typedef u32 __attribute__((aligned(1))) u32_unaligned;
+#define LAS __attribute__((address_space(3)))                   // LDS
+typedef LAS const volatile u32 lvcu32;          // dword access at any byte address
 template <class T> __device__ __forceinline__ GAS T *to_global(T *p) { return (GAS T *)p; }
 template <class T> __device__ __forceinline__ GAS const T *to_global(const T *p) { return (GAS const T *)p; }
 
@@ -114,6 +116,18 @@ __device__ __forceinline__ u32 quad_bcast0(u32 v) { return dpp_mov<QP(0, 0, 0, 0
 __device__ __forceinline__ u32 quad_bcast1(u32 v) { return dpp_mov<QP(1, 1, 1, 1)>(v); }
 __device__ __forceinline__ u32 quad_bcast2(u32 v) { return dpp_mov<QP(2, 2, 2, 2)>(v); }
 __device__ __forceinline__ u32 quad_bcast3(u32 v) { return dpp_mov<QP(3, 3, 3, 3)>(v); }
+
+// 4-bit mask of a predicate over this lane's quad without leaving the vector unit: each lane
+// contributes its own bit (bit = 1 << (lane & 3)) and two DPP quad_perm ORs spread them.
+__device__ __forceinline__ u32 quad_mask_dpp(bool p, u32 mybit)
+{
+    u32 v = p ? mybit : 0u;
+    v |= dpp_mov<QP(1, 0, 3, 2)>(v);
+    v |= dpp_mov<QP(2, 3, 0, 1)>(v);
+    return v;
+}
+
+typedef u16 u16x2 __attribute__((ext_vector_type(2)));
 
 // For a per-lane predicate: 4-bit mask of the predicate over this lane's quad.
 __device__ __forceinline__ u32 quad_ballot(bool p, u32 lane)
