@@ -36,6 +36,7 @@ struct rans4x16_hip_ctx {
     u8 *ws = nullptr;
     size_t ws_bytes = 0;
     double *logtab = nullptr;
+    u32 *rcptab = nullptr;
     // staging for the host-buffer entry points
     u8 *stage = nullptr;
     size_t stage_bytes = 0;
@@ -81,6 +82,19 @@ extern "C" rans4x16_hip_ctx *rans4x16_hip_create(int device)
         delete c;
         return nullptr;
     }
+    // reciprocal of every frequency 1..4096 (rANS_word.h:220-259); index 0 is never used
+    std::vector<u32> rcp(RCPTAB_ENTRIES, 0u);
+    rcp[1] = ~0u;
+    for (u32 f = 2; f < RCPTAB_ENTRIES; f++) {
+        u32 shift = 0;
+        while (f > (1u << shift)) shift++;
+        rcp[f] = (u32)(((1ull << (shift + 31)) + f - 1) / f);
+    }
+    if (hipMalloc((void **)&c->rcptab, RCPTAB_ENTRIES * 4) != hipSuccess ||
+        hipMemcpy(c->rcptab, rcp.data(), RCPTAB_ENTRIES * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        rans4x16_hip_destroy(c);
+        return nullptr;
+    }
     return c;
 }
 
@@ -93,6 +107,7 @@ extern "C" void rans4x16_hip_destroy(rans4x16_hip_ctx *c)
     if (c->ws) (void)hipFree(c->ws);
     if (c->stage) (void)hipFree(c->stage);
     if (c->logtab) (void)hipFree(c->logtab);
+    if (c->rcptab) (void)hipFree(c->rcptab);
     delete c;
 }
 
@@ -212,6 +227,7 @@ extern "C" int rans4x16_hip_compress_dev(rans4x16_hip_ctx *c, int n,
     if (ensure_ws(c, need) != 0) return -1;
     enc_ws_layout(c->ws, chunk, scratch_stride, xf_stride, scratch2_stride, &w);
     w.logtab = c->logtab;
+    w.rcptab = c->rcptab;
 
     BatchArgs a;
     a.in = d_in; a.in_off = d_in_off; a.in_size = d_in_size;

@@ -112,21 +112,22 @@ struct DecDesc {
 // ---------------------------------------------------------------------------------------------
 // Encode image (per item), compact:
 //   [0,256)            u8 idx_of[256] : byte value -> compact symbol index (order-0: identity)
-//   [256, 256+8*R*ns)  EncEntry ent[R][ns] : entry of (context row r, symbol index s) at r*ns + s;
+//   [256, 256+4*R*ns)  u32 ent[R][ns] : entry of (context row r, symbol index s) at r*ns + s;
 //                      order-1: R = ns = size of the alphabet (byte 0 included, index 0);
 //                      order-0: R = 1, ns = 256.
-//   EncEntry = { u32 rcp; u32 pk } : reciprocal (rANS_word.h:252, or ~0 for freq 1) and
-//              bias[0:13) | cmpl_freq[13:26) | rcp_shift[26:31)      (rANS_word.h:190-266);
-//              x_max is (M - cmpl_freq) << (31 - bits).
-// An order-1 image for a 46-symbol alphabet is 17 KB, so nine streams' tables fit one CU's LDS.
+//   entry = bias[0:13) | cmpl_freq[13:26) | rcp_shift[26:31)        (rANS_word.h:190-266)
+//           x_max is (M - cmpl_freq) << (31 - bits); the reciprocal (rANS_word.h:252) depends only on
+//           the frequency M - cmpl_freq, so it lives in ONE 16 KB table rcptab[freq] shared by every
+//           stream (it stays L1-resident) instead of costing 4 more bytes per entry.
+// An order-1 image for a 46-symbol alphabet is 8.7 KB: eighteen streams' tables fit one CU's LDS.
 // ---------------------------------------------------------------------------------------------
-struct EncEntry { u32 rcp; u32 pk; };
 #define ENC_IMG_IDX    256u
-#define ENC_IMG_MAIN   (ENC_IMG_IDX + 8u * 256u * 256u + 0u)      // 524,544
-#define ENC_IMG_O0     (ENC_IMG_IDX + 8u * 256u)                  // 2,304
-#define ENC_IMG_NESTED 524800u                                    // offset of the nested-table image
-#define ENC_IMG_META   (ENC_IMG_NESTED + 2304u)                   // offset of the RLE-meta image
-#define ENC_IMG_BYTES  (ENC_IMG_META + 2304u)                     // 529,408 per block
+#define ENC_IMG_MAIN   (ENC_IMG_IDX + 4u * 256u * 256u)           // 262,400
+#define ENC_IMG_O0     (ENC_IMG_IDX + 4u * 256u)                  // 1,280
+#define ENC_IMG_NESTED ENC_IMG_MAIN                               // offset of the nested-table image
+#define ENC_IMG_META   (ENC_IMG_NESTED + ENC_IMG_O0)              // offset of the RLE-meta image
+#define ENC_IMG_BYTES  (ENC_IMG_META + ENC_IMG_O0)                // 264,960 per block
+#define RCPTAB_ENTRIES 4097u
 
 struct EncItem {
     u64 data;        // device address of the bytes to code
@@ -187,6 +188,7 @@ struct EncWs {
     u8 *scratch;        // [nblk][scratch_stride]  backward-written states + words
     u32 *F;             // [nblk][65536]  order-1 counters when the alphabet is too big for LDS
     const double *logtab;   // [2][257]  log(1024+k), log(4096+k) from the host libm (:651-652)
+    const u32 *rcptab;      // [4097]    reciprocal by frequency (rANS_word.h:252), shared by all streams
     u64 scratch_stride;
     // X_PACK / X_RLE staging (strides are 0 when the batch cannot use them)
     u8 *packed;         // [nblk][xf_stride]   bit-packed bytes

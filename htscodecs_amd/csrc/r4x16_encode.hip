@@ -80,26 +80,23 @@ __device__ int normalise_freq(u32 *F, u32 cnt, int size, u32 tot)
     }
 }
 
-// RansEncSymbolInit, rANS_word.h:190-266, packed into an EncEntry.
-__device__ __forceinline__ EncEntry make_entry(u32 start, u32 freq, u32 bits)
+// RansEncSymbolInit, rANS_word.h:190-266: bias, complement of the frequency and reciprocal shift
+// packed into one word; the reciprocal itself comes from rcptab[freq] (r4x16_common.h).
+__device__ __forceinline__ u32 make_entry(u32 start, u32 freq, u32 bits)
 {
-    EncEntry e;
     const u32 M = 1u << bits;
     const u32 cmpl = M - freq;
     u32 bias, rsh;
     if (freq < 2) {
-        e.rcp = ~0u;
         rsh = 0;
         bias = start + M - 1;
     } else {
         u32 shift = 0;
         while (freq > (1u << shift)) shift++;
-        e.rcp = (u32)(((1ull << (shift + 31)) + freq - 1) / freq);
         rsh = shift - 1;
         bias = start;
     }
-    e.pk = bias | (cmpl << 13) | (rsh << 26);
-    return e;
+    return bias | (cmpl << 13) | (rsh << 26);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -118,7 +115,6 @@ __device__ __forceinline__ EncEntry make_entry(u32 start, u32 freq, u32 bits)
 //                       then all four walk their quarters backwards with the previous byte as
 //                       context, and the first byte of each quarter is coded in context 0.
 // ---------------------------------------------------------------------------------------------
-typedef GAS const EncEntry gcEncEntry;
 
 // One coding step given the entry; returns the emit flag (for the caller's ballot).
 __device__ __forceinline__ bool enc_wants_emit(u32 x, u32 pk, u32 bits)
@@ -126,6 +122,12 @@ __device__ __forceinline__ bool enc_wants_emit(u32 x, u32 pk, u32 bits)
     const u32 cmpl = (pk >> 13) & 0x1fffu;
     const u32 x_max = ((1u << bits) - cmpl) << (31 - bits);
     return x >= x_max;
+}
+__device__ __forceinline__ u32 enc_rcp(gcu32 *rcptab, u32 pk, u32 bits)
+{
+    // lanes without a live stream may hold garbage in pk: keep the index inside the table
+    const u32 f = (1u << bits) - ((pk >> 13) & 0x1fffu);
+    return rcptab[f < RCPTAB_ENTRIES ? f : 0u];
 }
 __device__ __forceinline__ u32 enc_advance(u32 x, u32 rcp, u32 pk)
 {
@@ -136,11 +138,11 @@ __device__ __forceinline__ u32 enc_advance(u32 x, u32 rcp, u32 pk)
 // General form: image in global memory, byte loads.  Used for the small nested streams inside
 // k_enc_front and for alphabets whose tables do not fit LDS.
 template <int ORDER>
-__device__ __forceinline__ u32 chain_encode(gcu8 *data, u32 n, gcu8 *image, u32 ns, u32 bits,
+__device__ __forceinline__ u32 chain_encode(gcu8 *data, u32 n, gcu8 *image, u32 ns, u32 bits, gcu32 *rcptab,
                                             gu8 *scratch_end, bool active, u32 lane)
 {
     const u32 k = lane & 3;
-    gcEncEntry *ent = (gcEncEntry *)(image + ENC_IMG_IDX);
+    gcu32 *ent = (gcu32 *)(image + ENC_IMG_IDX);
     u32 x = RANS_LOW;
     u32 written = 0;                 // words emitted by the quad so far
     u32 nsteps, first;               // this lane takes part in steps [first, nsteps)
@@ -174,8 +176,8 @@ __device__ __forceinline__ u32 chain_encode(gcu8 *data, u32 n, gcu8 *image, u32 
                 nextc = image[data[p - 1]];
                 row = nextc;
             }
-            gcEncEntry *ep = &ent[row * ns + cur];
-            rcp = ep->rcp; pk = ep->pk;
+            pk = ent[row * ns + cur];
+            rcp = enc_rcp(rcptab, pk, bits);
             emit = enc_wants_emit(x, pk, bits);
         }
         const u32 em = quad_ballot(emit, lane);
@@ -206,25 +208,25 @@ __device__ __forceinline__ u32 chain_encode(gcu8 *data, u32 n, gcu8 *image, u32 
 // the backward walk; (B') its last 0..3 steps; (C) the quarter starts in context 0.  Streams of
 // different lengths in one wave simply drop out of (B) at different trips.
 // ---------------------------------------------------------------------------------------------
-struct EncLds {
-    const u8 *idx;                  // u8  idx_of[256]
-    const u32x2 *ent;               // {rcp, pk}[ns*ns]
-};
-
 __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, gcu8 *data, u32 n, u32 ns, u32 bits,
-                                                   gu8 *scratch_end, bool active, u32 lane)
+                                                   gcu32 *rcptab, gu8 *scratch_end, bool active, u32 lane)
 {
     const u32 k = lane & 3;
-    const u32 qshift = lane & ~3u;
+    const u32 mybit = 1u << k;
     const u8 *idx = img_lds;
-    const u32x2 *ent = (const u32x2 *)(img_lds + ENC_IMG_IDX);
+    const u32 *ent = (const u32 *)(img_lds + ENC_IMG_IDX);
+    auto fetch = [&](u32 i) -> u32x2 {                    // {rcp, pk} of entry i
+        const u32 pk = ent[i];
+        u32x2 r = {enc_rcp(rcptab, pk, bits), pk};
+        return r;
+    };
     u32 x = RANS_LOW, written = 0;
     const u32 q = active ? n >> 2 : 0;
     const u32 tail = active ? n - 4 * q : 0;
 
     auto step = [&](bool live, u32 rcp, u32 pk) {
         const bool emit = live && enc_wants_emit(x, pk, bits);
-        const u32 em = (u32)(__ballot(emit) >> qshift) & 0xfu;
+        const u32 em = quad_mask_dpp(emit, mybit);
         if (emit) {
             const u32 above = __popc(em >> (k + 1));
             *(gu16 *)(scratch_end - 2 * (written + above + 1)) = (u16)x;
@@ -243,7 +245,7 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, gcu8 *data
         u32 rcp = 0, pk = 0;
         if (live) {
             const u32 ci = idx[data[n - 2 - s]];
-            const u32x2 e = ent[ci * ns + cur];
+            const u32x2 e = fetch(ci * ns + cur);
             rcp = e.x; pk = e.y;
             cur = ci;
         }
@@ -269,7 +271,7 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, gcu8 *data
         u32 c0, c1, c2, c3;
         auto lookup = [&](u32 ww, u32 sym, u32x2 &e0, u32x2 &e1, u32x2 &e2, u32x2 &e3, u32 &last) {
             c0 = idx[ww >> 24]; c1 = idx[(ww >> 16) & 0xff]; c2 = idx[(ww >> 8) & 0xff]; c3 = idx[ww & 0xff];
-            e0 = ent[c0 * ns + sym]; e1 = ent[c1 * ns + c0]; e2 = ent[c2 * ns + c1]; e3 = ent[c3 * ns + c2];
+            e0 = fetch(c0 * ns + sym); e1 = fetch(c1 * ns + c0); e2 = fetch(c2 * ns + c1); e3 = fetch(c3 * ns + c2);
             last = c3;
         };
         u32 nxt_cur = 0;
@@ -298,7 +300,7 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, gcu8 *data
         u32 rcp = 0, pk = 0;
         if (live) {
             const u32 ci = idx[qbase[r - 1]];
-            const u32x2 e = ent[ci * ns + cur];
+            const u32x2 e = fetch(ci * ns + cur);
             rcp = e.x; pk = e.y;
             cur = ci; r--; done++;
         }
@@ -308,7 +310,7 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, gcu8 *data
     {
         const bool live = active && q > 0;
         u32 rcp = 0, pk = 0;
-        if (live) { const u32x2 e = ent[0 * ns + cur]; rcp = e.x; pk = e.y; }
+        if (live) { const u32x2 e = fetch(cur); rcp = e.x; pk = e.y; }
         step(live, rcp, pk);
     }
     if (active) *(gu32 *)(scratch_end - 2 * written - 16 + 4 * k) = x;
@@ -317,12 +319,12 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, gcu8 *data
 
 // Hot form, order-0: one row of entries in LDS; chain k takes bytes 4g+k for descending g.
 __device__ __forceinline__ u32 chain_encode_o0_lds(const u8 *img_lds, gcu8 *data, u32 n, u32 bits,
-                                                   gu8 *scratch_end, bool active, u32 lane)
+                                                   gcu32 *rcptab, gu8 *scratch_end, bool active, u32 lane)
 {
     const u32 k = lane & 3;
-    const u32 qshift = lane & ~3u;
+    const u32 mybit = 1u << k;
     const u8 *idx = img_lds;
-    const u32x2 *ent = (const u32x2 *)(img_lds + ENC_IMG_IDX);
+    const u32 *ent = (const u32 *)(img_lds + ENC_IMG_IDX);
     u32 x = RANS_LOW, written = 0;
     const u32 gtop = (active && n) ? (n - 1) >> 2 : 0;
     u32 nsteps = (active && n) ? gtop + 1 : 0;
@@ -331,10 +333,11 @@ __device__ __forceinline__ u32 chain_encode_o0_lds(const u8 *img_lds, gcu8 *data
     u32 byte = (nsteps > first) ? data[p] : 0u;
     for (u32 s = 0; wave_any(s < nsteps); s++) {
         const bool live = s >= first && s < nsteps;
-        const u32x2 e = ent[idx[byte]];
+        const u32 pk0 = ent[idx[byte]];
+        const u32x2 e = {enc_rcp(rcptab, pk0, bits), pk0};
         const u32 nb = (live && p >= 4) ? data[p - 4] : 0u;          // next group's byte, a step ahead
         const bool emit = live && enc_wants_emit(x, e.y, bits);
-        const u32 em = (u32)(__ballot(emit) >> qshift) & 0xfu;
+        const u32 em = quad_mask_dpp(emit, mybit);
         if (emit) {
             const u32 above = __popc(em >> (k + 1));
             *(gu16 *)(scratch_end - 2 * (written + above + 1)) = (u16)x;
@@ -418,7 +421,7 @@ __device__ u32 put_alphabet(u8 *cp, const u8 *present)
 // enc_o0_tables expects the byte histogram of the data in S.F.
 __device__ void enc_o0_tables(u32 n, u8 *tab, u8 *image, EncShared &S, u32 lane)
 {
-    EncEntry *imgrow = (EncEntry *)(image + ENC_IMG_IDX);
+    u32 *imgrow = (u32 *)(image + ENC_IMG_IDX);
     for (u32 j = lane; j < 256; j += WAVE) image[j] = (u8)j;       // order-0: symbols index the row directly
     if (lane == 0) {
         u32 target = pow2_ceil(n);
@@ -927,7 +930,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
 
     // ---- encoder image: scale each row up to 1<<bits (:756) and build entries (:759-762) -----------
     for (u32 j = lane; j < 256; j += WAVE) img[j] = S.present[j] ? S.idx_of[j] : (u8)0;
-    EncEntry *ent = (EncEntry *)(img + ENC_IMG_IDX);
+    u32 *ent = (u32 *)(img + ENC_IMG_IDX);
     for (u32 r = 0; r < ns; r++) {
         u32 sh = 0;
         const u32 tgt = (u32)S.S[r];
@@ -954,7 +957,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
         __threadfence();
         wsync();
         const u32 npay = chain_encode<0>(to_global((const u8 *)tabraw), tlen, to_global((const u8 *)img0), 256u,
-                                         O0_BITS, to_global(scratch_end), lane < 4, lane);
+                                         O0_BITS, to_global(ws.rcptab), to_global(scratch_end), lane < 4, lane);
         const u32 np = __shfl(npay, 0);
         __threadfence();
         wsync();
@@ -985,7 +988,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
     if (lane == 0) {
         D->tab_len = final_len;
         I0->data = (u64)data; I0->n = n; I0->image = (u64)img; I0->bits = bits; I0->order = 1;
-        I0->ns = ns; I0->img_bytes = ENC_IMG_IDX + 8u * ns * ns;
+        I0->ns = ns; I0->img_bytes = ENC_IMG_IDX + 4u * ns * ns;
         I0->scratch_end = (u64)scratch_end;
         __threadfence();
         I0->active = 1;
@@ -996,8 +999,8 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
 // k_enc_chain: QPW streams per wave, one launch per LDS size class (see k_dec_chain).
 // ---------------------------------------------------------------------------------------------
 template <bool LDS_IMG>
-__global__ __launch_bounds__(WAVE) void k_enc_chain(EncItem *items, int nitems, int qpw, u32 lds_per_item,
-                                                    u32 cls_lo, u32 cls_hi)
+__global__ __launch_bounds__(WAVE) void k_enc_chain(EncItem *items, const u32 *rcptab_, int nitems, int qpw,
+                                                    u32 lds_per_item, u32 cls_lo, u32 cls_hi)
 {
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
     const u32 lane = threadIdx.x;
@@ -1011,6 +1014,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_chain(EncItem *items, int nitems, 
     if (!wave_any(active)) return;
 
     const u32 order = active ? I->order : 2u;
+    gcu32 *rcptab = to_global(rcptab_);
     gcu8 *data = (gcu8 *)I->data;
     gu8 *send = (gu8 *)I->scratch_end;
     const u32 n = I->n, ns = I->ns, bits = active ? I->bits : 12u;
@@ -1027,12 +1031,12 @@ __global__ __launch_bounds__(WAVE) void k_enc_chain(EncItem *items, int nitems, 
         }
         __syncthreads();
         const u8 *im = lds + (u64)quad * lds_per_item;
-        pay = chain_encode_o1_lds(im, data, n, ns, bits, send, order == 1, lane);
-        pay |= chain_encode_o0_lds(im, data, n, bits, send, order == 0, lane);
+        pay = chain_encode_o1_lds(im, data, n, ns, bits, rcptab, send, order == 1, lane);
+        pay |= chain_encode_o0_lds(im, data, n, bits, rcptab, send, order == 0, lane);
     } else {
         gcu8 *im = (gcu8 *)I->image;
-        pay = chain_encode<1>(data, n, im, ns, bits, send, order == 1, lane);
-        pay |= chain_encode<0>(data, n, im, ns, bits, send, order == 0, lane);
+        pay = chain_encode<1>(data, n, im, ns, bits, rcptab, send, order == 1, lane);
+        pay |= chain_encode<0>(data, n, im, ns, bits, rcptab, send, order == 0, lane);
     }
     if (active && (lane & 3) == 0) I->pay_len = pay;
 }
@@ -1119,8 +1123,9 @@ extern "C" void r4x16_launch_enc_front(const BatchArgs *a, const EncWs *ws, int 
     }
     hipLaunchKernelGGL(k_enc_front, dim3(nblk), dim3(FRONT_THREADS), FRONT_DYN_LDS, s, *a, *ws, base);
 }
+// {LDS bytes per stream, streams per wave}: q4/q8 images are ~0.5 KB, an order-0 row 1.3 KB, q40 8.7 KB
 static const struct { u32 bytes; int qpw; } ENC_CLASSES[] = {
-    {2560, 16}, {5120, 8}, {10240, 4}, {18432, 1}, {40960, 1}, {81920, 1}, {163840, 1},
+    {1536, 16}, {2560, 16}, {5120, 8}, {8960, 2}, {20480, 1}, {40960, 1}, {81920, 1}, {163840, 1},
 };
 extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t s)
 {
@@ -1133,11 +1138,11 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
     for (const auto &c : ENC_CLASSES) {
         const int grid = (nitems + c.qpw - 1) / c.qpw;
         hipLaunchKernelGGL(k_enc_chain<true>, dim3(grid), dim3(WAVE), (size_t)c.qpw * c.bytes, s,
-                           ws->items, nitems, c.qpw, c.bytes, lo, c.bytes);
+                           ws->items, ws->rcptab, nitems, c.qpw, c.bytes, lo, c.bytes);
         lo = c.bytes;
     }
     const int grid = (nitems + 15) / 16;
-    hipLaunchKernelGGL(k_enc_chain<false>, dim3(grid), dim3(WAVE), 0, s, ws->items, nitems, 16, 0u, lo, 0xffffffffu);
+    hipLaunchKernelGGL(k_enc_chain<false>, dim3(grid), dim3(WAVE), 0, s, ws->items, ws->rcptab, nitems, 16, 0u, lo, 0xffffffffu);
 }
 extern "C" void r4x16_launch_enc_finish(const BatchArgs *a, const EncWs *ws, int base, int nblk, hipStream_t s)
 {
