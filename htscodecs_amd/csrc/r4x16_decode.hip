@@ -189,6 +189,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
 
     u32 row = rows, cursor = 0, bad = 0, t = 0;
     u32 acc = 0;                                          // order-1: the last (up to) 4 decoded bytes
+    u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;                   // order-1: completed dwords not yet stored (a3 newest)
     u32 hdr = 0;                                          // order-1: alpha[] word of the symbol decoded last step
     if (ORDER == 1 && count) bad = img.ld16(0);
 
@@ -219,8 +220,17 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
                     bad |= live ? hdr : 0u;               // ROW_EMPTY bit is tested after the loop
                     acc = (t + u <= count) ? __builtin_amdgcn_alignbit(hdr, acc, 8) : acc;
                 }
-                // symbols t-4 .. t-1 are now in acc, oldest in the low byte
-                if (u == 0 && t >= 4 && t <= count) { *(gu32_unaligned *)op = acc; op += 4; }
+                // symbols t-4 .. t-1 are now in acc, oldest in the low byte: queue the dword, and every
+                // fourth trip store 16 bytes at once (4-byte stores to 16 different lines per wave made
+                // the L2 write each line to HBM 3.5 times over; see profiles/)
+                if (u == 0 && t >= 4 && t <= count) {
+                    a0 = a1; a1 = a2; a2 = a3; a3 = acc;
+                    if ((t & 15u) == 0) {
+                        const u32x4 v = {a0, a1, a2, a3};
+                        *(GAS u32x4_unaligned *)op = v;
+                        op += 16;
+                    }
+                }
                 const u32 rown = rows + __umul24(s, roww);
                 hdr = live ? hn : hdr;
                 row = live ? rown : row;
@@ -269,9 +279,14 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     if (ORDER == 1 && count) {
         // t steps ran.  A chain whose count equals t still has its last byte in hdr and its last
         // four symbols unstored; any other chain has count%4 symbols left, already in acc.
-        u32 stored = count & ~3u;
-        if (count == t) { acc = __builtin_amdgcn_alignbit(hdr, acc, 8); stored = t - 4; }
-        const u32 rem = count - stored;                    // 0..4, in the top `rem` bytes of acc
+        // dwords were queued at steps 4, 8, .. <= min(count, t-4) and stored 16 bytes at a time
+        const u32 lastq = count < t - 4 ? count : t - 4;
+        const u32 pushed = lastq >> 2, nd = pushed & 3u;   // nd queued dwords are still in a(4-nd)..a3
+        if (count == t) acc = __builtin_amdgcn_alignbit(hdr, acc, 8);
+        if (nd == 3) { *(gu32_unaligned *)op = a1; op += 4; }
+        if (nd >= 2) { *(gu32_unaligned *)op = a2; op += 4; }
+        if (nd >= 1) { *(gu32_unaligned *)op = a3; op += 4; }
+        const u32 rem = count - 4 * pushed;                // 0..4, in the top `rem` bytes of acc
         for (u32 j = 0; j < rem; j++) op[j] = (u8)(acc >> (8 * (4 - rem + j)));
     }
     return bad & ROW_EMPTY;
