@@ -198,6 +198,18 @@ def main():
             kname, kavg = "k_dec_chain", dec_avg
         alg_bytes = (nblk * bs + comp_bytes) / launches_per_step
         achieved = alg_bytes / (kavg / 1e3) / 1e9
+        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE, separate runs, gfx950 FETCH correction applied) — only if taken on this very workload
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                pmc = json.load(f)
+            w = pmc["workload"]
+            if (w["blocks"], w["block_size"], w["data"], w["order"]) == (nblk, bs, args.data, order):
+                key = "k_dec_chain<true, 3>" if kname == "k_dec_chain" else "k_enc_chain<true>"
+                traffic = pmc["kernels"][key]["traffic_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "MB/s uncompressed throughput (encode+decode), rANS4x16 order-1, q40 blocks",
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
@@ -210,7 +222,7 @@ def main():
             "enc_MBps": round(nblk * bs / t_enc / 1e6, 1), "dec_MBps": round(nblk * bs / t_dec / 1e6, 1),
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": None, "avg_kernel_ms": round(kavg, 3),
+                         "traffic": traffic, "avg_kernel_ms": round(kavg, 3),
                          "enc_chain_ms": round(enc_avg, 3), "dec_chain_ms": round(dec_avg, 3),
                          "algorithmic_bytes_per_launch": int(alg_bytes)},
             "workspace_GB": round(dc.workspace_bytes() / 2**30, 2),
