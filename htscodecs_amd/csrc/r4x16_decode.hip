@@ -10,6 +10,7 @@
 //                 Replaces the loops at :574-607 and :1027-1114.
 //   k_dec_back  : one wave per block.  RLE expansion, bit-unpacking, CAT copies, final size
 //                 and status.  Replaces :1578-1629, rle.c:142-187, pack.c:211-348.
+#include <type_traits>
 #include "r4x16_dev.h"
 
 // ---- image access: global memory or LDS ------------------------------------------------------
@@ -193,17 +194,20 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     u32 hdr = 0;                                          // order-1: alpha[] word of the symbol decoded last step
     if (ORDER == 1 && count) bad = img.ld16(0);
 
-    // Four steps per trip: one loop test, one dword store and one ring check per trip.
-    while (wave_any(t < count)) {
+    // Four steps per trip: one loop test, one store and one ring check per trip.  A trip in which
+    // every stream of the wave is still running on all four chains and has at least 16 words left
+    // takes the FAST body: no per-lane liveness selects and no end-of-stream test.
+    auto trip = [&](auto fastc) {
+        constexpr bool FAST = decltype(fastc)::value;
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const bool live = (t + u) < count;
+            const bool live = FAST ? true : (t + u) < count;
             // next four candidate words (8 bytes at any byte alignment) from the ring; issued
             // before the table lookups so that their latency hides under them
             const u32 cb = off0 + 2 * cursor;
             const u32 ra = cb & 124u;
-            // (volatile: keeps the compiler from sinking these reads into the refill branch, which
-            //  would put their latency back on the dependent path)
+            // (volatile: keeps the compiler from sinking these reads into a branch, which would
+            //  put their latency back on the dependent path)
             lvcu32 *rp = (lvcu32 *)(ring + ra);       // explicit LDS pointer: a volatile generic access would go FLAT
             const u32 d0 = rp[0], d1 = rp[1], d2 = rp[2];
             const u32 sh = (cb & 3u) * 8u;
@@ -218,14 +222,14 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
                 // the byte of the symbol decoded one step ago and the flags of the row in use now
                 if (u > 0 || t > 0) {
                     bad |= live ? hdr : 0u;               // ROW_EMPTY bit is tested after the loop
-                    acc = (t + u <= count) ? __builtin_amdgcn_alignbit(hdr, acc, 8) : acc;
+                    acc = (FAST || t + u <= count) ? __builtin_amdgcn_alignbit(hdr, acc, 8) : acc;
                 }
                 // symbols t-4 .. t-1 are now in acc, oldest in the low byte: queue the dword, and every
                 // fourth trip store 16 bytes at once (4-byte stores to 16 different lines per wave made
                 // the L2 write each line to HBM 3.5 times over; see profiles/)
-                if (u == 0 && t >= 4 && t <= count) {
+                if (u == 0 && t >= 4 && (FAST || t <= count)) {
                     a0 = a1; a1 = a2; a2 = a3; a3 = acc;
-                    if ((t & 15u) == 0) {
+                    if ((t & 15u) == 0 && active) {
                         const u32x4 v = {a0, a1, a2, a3};
                         *(GAS u32x4_unaligned *)op = v;
                         op += 16;
@@ -243,7 +247,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             // simply advance by the number of requests (rANS_word.h:402-410).
             const u32 wm = quad_mask_dpp(want, mybit);
             const u32 pre = __popc(wm & below);
-            const bool take = want && cursor + pre < nwords;
+            const bool take = FAST ? want : (want && cursor + pre < nwords);
             const u32 wlo = __builtin_amdgcn_alignbit(d1, d0, sh), whi = __builtin_amdgcn_alignbit(d2, d1, sh);
             const u32 w2 = (pre & 2u) ? whi : wlo;
             const u32 w = (w2 >> ((pre & 1u) * 16u)) & 0xffffu;
@@ -254,18 +258,23 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             if (ORDER == 0) {
                 // the quad's four bytes are consecutive: lane 0 stores them as one dword
                 const u32 b1 = quad_bcast1(byte0), b2 = quad_bcast2(byte0), b3 = quad_bcast3(byte0);
-                const u32 l3 = quad_bcast3(live ? 1u : 0u);
+                const u32 l3 = FAST ? 1u : quad_bcast3(live ? 1u : 0u);
                 const u32 dw = byte0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-                if (l3) { if (k == 0) *(gu32_unaligned *)(op + 4 * (u64)(t + u)) = dw; }
+                if (l3) { if (k == 0 && active) *(gu32_unaligned *)(op + 4 * (u64)(t + u)) = dw; }
                 else if (live) op[4 * (u64)(t + u)] = (u8)byte0;
             }
         }
         t += 4;
+    };
+    while (wave_any(t < count)) {
+        const bool slow = active && (t + 4 > count || cursor + 16 > nwords);
+        if (!wave_any(slow)) trip(std::true_type{});
+        else trip(std::false_type{});
 
         // ring refill when the cursor has entered a new 64-byte half (at most 32 bytes ago)
         const u32 nh = (off0 + 2 * cursor) >> 6;
-        if (wave_any(nh != half)) {
-            if (nh != half) {
+        if (wave_any(active && nh != half)) {
+            if (active && nh != half) {                   // idle lanes hold garbage cursors: they must not write LDS
                 // half `nh+1` was requested at the previous crossing: park it in the slots just vacated
                 const u32 slot = ((nh + 1) & 1u) * 64u + 16u * k;
                 *(u32x4 *)(ring + slot) = pend;
@@ -289,7 +298,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
         const u32 rem = count - 4 * pushed;                // 0..4, in the top `rem` bytes of acc
         for (u32 j = 0; j < rem; j++) op[j] = (u8)(acc >> (8 * (4 - rem + j)));
     }
-    return bad & ROW_EMPTY;
+    return active ? (bad & ROW_EMPTY) : 0u;        // idle lanes ran on garbage in the fast trips
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1009,7 +1018,7 @@ extern "C" void r4x16_launch_dec_front(const BatchArgs *a, const DecWs *ws, int 
 // images at least 21 KB (or the lone 1.3 KB row of a large order-0 alphabet), so the two groups of
 // classes are walked separately.
 static const struct { u32 bytes; int qpw; int lv; } DEC_CLASSES[] = {
-    {1024, 16, 3}, {2560, 16, 3}, {5120, 8, 3}, {7680, 4, 3}, {8448, 4, 3},
+    {1024, 16, 3}, {2560, 16, 3}, {5120, 8, 3}, {7680, 4, 3}, {8960, 3, 3},
     {22528, 1, 4}, {32768, 1, 4}, {53248, 1, 4}, {81920, 1, 4}, {163840, 1, 4},
 };
 extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t s)
@@ -1020,21 +1029,23 @@ extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t 
         (void)hipFuncSetAttribute((const void *)k_dec_chain<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         once = true;
     }
-    u32 lo = 0;
+    u32 lo3 = 0, lo4 = 0;                                  // each tree depth walks its own classes from 0
     for (const auto &c : DEC_CLASSES) {
         const int grid = (nitems + c.qpw - 1) / c.qpw;
-        if (c.lv == 3)
+        if (c.lv == 3) {
             hipLaunchKernelGGL((k_dec_chain<true, 3>), dim3(grid), dim3(WAVE), (size_t)c.qpw * c.bytes, s,
-                               ws->items, ws->desc, nitems, c.qpw, c.bytes, lo, c.bytes);
-        else
+                               ws->items, ws->desc, nitems, c.qpw, c.bytes, lo3, c.bytes);
+            lo3 = c.bytes;
+        } else {
             hipLaunchKernelGGL((k_dec_chain<true, 4>), dim3(grid), dim3(WAVE), (size_t)c.qpw * c.bytes, s,
-                               ws->items, ws->desc, nitems, c.qpw, c.bytes, lo, c.bytes);
-        if (c.bytes == 8448) lo = 0; else lo = c.bytes;       // the 4-level classes start again from 0
+                               ws->items, ws->desc, nitems, c.qpw, c.bytes, lo4, c.bytes);
+            lo4 = c.bytes;
+        }
     }
     // images that fit no LDS class: tables stay in global memory (L2)
     const int grid = (nitems + 15) / 16;
-    hipLaunchKernelGGL((k_dec_chain<false, 3>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, nitems, 16, 0u, 8448u, 0xffffffffu);
-    hipLaunchKernelGGL((k_dec_chain<false, 4>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, nitems, 16, 0u, 163840u, 0xffffffffu);
+    hipLaunchKernelGGL((k_dec_chain<false, 3>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, nitems, 16, 0u, lo3, 0xffffffffu);
+    hipLaunchKernelGGL((k_dec_chain<false, 4>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, nitems, 16, 0u, lo4, 0xffffffffu);
 }
 extern "C" void r4x16_launch_dec_back(const BatchArgs *a, const DecWs *ws, int base, int nblk, hipStream_t s)
 {

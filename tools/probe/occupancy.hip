@@ -12,7 +12,7 @@ __global__ __launch_bounds__(64) void spin(unsigned long long ticks, unsigned *s
 int main(int argc, char **argv) {
     unsigned *sink; hipMalloc(&sink, 4);
     hipFuncSetAttribute((const void *)spin, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-    int sizes[] = {2560, 5120, 10240, 16384, 20480, 22528, 24576, 32768, 40960, 65536, 81920, 163840};
+    int sizes[] = {7232, 7296, 7680, 8192, 14464, 14592, 14848, 15360, 16384, 17920, 18176, 18432, 20480, 28928, 30720, 36160};
     for (int s : sizes) {
         int best = 0;
         for (int k = 1; k <= 40; k++) {
