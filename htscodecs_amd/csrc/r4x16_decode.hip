@@ -715,11 +715,13 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
             if (!S.present[ctx]) {
                 S.empty = 1;                                           // byte 0 outside F0
             } else {
-                // decode_freq_d :327-358
+                // decode_freq_d :327-358; "for j in 0..255 if F0[j]" is a walk over the compact
+                // alphabet (its members other than a forced-in 0 are exactly F0, in byte order)
                 u32 p = S.pos, total = 0, zeros = 0;
                 bool ok = p != tend;
-                for (u32 j = 0; j < 256; j++) S.F[j] = 0;
-                for (u32 j = 0; ok && j < 256 && p < tend; j++) {
+                for (u32 cj = 0; cj < nsym; cj++) S.F[S.alpha[cj]] = 0;
+                for (u32 cj = 0; ok && cj < nsym && p < tend; cj++) {
+                    const u32 j = S.alpha[cj];
                     if (!S.present[j]) continue;
                     u32 f;
                     if (zeros) { f = 0; zeros--; }

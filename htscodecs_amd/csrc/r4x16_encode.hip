@@ -318,7 +318,8 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, gcu8 *data
 }
 
 // Hot form, order-0: one row of entries in LDS; chain k takes bytes 4g+k for descending g.
-__device__ __forceinline__ u32 chain_encode_o0_lds(const u8 *img_lds, gcu8 *data, u32 n, u32 bits,
+template <class DP>     // DP: gcu8* (stream in HBM) or const u8* (small stream staged in LDS)
+__device__ __forceinline__ u32 chain_encode_o0_lds(const u8 *img_lds, DP data, u32 n, u32 bits,
                                                    gcu32 *rcptab, gu8 *scratch_end, bool active, u32 lane)
 {
     const u32 k = lane & 3;
@@ -463,10 +464,13 @@ __device__ void enc_o0_front(const u8 *data, u32 n, u8 *tab, u8 *image, EncShare
 // ---------------------------------------------------------------------------------------------
 #define FRONT_THREADS 256u
 
-__device__ void wg_hist8(const u8 *data, u32 n, u32 *F, u32 tid)
+// `priv`: 16 x 256 scratch counters; threads spread over 16 private copies (tid & 15) so that the
+// few hot symbols of quality data do not serialise the LDS atomics of a whole wave.
+__device__ void wg_hist8(const u8 *data, u32 n, u32 *Fout, u32 *priv, u32 tid)
 {
-    for (u32 j = tid; j < 256; j += FRONT_THREADS) F[j] = 0;
+    for (u32 j = tid; j < 4096; j += FRONT_THREADS) priv[j] = 0;
     __syncthreads();
+    u32 *F = priv + 256 * (tid & 15);
     u32 head = (u32)((16 - ((u64)data & 15)) & 15);
     if (head > n) head = n;
     if (tid < head) atomicAdd(&F[data[tid]], 1u);
@@ -486,12 +490,21 @@ __device__ void wg_hist8(const u8 *data, u32 n, u32 *F, u32 tid)
     const u32 done = head + body * 16;
     if (done + tid < n) atomicAdd(&F[data[done + tid]], 1u);
     __syncthreads();
+    {
+        u32 t = 0;
+#pragma unroll
+        for (int c = 0; c < 16; c++) t += priv[256 * c + tid];
+        Fout[tid] = t;                                   // FRONT_THREADS == 256
+    }
+    __syncthreads();
 }
 
-// FP points at ns*ns zeroed counters (LDS when IN_LDS, else global).
+// Fp0 points at `copies` x ns*ns zeroed counters (LDS, or global with copies == 1); threads spread
+// over the copies by tid, and the copies are summed into the first one at the end.
 template <class FP>
-__device__ void wg_hist1(const u8 *data, u32 n, FP Fp, u32 ns, const u8 *idx_of, u32 tid)
+__device__ void wg_hist1(const u8 *data, u32 n, FP Fp0, u32 ns, u32 copies, const u8 *idx_of, u32 tid)
 {
+    FP Fp = Fp0 + (tid & (copies - 1)) * ns * ns;
     const u32 pieces = (n + 15) >> 4;
     for (u32 pi = tid; pi < pieces; pi += FRONT_THREADS) {
         const u32 off = pi * 16;
@@ -520,8 +533,16 @@ __device__ void wg_hist1(const u8 *data, u32 n, FP Fp, u32 ns, const u8 *idx_of,
     }
     __syncthreads();
     // the three quarter starts are coded in context 0 (rANS_static4x16pr.c:720-723)
-    if (tid >= 1 && tid < 4) atomicAdd(&Fp[idx_of[data[tid * (n >> 2)]]], 1u);
+    if (tid >= 1 && tid < 4) atomicAdd(&Fp0[idx_of[data[tid * (n >> 2)]]], 1u);
     __syncthreads();
+    if (copies > 1) {
+        for (u32 j = tid; j < ns * ns; j += FRONT_THREADS) {
+            u32 t = Fp0[j];
+            for (u32 c = 1; c < copies; c++) t += Fp0[c * ns * ns + j];
+            Fp0[j] = t;
+        }
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -784,7 +805,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
     const u32 n = H.dlen;
 
     // pass 1 over the block: byte histogram (hist8 / present8, utils.h:80-131), all waves
-    wg_hist8(data, n, S.F, tid);
+    wg_hist8(data, n, S.F, (u32 *)dyn, tid);
 
     if (H.order == 0) {
         if (!w0) return;
@@ -815,12 +836,13 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
     const u32 ns = S.nsym;
     const bool f_in_lds = ns <= FRONT_LDS_NSYM;
     u32 *Fg = ws.F + (u64)b * 65536u;
-    if (f_in_lds) { for (u32 j = tid; j < ns * ns; j += FRONT_THREADS) ((u32 *)dyn)[j] = 0; }
+    const u32 copies = !f_in_lds ? 1u : (16u * ns * ns <= FRONT_DYN_LDS ? 4u : (8u * ns * ns <= FRONT_DYN_LDS ? 2u : 1u));
+    if (f_in_lds) { for (u32 j = tid; j < copies * ns * ns; j += FRONT_THREADS) ((u32 *)dyn)[j] = 0; }
     else          { for (u32 j = tid; j < ns * ns; j += FRONT_THREADS) Fg[j] = 0; }
     __syncthreads();
     // pass 2 over the block: order-1 pair histogram, all waves
-    if (f_in_lds) wg_hist1(data, n, (u32 *)dyn, ns, S.idx_of, tid);
-    else          wg_hist1(data, n, Fg, ns, S.idx_of, tid);
+    if (f_in_lds) wg_hist1(data, n, (u32 *)dyn, ns, copies, S.idx_of, tid);
+    else          wg_hist1(data, n, Fg, ns, 1u, S.idx_of, tid);
     if (!w0) return;
 
     u32 *Fp = f_in_lds ? (u32 *)dyn : Fg;
@@ -951,13 +973,29 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
     u32 final_len = 0;
     bool nested = false;
     if (1 + tlen > 1000) {
-        u8 *img0 = img + ENC_IMG_NESTED;
         u8 *ntab = scratch;                                           // nested table bytes, staged low
-        enc_o0_front(tabraw, tlen, ntab, img0, S, lane);
-        __threadfence();
-        wsync();
-        const u32 npay = chain_encode<0>(to_global((const u8 *)tabraw), tlen, to_global((const u8 *)img0), 256u,
-                                         O0_BITS, to_global(ws.rcptab), to_global(scratch_end), lane < 4, lane);
+        u32 npay;
+        if (f_in_lds && tlen <= 49152u) {
+            // the counters in `dyn` are spent: reuse the space for the table bytes and the coder's
+            // one-row image, so that the 4-lane coder of this small stream never leaves the CU
+            u8 *ltab = dyn, *limg = dyn + 49152u;
+            __threadfence();
+            wsync();
+            wave_copy(ltab, tabraw, tlen, lane);
+            wsync();
+            enc_o0_front(ltab, tlen, ntab, limg, S, lane);
+            __threadfence();
+            wsync();
+            npay = chain_encode_o0_lds(limg, (const u8 *)ltab, tlen, O0_BITS, to_global(ws.rcptab),
+                                       to_global(scratch_end), lane < 4, lane);
+        } else {
+            u8 *img0 = img + ENC_IMG_NESTED;
+            enc_o0_front(tabraw, tlen, ntab, img0, S, lane);
+            __threadfence();
+            wsync();
+            npay = chain_encode<0>(to_global((const u8 *)tabraw), tlen, to_global((const u8 *)img0), 256u,
+                                   O0_BITS, to_global(ws.rcptab), to_global(scratch_end), lane < 4, lane);
+        }
         const u32 np = __shfl(npay, 0);
         __threadfence();
         wsync();
