@@ -224,7 +224,10 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic, "avg_kernel_ms": round(kavg, 3),
                          "enc_chain_ms": round(enc_avg, 3), "dec_chain_ms": round(dec_avg, 3),
-                         "algorithmic_bytes_per_launch": int(alg_bytes)},
+                         "algorithmic_bytes_per_launch": int(alg_bytes),
+                         "note": "avg_kernel_ms = HIP-event time of the chain kernel per step; the kernel is launched "
+                                 "once per LDS size class and all but one class exit in microseconds, so compare with "
+                                 "rocprof's TotalDurationNs / steps (profiles/r01_final_working_launches.csv)"},
             "workspace_GB": round(dc.workspace_bytes() / 2**30, 2),
         }
         if world == 1 and not args.no_cpu:
