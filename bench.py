@@ -117,9 +117,14 @@ def main():
 
     from htscodecs_amd import shard
     rank, world, local = shard.env_rank()
+    # rehearsal knobs (not used by the driver): several ranks on one card over gloo
+    if "R4X16_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["R4X16_FORCE_DEVICE"])
+    backend = os.environ.get("R4X16_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = shard.init("nccl", device_id=dev)        # RCCL; used for the barrier and the max only
+    dist = shard.init(backend, device_id=dev)       # nccl = RCCL; used for the barrier and the max only
+    red_dev = dev if backend == "nccl" else None
 
     nblk, bs, order = args.blocks, args.block_size, args.order
     dc = H.DeviceCodec(local)
@@ -181,7 +186,7 @@ def main():
             got = d_comp[b * slot:b * slot + int(csz[b])].cpu().numpy().tobytes()
             assert got == want, f"block {b}: device stream differs from the CPU reference"
 
-    elapsed = shard.max_over_ranks(dist, elapsed, dev)
+    elapsed = shard.max_over_ranks(dist, elapsed, red_dev)
 
     if rank == 0:
         total_unc = nblk * bs * world
