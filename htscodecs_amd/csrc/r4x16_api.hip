@@ -21,6 +21,7 @@ void r4x16_launch_dec_front(const BatchArgs *, const DecWs *, int, int, hipStrea
 void r4x16_launch_dec_chain(const DecWs *, int, hipStream_t);
 void r4x16_launch_dec_back(const BatchArgs *, const DecWs *, int, int, hipStream_t);
 void r4x16_launch_enc_front(const BatchArgs *, const EncWs *, int, int, hipStream_t);
+void r4x16_launch_enc_tables(const BatchArgs *, const EncWs *, int, int, hipStream_t);
 void r4x16_launch_enc_chain(const EncWs *, int, hipStream_t);
 void r4x16_launch_enc_finish(const BatchArgs *, const EncWs *, int, int, hipStream_t);
 u32  r4x16_compress_bound(u32 size, int order);
@@ -189,6 +190,7 @@ static size_t enc_ws_layout(u8 *base, size_t nblk, u64 scratch_stride, u64 xf_st
     w->meta = cv.take<u8>(nblk, xf_stride ? xf_stride + 768 : 0);
     w->metatab = cv.take<u8>(nblk, xf_stride ? META_TAB_BYTES : 0);
     w->scratch2 = cv.take<u8>(nblk, scratch2_stride);
+    w->stat = cv.take<EncStat>(nblk);
     w->xf_stride = xf_stride;
     w->scratch2_stride = scratch2_stride;
     return align_up(cv.off, 256);
@@ -237,6 +239,7 @@ extern "C" int rans4x16_hip_compress_dev(rans4x16_hip_ctx *c, int n,
     for (size_t base = 0; base < (size_t)n; base += chunk) {
         const int nb = (int)((size_t)n - base < chunk ? (size_t)n - base : chunk);
         r4x16_launch_enc_front(&a, &w, (int)base, nb, s);
+        r4x16_launch_enc_tables(&a, &w, (int)base, nb, s);
         TimedLaunch t;
         if (c->timing) time_begin(c, 0, s, t);
         r4x16_launch_enc_chain(&w, 2 * nb, s);

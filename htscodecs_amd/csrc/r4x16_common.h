@@ -179,6 +179,18 @@ struct DecWs {
     u64 tmp_stride, meta_stride;
 };
 
+// What the histogram kernel hands to the table kernel (per block).
+struct EncStat {
+    u32 F0[256];        // byte histogram of the data handed to the entropy stage
+    u8  present[256];   // order-1 alphabet F0 (byte 0 forced in)
+    u8  idx_of[256];    // byte -> compact index
+    u8  alpha[256];     // compact index -> byte
+    u32 ns;             // alphabet size
+    u32 run;            // 0: nothing to do for this block (failed, CAT, empty)
+    u32 order;          // 0 / 1 after the "fewer than 8 bytes" rule
+    u32 pad;
+};
+
 struct EncWs {
     EncDesc *desc;      // [nblk]
     EncItem *items;     // [2*nblk]  [b] = payload stream of block b, [nblk+b] = its RLE meta stream
@@ -196,6 +208,8 @@ struct EncWs {
     u8 *meta;           // [nblk][xf_stride + 768]  RLE meta: nsyms, syms, run varints (filled from the end)
     u8 *metatab;        // [nblk][1024]        order-0 table of the meta stream
     u8 *scratch2;       // [nblk][scratch2_stride]  backward-written meta stream
+    EncStat *stat;      // [nblk]
     u64 xf_stride, scratch2_stride;
 };
 #define META_TAB_BYTES 1024u
+

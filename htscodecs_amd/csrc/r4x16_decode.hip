@@ -466,6 +466,7 @@ __device__ void o0_front(ByteSrc &src, u32 pos, u32 len, u32 out_sz, u8 *img, Fr
 __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int base)
 {
     __shared__ FrontShared S;
+    __shared__ __attribute__((aligned(16))) u8 nimg[IMG_O0_BYTES + RING_BYTES];   // nested table stream: image + ring
     __shared__ struct {
         i32 status;
         u32 order, pay_pos, pay_len, s1_size, compressed, usz, csz, tab_pos, after_table;
@@ -664,23 +665,23 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
     const bool compressed = H.compressed != 0;
 
     if (compressed) {
-        // un-nest the table: an order-0 stream of usz bytes inside src[tab_pos, tab_pos+csz)
-        u8 *img0 = img + IMG_MAX_BYTES;
-        o0_front(src, H.tab_pos, H.csz, H.usz, img0, S, lane);
+        // un-nest the table: an order-0 stream of usz bytes inside src[tab_pos, tab_pos+csz).  Its
+        // one-row image and word ring live in this workgroup's LDS, so the 4-lane decoder of this
+        // small stream runs at LDS latency; its output goes to tbuf (L2-resident, read back below).
+        o0_front(src, H.tab_pos, H.csz, H.usz, nimg, S, lane);
         if (S.status != ST_OK) { if (lane == 0) D->status = S.status; return; }
-        __threadfence();
-        GImg g{to_global((const u8 *)img0)};
+        u8 *nring = nimg + IMG_O0_BYTES;
         if (img_levels(S.nsym) == 3)
-            chain_decode<0, 3>(g, S.nsym, to_global(in + S.words_pos), H.tab_pos + H.csz - S.words_pos, to_global(tbuf),
-                               H.usz, S.R[lane & 3], O0_BITS, lane < 4, lane);
+            chain_decode_lds<0, 3>(nimg, S.nsym, nring, to_global(in + S.words_pos), H.tab_pos + H.csz - S.words_pos,
+                                   to_global(tbuf), H.usz, S.R[lane & 3], O0_BITS, lane < 4, lane);
         else
-            chain_decode<0, 4>(g, S.nsym, to_global(in + S.words_pos), H.tab_pos + H.csz - S.words_pos, to_global(tbuf),
-                               H.usz, S.R[lane & 3], O0_BITS, lane < 4, lane);
+            chain_decode_lds<0, 4>(nimg, S.nsym, nring, to_global(in + S.words_pos), H.tab_pos + H.csz - S.words_pos,
+                                   to_global(tbuf), H.usz, S.R[lane & 3], O0_BITS, lane < 4, lane);
         __threadfence();
         __syncthreads();
     }
 
-    ByteSrc tsrc(compressed ? tbuf : in, compressed);
+    ByteSrc tsrc(compressed ? tbuf : in);      // tbuf was never read by this CU before the fence above
     const u32 tend = compressed ? H.usz : pay_pos + pay_len;
 
     // alphabet F0 (:958-965) and the compact alphabet F0 ∪ {0}

@@ -690,6 +690,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
     // ---- container header (:1144-1237) ---------------------------------------------------------
     if (lane == 0) {
         H.run = 0;
+        ws.stat[b].run = 0;
         I0->active = 0; I1->active = 0; I0->pay_len = 0; I1->pay_len = 0;
         I0->blk = b; I1->blk = b;
         D->cat = 0; D->rle_on = 0; D->tab_len = 0; D->hdr_len = 0; D->dlen = 0; D->tab = (u64)tab;
@@ -807,18 +808,10 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
     // pass 1 over the block: byte histogram (hist8 / present8, utils.h:80-131), all waves
     wg_hist8(data, n, S.F, (u32 *)dyn, tid);
 
+    EncStat *ST = &ws.stat[b];
+    ST->F0[tid] = S.F[tid];                                               // FRONT_THREADS == 256
     if (H.order == 0) {
-        if (!w0) return;
-        enc_o0_tables(n, tab, img, S, lane);
-        if (lane == 0) {
-            D->status = S.status;
-            D->tab_len = S.tab_len;
-            I0->data = (u64)data; I0->n = n; I0->image = (u64)img; I0->bits = O0_BITS; I0->order = 0;
-            I0->ns = 256; I0->img_bytes = ENC_IMG_O0;
-            I0->scratch_end = (u64)scratch_end;
-            __threadfence();
-            I0->active = S.status == ST_OK;
-        }
+        if (tid == 0) { ST->run = 1; ST->order = 0; ST->ns = 0; }
         return;
     }
 
@@ -843,10 +836,65 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
     // pass 2 over the block: order-1 pair histogram, all waves
     if (f_in_lds) wg_hist1(data, n, (u32 *)dyn, ns, copies, S.idx_of, tid);
     else          wg_hist1(data, n, Fg, ns, 1u, S.idx_of, tid);
-    if (!w0) return;
+    // hand over to k_enc_tables: alphabet maps and the pair counters (compact, ns*ns)
+    ST->present[tid] = S.present[tid]; ST->idx_of[tid] = S.idx_of[tid]; ST->alpha[tid] = S.alpha[tid];
+    if (f_in_lds) for (u32 j = tid; j < ns * ns; j += FRONT_THREADS) Fg[j] = ((u32 *)dyn)[j];
+    if (tid == 0) { ST->run = 1; ST->order = 1; ST->ns = ns; }
+}
 
+// ---------------------------------------------------------------------------------------------
+// k_enc_tables: one wave per block, small LDS footprint so that thousands of blocks are resident:
+// everything between the histograms and the chain kernel — normalisation, the 10/12-bit decision,
+// table serialisation (nested coding included) and the encoder image.
+// ---------------------------------------------------------------------------------------------
+#define TABLES_DYN_LDS 10240u          // pair counters of alphabets up to 50 symbols; later the nested coder
+#define TABLES_LDS_NSYM 50u
+#define TABLES_NEST_MAX 8704u          // nested table bytes that fit next to a 1,280-byte image + slack
+
+__global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int base)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 dyn[];
+    __shared__ EncShared S;
+    __shared__ struct { i32 status; u32 nested_len; double e10, e12; int max_tot; } H;
+    const u32 lane = threadIdx.x;
+    const u32 b = blockIdx.x;
+    EncDesc *D = &ws.desc[b];
+    EncItem *I0 = &ws.items[b];
+    const EncStat *ST = &ws.stat[b];
+    if (D->status != ST_OK || !ST->run) return;
+    u8 *img = ws.images + (u64)b * ENC_IMG_BYTES;
+    u8 *tab = ws.tab + (u64)b * TAB_BYTES;
+    u8 *tabraw = ws.tabraw + (u64)b * TAB_BYTES;
+    u8 *scratch = ws.scratch + (u64)b * ws.scratch_stride;
+    u8 *scratch_end = scratch + ws.scratch_stride;
+    const u8 *data = (const u8 *)D->data;
+    const u32 n = D->dlen;
+
+    for (u32 j = lane; j < 256; j += WAVE) S.F[j] = ST->F0[j];
+    if (lane == 0) H.status = ST_OK;
+    wsync();
+    if (ST->order == 0) {
+        enc_o0_tables(n, tab, img, S, lane);
+        if (lane == 0) {
+            D->status = S.status;
+            D->tab_len = S.tab_len;
+            I0->data = (u64)data; I0->n = n; I0->image = (u64)img; I0->bits = O0_BITS; I0->order = 0;
+            I0->ns = 256; I0->img_bytes = ENC_IMG_O0;
+            I0->scratch_end = (u64)scratch_end;
+            __threadfence();
+            I0->active = S.status == ST_OK;
+        }
+        return;
+    }
+
+    const u32 ns = ST->ns;
+    for (u32 j = lane; j < 256; j += WAVE) { S.present[j] = ST->present[j]; S.idx_of[j] = ST->idx_of[j]; S.alpha[j] = ST->alpha[j]; }
+    if (lane == 0) S.nsym = ns;
+    u32 *Fg = ws.F + (u64)b * 65536u;
+    const bool f_in_lds = ns <= TABLES_LDS_NSYM;
+    if (f_in_lds) for (u32 j = lane; j < ns * ns; j += WAVE) ((u32 *)dyn)[j] = Fg[j];
+    wsync();
     u32 *Fp = f_in_lds ? (u32 *)dyn : Fg;
-    if (!f_in_lds) __threadfence();
     // context totals = row sums
     for (u32 r = lane; r < ns; r += WAVE) {
         u32 t = 0;
@@ -975,10 +1023,10 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
     if (1 + tlen > 1000) {
         u8 *ntab = scratch;                                           // nested table bytes, staged low
         u32 npay;
-        if (f_in_lds && tlen <= 49152u) {
+        if (f_in_lds && tlen <= TABLES_NEST_MAX) {
             // the counters in `dyn` are spent: reuse the space for the table bytes and the coder's
             // one-row image, so that the 4-lane coder of this small stream never leaves the CU
-            u8 *ltab = dyn, *limg = dyn + 49152u;
+            u8 *ltab = dyn, *limg = dyn + TABLES_NEST_MAX;
             __threadfence();
             wsync();
             wave_copy(ltab, tabraw, tlen, lane);
@@ -1165,6 +1213,10 @@ extern "C" void r4x16_launch_enc_front(const BatchArgs *a, const EncWs *ws, int 
 static const struct { u32 bytes; int qpw; } ENC_CLASSES[] = {
     {1536, 16}, {2560, 16}, {5120, 8}, {8960, 2}, {20480, 1}, {40960, 1}, {81920, 1}, {163840, 1},
 };
+extern "C" void r4x16_launch_enc_tables(const BatchArgs *a, const EncWs *ws, int base, int nblk, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_enc_tables, dim3(nblk), dim3(WAVE), TABLES_DYN_LDS, s, *a, *ws, base);
+}
 extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t s)
 {
     static bool once = false;
