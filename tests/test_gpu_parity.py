@@ -244,3 +244,71 @@ def test_cli_mirrors_reference_test_script(H, tmp_path):
     subprocess.run([cli, "-d", str(tmp_path / "f"), str(tmp_path / "g")], check=True)
     with open(tmp_path / "g", "rb") as f, open(os.path.join(GOLD, "dat", "q8.nl"), "rb") as g:
         assert f.read() == g.read()
+
+
+def test_device_batch_unaligned_offsets_and_edge_sizes(H, oracle):
+    """*_dev with blocks at odd byte offsets, zero-length and tiny blocks, a 5 MiB block, per-block
+    orders, and one slot whose capacity is too small (must fail alone with CAPACITY)."""
+    import torch
+    dc = H.DeviceCodec(0)
+    dev = dc.dev
+    sizes = [0, 1, 7, 8, 9, 63, 64, 65, 4097, 65537, 5 * (1 << 20) + 3, 1000, 12345]
+    names = ["q4", "q8", "q40+dir", "qvar"]
+    orders = [1, 0, 193, 65, 1, 129, 0, 1, 193, 1, 1, 64, 1]
+    blocks = [datagen.tile(names[i % 4], s, i) for i, s in enumerate(sizes)]
+    in_off, pos = [], 1                                   # odd offsets on purpose
+    for b in blocks:
+        in_off.append(pos)
+        pos += len(b) + 3 + (len(b) & 1)
+    arena = np.zeros(pos + 64, dtype=np.uint8)
+    for b, off in zip(blocks, in_off):
+        arena[off:off + len(b)] = b
+    caps = [H.rans_compress_bound_4x16(len(b), o) for b, o in zip(blocks, orders)]
+    caps[3] -= 100                                        # too small on purpose
+    out_off, pos = [], 3
+    for c in caps:
+        out_off.append(pos)
+        pos += c + 5
+    t = lambda a, dt: torch.from_numpy(np.asarray(a, dtype=dt)).to(dev)
+    d_in = torch.from_numpy(arena).to(dev)
+    d_out = torch.zeros(pos + 64, dtype=torch.uint8, device=dev)
+    d_in_off, d_in_size = t(in_off, np.int64), t(sizes, np.int32)
+    d_out_off, d_caps, d_ord = t(out_off, np.int64), t(caps, np.int32), t(orders, np.int32)
+    d_osz = torch.zeros(len(blocks), dtype=torch.int32, device=dev)
+    d_st = torch.full((len(blocks),), -1, dtype=torch.int32, device=dev)
+    dc.compress(d_in, d_in_off, d_in_size, d_out, d_out_off, d_caps, d_osz, d_st, 0, max(sizes), d_order=d_ord)
+    torch.cuda.synchronize()
+    st, osz, comp = d_st.cpu().numpy(), d_osz.cpu().numpy(), d_out.cpu().numpy()
+    assert st[3] == 1 and osz[3] == 0
+    for i, (b, o) in enumerate(zip(blocks, orders)):
+        if i == 3:
+            continue
+        assert st[i] == 0, (i, st[i])
+        assert comp[out_off[i]:out_off[i] + osz[i]].tobytes() == oracle.compress(b.tobytes(), o), (i, o)
+    # decode the good ones back to odd offsets
+    keep = [i for i in range(len(blocks)) if i != 3]
+    d_dec = torch.zeros_like(d_in)
+    dsz = torch.zeros(len(keep), dtype=torch.int32, device=dev)
+    dst = torch.full((len(keep),), -1, dtype=torch.int32, device=dev)
+    dc.uncompress(d_out, t([out_off[i] for i in keep], np.int64), t([int(osz[i]) for i in keep], np.int32),
+                  d_dec, t([in_off[i] for i in keep], np.int64), t([sizes[i] for i in keep], np.int32),
+                  dsz, dst, int(osz.max()), max(sizes))
+    torch.cuda.synchronize()
+    assert (dst.cpu().numpy() == 0).all(), dst.tolist()
+    dec = d_dec.cpu().numpy()
+    for i in keep:
+        assert (dec[in_off[i]:in_off[i] + sizes[i]] == blocks[i]).all(), i
+
+
+def test_host_api_from_threads(H, oracle):
+    """The five entry points are re-entrant: four host threads, each with its own lazily
+    created context, must all produce reference bytes."""
+    from concurrent.futures import ThreadPoolExecutor
+    datas = [datagen.tile("q8", 30000 + 1000 * i, i).tobytes() for i in range(16)]
+
+    def work(i):
+        c = H.rans_compress_4x16(datas[i], i % 2)
+        return c == oracle.compress(datas[i], i % 2) and H.rans_uncompress_4x16(c) == datas[i]
+
+    with ThreadPoolExecutor(4) as ex:
+        assert all(ex.map(work, range(16)))
