@@ -47,16 +47,19 @@ typedef int32_t  i32;
 //   [A, A + R*W)    one row of W bytes per context (order-0: R = 1; order-1: R = n, row of symbol s
 //                   at A + s*W).  A row holds, as u16, for cum[0..n] = cumulative starts
 //                   (cum[0] = 0, cum[n] = 1 << bits, cum[i > n] = 0xFFFF):
-//       3 levels (n <= 50):  root  : cum[10], cum[20], cum[30], cum[40]
-//                            node b: cum[10b+2], cum[10b+4], cum[10b+6], cum[10b+8]      (b = 0..4)
-//                            leaf  : cum[0 .. n+3]
+//       2 reads (n <= 50):   root  : cum[10], cum[20], cum[30], cum[40]                (8 bytes)
+//                            leaf  : cum[0 .. 10*((n-1)/10) + 11]  (the cum array itself, no copies)
+//                            After the root narrows the symbol to the ten of group b, ONE read of the
+//                            24 bytes cum[10b .. 10b+11] brings the whole group into registers and the
+//                            rest is register work (a packed compare of the even-ranked entries, two
+//                            select chains).  Rows are ~112 bytes for 46 symbols.
 //       4 levels (n <= 256): top   : cum[50], cum[100], .., cum[400]                  (8 separators)
 //                            mid a : cum[50a+10], .., cum[50a+40]                        (a = 0..5)
 //                            low ab: cum[50a+10b+2], .., cum[50a+10b+8]                 (30 nodes)
 //                            leaf  : cum[0 .. n+3]
 //
-// Lookup of slot m: at each inner level count the separators <= m (one 8-byte LDS read and four
-// compares), which narrows the symbol to a pair e, e+1; one more read of cum[e..e+2] settles it:
+// Lookup of slot m: at each inner level count the separators <= m (one 8-byte LDS read, compare-free
+// SWAR count), which narrows the symbol to a pair e, e+1; cum[e..e+2] settles it:
 // s = e + (m >= cum[e+1]), start = cum[s], freq = cum[s+1] - cum[s].  Symbols of zero frequency
 // have equal neighbours and are skipped by construction.
 //
@@ -66,10 +69,11 @@ typedef int32_t  i32;
 // decoder's throughput is made of (each stream is only four dependent chains wide).
 // ---------------------------------------------------------------------------------------------
 #define ROW_EMPTY 0x100u
-static inline __host__ __device__ u32 img_levels(u32 n) { return n <= 50 ? 3u : 4u; }
+static inline __host__ __device__ u32 img_levels(u32 n) { return n <= 50 ? 2u : 4u; }
 static inline __host__ __device__ u32 img_alpha_bytes(u32 n) { return (2u * n + 15u) & ~15u; }
-static inline __host__ __device__ u32 img_leaf_off(u32 lv) { return lv == 3 ? 48u : 304u; }
-static inline __host__ __device__ u32 img_row_bytes(u32 n) { return (img_leaf_off(img_levels(n)) + 2u * (n + 4u) + 7u) & ~7u; }
+static inline __host__ __device__ u32 img_leaf_off(u32 lv) { return lv == 2 ? 8u : 304u; }
+static inline __host__ __device__ u32 img_leaf_len(u32 n) { return img_levels(n) == 2 ? 10u * ((n - 1u) / 10u) + 12u : n + 4u; }   // u16 entries
+static inline __host__ __device__ u32 img_row_bytes(u32 n) { return (img_leaf_off(img_levels(n)) + 2u * img_leaf_len(n) + 7u) & ~7u; }
 static inline __host__ __device__ u32 img_bytes(u32 n, u32 rows) { return img_alpha_bytes(n) + rows * img_row_bytes(n); }
 #define IMG_O0_BYTES  1344u                       // 256 symbols, one row
 #define IMG_MAX_BYTES (512u + 256u * 824u)        // 256 symbols, 256 rows

@@ -44,20 +44,33 @@ __device__ __forceinline__ u32 lookup_step(const IMG &img, u32 row, u32 look, u3
 {
     const u32 m = x & mask;
     const u32 mm = m | (m << 16) | 0x80008000u;
-    u32 e;
+    u32 e, c0, c1, c2;
     if (LV == 4) {
         const u32 a = count_le(mm, img.ld64(row)) + count_le(mm, img.ld64(row + 8));
         const u32 b = count_le(mm, img.ld64(row + 16 + 8 * a));
         const u32 dd = count_le(mm, img.ld64(row + 64 + 8 * (5 * a + b)));
         e = 50 * a + 10 * b + 2 * dd;
+        const u32 lo = row + 304u + 2 * e;
+        const u32 c01 = img.ld32(lo), c23 = img.ld32(lo + 4);
+        c0 = c01 & 0xffffu; c1 = c01 >> 16; c2 = c23 & 0xffffu;
     } else {
+        // root, then the whole group of ten: dwords E_k = cum[10b+2k] | cum[10b+2k+1] << 16, k = 0..5
         const u32 b = count_le(mm, img.ld64(row));
-        const u32 dd = count_le(mm, img.ld64(row + 8 + 8 * b));
+        const u32 g = row + 8 + 20 * b;
+        const u32 E0 = img.ld32(g), E1 = img.ld32(g + 4), E2 = img.ld32(g + 8), E3 = img.ld32(g + 12),
+                  E4 = img.ld32(g + 16), E5 = img.ld32(g + 20);
+        // even-ranked entries 2,4,6,8 of the group are its inner separators
+        const u32 p01 = __builtin_amdgcn_perm(E2, E1, 0x05040100u);     // lo16(E1) | lo16(E2) << 16
+        const u32 p23 = __builtin_amdgcn_perm(E4, E3, 0x05040100u);
+        const u32 dd = __popc((mm - p01) & 0x80008000u) + __popc((mm - p23) & 0x80008000u);
+        u32 Ed = E0, En = E1;
+        if (dd >= 1) { Ed = E1; En = E2; }
+        if (dd >= 2) { Ed = E2; En = E3; }
+        if (dd >= 3) { Ed = E3; En = E4; }
+        if (dd >= 4) { Ed = E4; En = E5; }
         e = 10 * b + 2 * dd;
+        c0 = Ed & 0xffffu; c1 = Ed >> 16; c2 = En & 0xffffu;
     }
-    const u32 lo = row + (LV == 4 ? 304u : 48u) + 2 * e;
-    const u32 c01 = img.ld32(lo), c23 = img.ld32(lo + 4);
-    const u32 c0 = c01 & 0xffffu, c1 = c01 >> 16, c2 = c23 & 0xffffu;
     const bool up = m >= c1;
     const u32 start = up ? c1 : c0;
     const u32 next = up ? c2 : c1;
@@ -385,15 +398,11 @@ __device__ void write_row(u8 *rowp, const FrontShared &S, u32 n, bool empty, u32
     };
     auto N = [&](u32 r) -> u16 { const u16 v = C(r); return v > 0x7fffu ? (u16)0x7fffu : v; };   // node separator
     u16 *w = (u16 *)rowp;
-    if (lv == 3) {
-        // 4 root separators, 5 x 4 node separators
-        for (u32 t = lane; t < 24; t += WAVE) {
-            u16 v;
-            if (t < 4) v = N(10 * (t + 1));
-            else { const u32 b = (t - 4) >> 2, i = (t - 4) & 3; v = N(10 * b + 2 * (i + 1)); }
-            w[t] = v;
-        }
-        for (u32 t = lane; t < n + 4; t += WAVE) w[24 + t] = C(t);
+    if (lv == 2) {
+        // 4 root separators, then the cumulative array itself (sentinel-padded to whole groups)
+        if (lane < 4) w[lane] = N(10 * (lane + 1));
+        const u32 len = img_leaf_len(n);
+        for (u32 t = lane; t < len; t += WAVE) w[4 + t] = C(t);
     } else {
         for (u32 t = lane; t < 152; t += WAVE) {
             u16 v;
@@ -671,8 +680,8 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
         o0_front(src, H.tab_pos, H.csz, H.usz, nimg, S, lane);
         if (S.status != ST_OK) { if (lane == 0) D->status = S.status; return; }
         u8 *nring = nimg + IMG_O0_BYTES;
-        if (img_levels(S.nsym) == 3)
-            chain_decode_lds<0, 3>(nimg, S.nsym, nring, to_global(in + S.words_pos), H.tab_pos + H.csz - S.words_pos,
+        if (img_levels(S.nsym) == 2)
+            chain_decode_lds<0, 2>(nimg, S.nsym, nring, to_global(in + S.words_pos), H.tab_pos + H.csz - S.words_pos,
                                    to_global(tbuf), H.usz, S.R[lane & 3], O0_BITS, lane < 4, lane);
         else
             chain_decode_lds<0, 4>(nimg, S.nsym, nring, to_global(in + S.words_pos), H.tab_pos + H.csz - S.words_pos,
@@ -1017,26 +1026,27 @@ extern "C" void r4x16_launch_dec_front(const BatchArgs *a, const DecWs *ws, int 
     hipLaunchKernelGGL(k_dec_front, dim3(nblk), dim3(WAVE), 0, s, *a, *ws, base);
 }
 // LDS size classes: {bytes per stream (image + word ring), streams per wave, tree depth}.
-// Streams per CU = floor(160 KB / (qpw * bytes)) * qpw.  3-level images are at most 8.3 KB, 4-level
+// LDS is allocated in 1,280-byte granules; streams per CU = floor(160 KB / granules(qpw * bytes)) * qpw.
+// 2-read images are at most 6 KB, 4-level
 // images at least 21 KB (or the lone 1.3 KB row of a large order-0 alphabet), so the two groups of
 // classes are walked separately.
 static const struct { u32 bytes; int qpw; int lv; } DEC_CLASSES[] = {
-    {1024, 16, 3}, {2560, 16, 3}, {5120, 8, 3}, {7680, 4, 3}, {8960, 3, 3},
+    {640, 16, 2}, {1280, 16, 2}, {2560, 16, 2}, {3840, 10, 2}, {5440, 7, 2}, {6400, 6, 2},
     {22528, 1, 4}, {32768, 1, 4}, {53248, 1, 4}, {81920, 1, 4}, {163840, 1, 4},
 };
 extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t s)
 {
     static bool once = false;
     if (!once) {
-        (void)hipFuncSetAttribute((const void *)k_dec_chain<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void *)k_dec_chain<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         (void)hipFuncSetAttribute((const void *)k_dec_chain<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         once = true;
     }
     u32 lo3 = 0, lo4 = 0;                                  // each tree depth walks its own classes from 0
     for (const auto &c : DEC_CLASSES) {
         const int grid = (nitems + c.qpw - 1) / c.qpw;
-        if (c.lv == 3) {
-            hipLaunchKernelGGL((k_dec_chain<true, 3>), dim3(grid), dim3(WAVE), (size_t)c.qpw * c.bytes, s,
+        if (c.lv == 2) {
+            hipLaunchKernelGGL((k_dec_chain<true, 2>), dim3(grid), dim3(WAVE), (size_t)c.qpw * c.bytes, s,
                                ws->items, ws->desc, nitems, c.qpw, c.bytes, lo3, c.bytes);
             lo3 = c.bytes;
         } else {
@@ -1047,7 +1057,7 @@ extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t 
     }
     // images that fit no LDS class: tables stay in global memory (L2)
     const int grid = (nitems + 15) / 16;
-    hipLaunchKernelGGL((k_dec_chain<false, 3>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, nitems, 16, 0u, lo3, 0xffffffffu);
+    hipLaunchKernelGGL((k_dec_chain<false, 2>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, nitems, 16, 0u, lo3, 0xffffffffu);
     hipLaunchKernelGGL((k_dec_chain<false, 4>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, nitems, 16, 0u, lo4, 0xffffffffu);
 }
 extern "C" void r4x16_launch_dec_back(const BatchArgs *a, const DecWs *ws, int base, int nblk, hipStream_t s)
