@@ -115,22 +115,23 @@ struct DecDesc {
 
 // ---------------------------------------------------------------------------------------------
 // Encode image (per item), compact:
-//   [0,256)            u8 idx_of[256] : byte value -> compact symbol index (order-0: identity)
-//   [256, 256+4*R*ns)  u32 ent[R][ns] : entry of (context row r, symbol index s) at r*ns + s;
-//                      order-1: R = ns = size of the alphabet (byte 0 included, index 0);
-//                      order-0: R = 1, ns = 256.
-//   entry = bias[0:13) | cmpl_freq[13:26) | rcp_shift[26:31)        (rANS_word.h:190-266)
-//           x_max is (M - cmpl_freq) << (31 - bits); the reciprocal (rANS_word.h:252) depends only on
-//           the frequency M - cmpl_freq, so it lives in ONE 16 KB table rcptab[freq] shared by every
-//           stream (it stays L1-resident) instead of costing 4 more bytes per entry.
-// An order-1 image for a 46-symbol alphabet is 8.7 KB: eighteen streams' tables fit one CU's LDS.
+//   [0,256)                 u8  idx_of[256] : byte value -> compact symbol index (order-0: identity)
+//   [256, 256+2*R*(ns+1))   u16 cum[R][ns+1]: cumulative starts of context row r (cum[r][ns] = 1 << bits);
+//                           order-1: R = ns = size of the alphabet (byte 0 included, index 0);
+//                           order-0: R = 1, ns = 256.
+// Everything the coder needs for symbol s in context r follows from cum[r][s] and cum[r][s+1]:
+// start, freq, x_max = freq << (31 - bits), the reciprocal shift ceil(log2 freq) - 1, and the
+// reciprocal itself (rANS_word.h:252) from ONE 16 KB table rcptab[freq] shared by every stream (it
+// stays L1-resident).  None of that is on the dependent path (symbols are known in advance), so two
+// bytes per (context, symbol) are enough: a 46-symbol order-1 image is 4.6 KB and ~32 streams'
+// tables fit one CU's LDS, against 2 with the reference's 24-byte RansEncSymbol records.
 // ---------------------------------------------------------------------------------------------
 #define ENC_IMG_IDX    256u
-#define ENC_IMG_MAIN   (ENC_IMG_IDX + 4u * 256u * 256u)           // 262,400
-#define ENC_IMG_O0     (ENC_IMG_IDX + 4u * 256u)                  // 1,280
+#define ENC_IMG_MAIN   132096u                                    // 256 + 2*256*257, rounded to 256
+#define ENC_IMG_O0     1024u                                      // 256 + 2*257, rounded
 #define ENC_IMG_NESTED ENC_IMG_MAIN                               // offset of the nested-table image
 #define ENC_IMG_META   (ENC_IMG_NESTED + ENC_IMG_O0)              // offset of the RLE-meta image
-#define ENC_IMG_BYTES  (ENC_IMG_META + ENC_IMG_O0)                // 264,960 per block
+#define ENC_IMG_BYTES  (ENC_IMG_META + ENC_IMG_O0)                // 134,144 per block
 #define RCPTAB_ENTRIES 4097u
 
 struct EncItem {
@@ -143,7 +144,7 @@ struct EncItem {
     u32 active;
     u32 pay_len;     // OUT: bytes written backwards (states + words)
     u32 blk;
-    u32 ns;          // symbols per image row
+    u32 ns;          // symbols per image row (a row is ns+1 u16)
     u32 img_bytes;   // bytes of the image (what must sit in LDS)
     u32 pad[2];
 };

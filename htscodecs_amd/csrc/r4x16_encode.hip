@@ -80,25 +80,6 @@ __device__ int normalise_freq(u32 *F, u32 cnt, int size, u32 tot)
     }
 }
 
-// RansEncSymbolInit, rANS_word.h:190-266: bias, complement of the frequency and reciprocal shift
-// packed into one word; the reciprocal itself comes from rcptab[freq] (r4x16_common.h).
-__device__ __forceinline__ u32 make_entry(u32 start, u32 freq, u32 bits)
-{
-    const u32 M = 1u << bits;
-    const u32 cmpl = M - freq;
-    u32 bias, rsh;
-    if (freq < 2) {
-        rsh = 0;
-        bias = start + M - 1;
-    } else {
-        u32 shift = 0;
-        while (freq > (1u << shift)) shift++;
-        rsh = shift - 1;
-        bias = start;
-    }
-    return bias | (cmpl << 13) | (rsh << 26);
-}
-
 // ---------------------------------------------------------------------------------------------
 // The chain encoder.  lane&3 = chain, lane>>2 = stream.  Returns the number of bytes written
 // backwards from scratch_end (16 bytes of states + 2 per emitted word), same in all 4 lanes.
@@ -116,23 +97,26 @@ __device__ __forceinline__ u32 make_entry(u32 start, u32 freq, u32 bits)
 //                       context, and the first byte of each quarter is coded in context 0.
 // ---------------------------------------------------------------------------------------------
 
-// One coding step given the entry; returns the emit flag (for the caller's ballot).
-__device__ __forceinline__ bool enc_wants_emit(u32 x, u32 pk, u32 bits)
+// A prefetched symbol is two words: rcp = rcptab[freq] and sf = start | freq << 16.
+// RansEncPutSymbol (rANS_word.h:281-321) with RansEncSymbolInit's parameters (:190-266) derived on
+// the fly: x_max = freq << (31 - bits); q = (x * rcp) >> (32 + ceil(log2 freq) - 1) is the exact
+// quotient x / freq for freq >= 2 (Alverson), and freq == 1 takes q = x; then
+// x' = x + start + q * (M - freq)  ==  ((x / freq) << bits) + x % freq + start.
+__device__ __forceinline__ bool enc_wants_emit(u32 x, u32 sf, u32 bits)
 {
-    const u32 cmpl = (pk >> 13) & 0x1fffu;
-    const u32 x_max = ((1u << bits) - cmpl) << (31 - bits);
-    return x >= x_max;
+    return x >= ((sf >> 16) << (31 - bits));
 }
-__device__ __forceinline__ u32 enc_rcp(gcu32 *rcptab, u32 pk, u32 bits)
+__device__ __forceinline__ u32 enc_rcp(gcu32 *rcptab, u32 f)
 {
-    // lanes without a live stream may hold garbage in pk: keep the index inside the table
-    const u32 f = (1u << bits) - ((pk >> 13) & 0x1fffu);
-    return rcptab[f < RCPTAB_ENTRIES ? f : 0u];
+    return rcptab[f < RCPTAB_ENTRIES ? f : 0u];          // idle lanes may hold garbage: stay inside the table
 }
-__device__ __forceinline__ u32 enc_advance(u32 x, u32 rcp, u32 pk)
+__device__ __forceinline__ u32 enc_advance(u32 x, u32 rcp, u32 sf, u32 bits)
 {
-    const u32 qq = __umulhi(x, rcp) >> (pk >> 26);
-    return x + (pk & 0x1fffu) + qq * ((pk >> 13) & 0x1fffu);
+    const u32 f = sf >> 16, start = sf & 0xffffu;
+    const u32 rsh = 31u - (u32)__clz((int)(f - 1u));     // ceil(log2 f) - 1 for f >= 2
+    u32 q = __umulhi(x, rcp) >> (rsh & 31u);
+    q = f < 2u ? x : q;
+    return x + start + q * ((1u << bits) - f);
 }
 
 // General form: image in global memory, byte loads.  Used for the small nested streams inside
@@ -142,7 +126,8 @@ __device__ __forceinline__ u32 chain_encode(gcu8 *data, u32 n, gcu8 *image, u32 
                                             gu8 *scratch_end, bool active, u32 lane)
 {
     const u32 k = lane & 3;
-    gcu32 *ent = (gcu32 *)(image + ENC_IMG_IDX);
+    GAS const u16 *cum = (GAS const u16 *)(image + ENC_IMG_IDX);
+    const u32 rs = ns + 1;
     u32 x = RANS_LOW;
     u32 written = 0;                 // words emitted by the quad so far
     u32 nsteps, first;               // this lane takes part in steps [first, nsteps)
@@ -176,8 +161,9 @@ __device__ __forceinline__ u32 chain_encode(gcu8 *data, u32 n, gcu8 *image, u32 
                 nextc = image[data[p - 1]];
                 row = nextc;
             }
-            pk = ent[row * ns + cur];
-            rcp = enc_rcp(rcptab, pk, bits);
+            const u32 c0 = cum[row * rs + cur], c1 = cum[row * rs + cur + 1];
+            pk = c0 | ((c1 - c0) << 16);
+            rcp = enc_rcp(rcptab, c1 - c0);
             emit = enc_wants_emit(x, pk, bits);
         }
         const u32 em = quad_ballot(emit, lane);
@@ -188,7 +174,7 @@ __device__ __forceinline__ u32 chain_encode(gcu8 *data, u32 n, gcu8 *image, u32 
         }
         written += __popc(em);
         if (live) {
-            x = enc_advance(x, rcp, pk);
+            x = enc_advance(x, rcp, pk, bits);
             cur = nextc;
             p -= (ORDER == 0) ? 4 : 1;
         }
@@ -214,10 +200,12 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, gcu8 *data
     const u32 k = lane & 3;
     const u32 mybit = 1u << k;
     const u8 *idx = img_lds;
-    const u32 *ent = (const u32 *)(img_lds + ENC_IMG_IDX);
-    auto fetch = [&](u32 i) -> u32x2 {                    // {rcp, pk} of entry i
-        const u32 pk = ent[i];
-        u32x2 r = {enc_rcp(rcptab, pk, bits), pk};
+    const u16 *cum = (const u16 *)(img_lds + ENC_IMG_IDX);
+    const u32 rs = ns + 1;                                // u16 per context row
+    auto fetch = [&](u32 ci, u32 si) -> u32x2 {           // {rcp, start | freq << 16} of symbol si in context ci
+        const u32 i = ci * rs + si;
+        const u32 c0 = cum[i], c1 = cum[i + 1];
+        u32x2 r = {enc_rcp(rcptab, c1 - c0), c0 | ((c1 - c0) << 16)};
         return r;
     };
     u32 x = RANS_LOW, written = 0;
@@ -233,7 +221,7 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, gcu8 *data
             x >>= 16;
         }
         written += __popc(em);
-        const u32 xn = enc_advance(x, rcp, pk);
+        const u32 xn = enc_advance(x, rcp, pk, bits);
         x = live ? xn : x;
     };
 
@@ -245,7 +233,7 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, gcu8 *data
         u32 rcp = 0, pk = 0;
         if (live) {
             const u32 ci = idx[data[n - 2 - s]];
-            const u32x2 e = fetch(ci * ns + cur);
+            const u32x2 e = fetch(ci, cur);
             rcp = e.x; pk = e.y;
             cur = ci;
         }
@@ -271,7 +259,7 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, gcu8 *data
         u32 c0, c1, c2, c3;
         auto lookup = [&](u32 ww, u32 sym, u32x2 &e0, u32x2 &e1, u32x2 &e2, u32x2 &e3, u32 &last) {
             c0 = idx[ww >> 24]; c1 = idx[(ww >> 16) & 0xff]; c2 = idx[(ww >> 8) & 0xff]; c3 = idx[ww & 0xff];
-            e0 = fetch(c0 * ns + sym); e1 = fetch(c1 * ns + c0); e2 = fetch(c2 * ns + c1); e3 = fetch(c3 * ns + c2);
+            e0 = fetch(c0, sym); e1 = fetch(c1, c0); e2 = fetch(c2, c1); e3 = fetch(c3, c2);
             last = c3;
         };
         u32 nxt_cur = 0;
@@ -300,7 +288,7 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, gcu8 *data
         u32 rcp = 0, pk = 0;
         if (live) {
             const u32 ci = idx[qbase[r - 1]];
-            const u32x2 e = fetch(ci * ns + cur);
+            const u32x2 e = fetch(ci, cur);
             rcp = e.x; pk = e.y;
             cur = ci; r--; done++;
         }
@@ -310,7 +298,7 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, gcu8 *data
     {
         const bool live = active && q > 0;
         u32 rcp = 0, pk = 0;
-        if (live) { const u32x2 e = fetch(cur); rcp = e.x; pk = e.y; }
+        if (live) { const u32x2 e = fetch(0, cur); rcp = e.x; pk = e.y; }
         step(live, rcp, pk);
     }
     if (active) *(gu32 *)(scratch_end - 2 * written - 16 + 4 * k) = x;
@@ -325,7 +313,7 @@ __device__ __forceinline__ u32 chain_encode_o0_lds(const u8 *img_lds, DP data, u
     const u32 k = lane & 3;
     const u32 mybit = 1u << k;
     const u8 *idx = img_lds;
-    const u32 *ent = (const u32 *)(img_lds + ENC_IMG_IDX);
+    const u16 *cum = (const u16 *)(img_lds + ENC_IMG_IDX);
     u32 x = RANS_LOW, written = 0;
     const u32 gtop = (active && n) ? (n - 1) >> 2 : 0;
     u32 nsteps = (active && n) ? gtop + 1 : 0;
@@ -334,8 +322,9 @@ __device__ __forceinline__ u32 chain_encode_o0_lds(const u8 *img_lds, DP data, u
     u32 byte = (nsteps > first) ? data[p] : 0u;
     for (u32 s = 0; wave_any(s < nsteps); s++) {
         const bool live = s >= first && s < nsteps;
-        const u32 pk0 = ent[idx[byte]];
-        const u32x2 e = {enc_rcp(rcptab, pk0, bits), pk0};
+        const u32 si = idx[byte];
+        const u32 c0 = cum[si], c1 = cum[si + 1];
+        const u32x2 e = {enc_rcp(rcptab, c1 - c0), c0 | ((c1 - c0) << 16)};
         const u32 nb = (live && p >= 4) ? data[p - 4] : 0u;          // next group's byte, a step ahead
         const bool emit = live && enc_wants_emit(x, e.y, bits);
         const u32 em = quad_mask_dpp(emit, mybit);
@@ -345,7 +334,7 @@ __device__ __forceinline__ u32 chain_encode_o0_lds(const u8 *img_lds, DP data, u
             x >>= 16;
         }
         written += __popc(em);
-        const u32 xn = enc_advance(x, e.x, e.y);
+        const u32 xn = enc_advance(x, e.x, e.y, bits);
         if (live) { x = xn; byte = nb; p -= 4; }
     }
     if (active) *(gu32 *)(scratch_end - 2 * written - 16 + 4 * k) = x;
@@ -422,7 +411,7 @@ __device__ u32 put_alphabet(u8 *cp, const u8 *present)
 // enc_o0_tables expects the byte histogram of the data in S.F.
 __device__ void enc_o0_tables(u32 n, u8 *tab, u8 *image, EncShared &S, u32 lane)
 {
-    u32 *imgrow = (u32 *)(image + ENC_IMG_IDX);
+    u16 *imgrow = (u16 *)(image + ENC_IMG_IDX);      // cum[0..256]
     for (u32 j = lane; j < 256; j += WAVE) image[j] = (u8)j;       // order-0: symbols index the row directly
     if (lane == 0) {
         u32 target = pow2_ceil(n);
@@ -445,9 +434,10 @@ __device__ void enc_o0_tables(u32 n, u8 *tab, u8 *image, EncShared &S, u32 lane)
     u32 start = wave_incl_scan(sum, lane) - sum;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-        if (f[c]) imgrow[lane * 4 + c] = make_entry(start, f[c], O0_BITS);
+        imgrow[lane * 4 + c] = (u16)start;
         start += f[c];
     }
+    if (lane == WAVE - 1) imgrow[256] = (u16)start;
     wsync();
 }
 
@@ -775,7 +765,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
                     D->rle_meta = (u64)m; D->meta_tab = (u64)mtab; D->meta_tab_len = S.tab_len;
                     if (S.status != ST_OK) D->status = S.status;
                     I1->data = (u64)m; I1->n = mlen; I1->image = (u64)imgm; I1->bits = O0_BITS; I1->order = 0;
-                    I1->ns = 256; I1->img_bytes = ENC_IMG_O0;
+                    I1->ns = 256; I1->img_bytes = ENC_IMG_IDX + 2u * 257u;
                     I1->scratch_end = (u64)(ws.scratch2 + (u64)b * ws.scratch2_stride + ws.scratch2_stride);
                     __threadfence();
                     I1->active = S.status == ST_OK;
@@ -849,7 +839,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
 // ---------------------------------------------------------------------------------------------
 #define TABLES_DYN_LDS 10240u          // pair counters of alphabets up to 50 symbols; later the nested coder
 #define TABLES_LDS_NSYM 50u
-#define TABLES_NEST_MAX 8704u          // nested table bytes that fit next to a 1,280-byte image + slack
+#define TABLES_NEST_MAX 9216u          // nested table bytes that fit next to a 1,024-byte image
 
 __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int base)
 {
@@ -879,7 +869,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
             D->status = S.status;
             D->tab_len = S.tab_len;
             I0->data = (u64)data; I0->n = n; I0->image = (u64)img; I0->bits = O0_BITS; I0->order = 0;
-            I0->ns = 256; I0->img_bytes = ENC_IMG_O0;
+            I0->ns = 256; I0->img_bytes = ENC_IMG_IDX + 2u * 257u;
             I0->scratch_end = (u64)scratch_end;
             __threadfence();
             I0->active = S.status == ST_OK;
@@ -1000,7 +990,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
 
     // ---- encoder image: scale each row up to 1<<bits (:756) and build entries (:759-762) -----------
     for (u32 j = lane; j < 256; j += WAVE) img[j] = S.present[j] ? S.idx_of[j] : (u8)0;
-    u32 *ent = (u32 *)(img + ENC_IMG_IDX);
+    u16 *cumimg = (u16 *)(img + ENC_IMG_IDX);            // cum[r][0..ns]
     for (u32 r = 0; r < ns; r++) {
         u32 sh = 0;
         const u32 tgt = (u32)S.S[r];
@@ -1010,9 +1000,10 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
             const u32 j = jb + lane;
             const u32 f = (j < ns) ? (Fp[r * ns + j] << sh) : 0u;
             const u32 incl = wave_incl_scan(f, lane);
-            if (f) ent[r * ns + j] = make_entry(carry + incl - f, f, bits);
+            if (j < ns) cumimg[r * (ns + 1) + j] = (u16)(carry + incl - f);
             carry += __shfl(incl, WAVE - 1);
         }
+        if (lane == 0) cumimg[r * (ns + 1) + ns] = (u16)carry;
     }
     __threadfence();
     wsync();
@@ -1074,7 +1065,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
     if (lane == 0) {
         D->tab_len = final_len;
         I0->data = (u64)data; I0->n = n; I0->image = (u64)img; I0->bits = bits; I0->order = 1;
-        I0->ns = ns; I0->img_bytes = ENC_IMG_IDX + 4u * ns * ns;
+        I0->ns = ns; I0->img_bytes = ENC_IMG_IDX + 2u * ns * (ns + 1);
         I0->scratch_end = (u64)scratch_end;
         __threadfence();
         I0->active = 1;
@@ -1209,9 +1200,10 @@ extern "C" void r4x16_launch_enc_front(const BatchArgs *a, const EncWs *ws, int 
     }
     hipLaunchKernelGGL(k_enc_front, dim3(nblk), dim3(FRONT_THREADS), FRONT_DYN_LDS, s, *a, *ws, base);
 }
-// {LDS bytes per stream, streams per wave}: q4/q8 images are ~0.5 KB, an order-0 row 1.3 KB, q40 8.7 KB
+// {LDS bytes per stream, streams per wave}; LDS is allocated in 1,280-byte granules.
+// q4/q8 images are ~0.4 KB, an order-0 row 0.8 KB, q40 4.6 KB (4 x 4,800 = 15 granules: 8 waves, 32 streams per CU)
 static const struct { u32 bytes; int qpw; } ENC_CLASSES[] = {
-    {1536, 16}, {2560, 16}, {5120, 8}, {8960, 2}, {20480, 1}, {40960, 1}, {81920, 1}, {163840, 1},
+    {640, 16}, {1280, 16}, {2560, 16}, {4800, 4}, {6400, 4}, {12800, 2}, {33280, 1}, {81920, 1}, {163840, 1},
 };
 extern "C" void r4x16_launch_enc_tables(const BatchArgs *a, const EncWs *ws, int base, int nblk, hipStream_t s)
 {
