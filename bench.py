@@ -104,8 +104,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    # 9216 = 2 full rounds of the encoder's 4608 resident streams (18 per CU) and 1.8 of the decoder's 5120
-    ap.add_argument("--blocks", type=int, default=int(os.environ.get("R4X16_BLOCKS", 9216)))
+    # 14336 = 2 full rounds of the decoder's 7168 resident streams (28 per CU), 1.75 of the encoder's 8192
+    ap.add_argument("--blocks", type=int, default=int(os.environ.get("R4X16_BLOCKS", 14336)))
     ap.add_argument("--block-size", type=int, default=1 << 20)
     ap.add_argument("--data", default="q40+dir")
     ap.add_argument("--order", type=int, default=1)

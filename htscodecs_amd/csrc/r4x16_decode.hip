@@ -10,6 +10,7 @@
 //                 Replaces the loops at :574-607 and :1027-1114.
 //   k_dec_back  : one wave per block.  RLE expansion, bit-unpacking, CAT copies, final size
 //                 and status.  Replaces :1578-1629, rle.c:142-187, pack.c:211-348.
+#include <stdlib.h>
 #include <type_traits>
 #include "r4x16_dev.h"
 
@@ -1031,7 +1032,7 @@ extern "C" void r4x16_launch_dec_front(const BatchArgs *a, const DecWs *ws, int 
 // images at least 21 KB (or the lone 1.3 KB row of a large order-0 alphabet), so the two groups of
 // classes are walked separately.
 static const struct { u32 bytes; int qpw; int lv; } DEC_CLASSES[] = {
-    {640, 16, 2}, {1280, 16, 2}, {2560, 16, 2}, {3840, 10, 2}, {5440, 7, 2}, {6400, 6, 2},
+    {640, 16, 2}, {1280, 16, 2}, {2560, 16, 2}, {3840, 16, 2}, {5440, 14, 2}, {6400, 12, 2},
     {22528, 1, 4}, {32768, 1, 4}, {53248, 1, 4}, {81920, 1, 4}, {163840, 1, 4},
 };
 extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t s)
@@ -1043,11 +1044,13 @@ extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t 
         once = true;
     }
     u32 lo3 = 0, lo4 = 0;                                  // each tree depth walks its own classes from 0
+    static const int force_qpw = getenv("R4X16_DEC_QPW") ? atoi(getenv("R4X16_DEC_QPW")) : 0;   // tuning aid
     for (const auto &c : DEC_CLASSES) {
-        const int grid = (nitems + c.qpw - 1) / c.qpw;
+        const int qpw = (force_qpw && c.bytes == 5440) ? force_qpw : c.qpw;
+        const int grid = (nitems + qpw - 1) / qpw;
         if (c.lv == 2) {
-            hipLaunchKernelGGL((k_dec_chain<true, 2>), dim3(grid), dim3(WAVE), (size_t)c.qpw * c.bytes, s,
-                               ws->items, ws->desc, nitems, c.qpw, c.bytes, lo3, c.bytes);
+            hipLaunchKernelGGL((k_dec_chain<true, 2>), dim3(grid), dim3(WAVE), (size_t)qpw * c.bytes, s,
+                               ws->items, ws->desc, nitems, qpw, c.bytes, lo3, c.bytes);
             lo3 = c.bytes;
         } else {
             hipLaunchKernelGGL((k_dec_chain<true, 4>), dim3(grid), dim3(WAVE), (size_t)c.qpw * c.bytes, s,

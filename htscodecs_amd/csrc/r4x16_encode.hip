@@ -11,6 +11,7 @@
 //                  ballot prefix inside the quad.
 //   k_enc_finish : one wave per block.  Chooses CAT fall-back (:1332-1337), assembles
 //                  header + table + payload into the caller's slot, writes size and status.
+#include <stdlib.h>
 #include "r4x16_dev.h"
 
 #define FRONT_DYN_LDS  61440u                           // LDS counters: alphabets up to 123 symbols
@@ -1201,9 +1202,9 @@ extern "C" void r4x16_launch_enc_front(const BatchArgs *a, const EncWs *ws, int 
     hipLaunchKernelGGL(k_enc_front, dim3(nblk), dim3(FRONT_THREADS), FRONT_DYN_LDS, s, *a, *ws, base);
 }
 // {LDS bytes per stream, streams per wave}; LDS is allocated in 1,280-byte granules.
-// q4/q8 images are ~0.4 KB, an order-0 row 0.8 KB, q40 4.6 KB (4 x 4,800 = 15 granules: 8 waves, 32 streams per CU)
+// q4/q8 images are ~0.4 KB, an order-0 row 0.8 KB, q40 4.6 KB (16 x 4,800 = 60 granules: 2 waves, 32 streams per CU — fuller waves measured faster than more waves)
 static const struct { u32 bytes; int qpw; } ENC_CLASSES[] = {
-    {640, 16}, {1280, 16}, {2560, 16}, {4800, 4}, {6400, 4}, {12800, 2}, {33280, 1}, {81920, 1}, {163840, 1},
+    {640, 16}, {1280, 16}, {2560, 16}, {4800, 16}, {6400, 12}, {12800, 6}, {33280, 2}, {81920, 1}, {163840, 1},
 };
 extern "C" void r4x16_launch_enc_tables(const BatchArgs *a, const EncWs *ws, int base, int nblk, hipStream_t s)
 {
@@ -1217,10 +1218,12 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
         once = true;
     }
     u32 lo = 0;
+    static const int force_qpw = getenv("R4X16_ENC_QPW") ? atoi(getenv("R4X16_ENC_QPW")) : 0;   // tuning aid
     for (const auto &c : ENC_CLASSES) {
-        const int grid = (nitems + c.qpw - 1) / c.qpw;
-        hipLaunchKernelGGL(k_enc_chain<true>, dim3(grid), dim3(WAVE), (size_t)c.qpw * c.bytes, s,
-                           ws->items, ws->rcptab, nitems, c.qpw, c.bytes, lo, c.bytes);
+        const int qpw = (force_qpw && c.bytes == 4800) ? force_qpw : c.qpw;
+        const int grid = (nitems + qpw - 1) / qpw;
+        hipLaunchKernelGGL(k_enc_chain<true>, dim3(grid), dim3(WAVE), (size_t)qpw * c.bytes, s,
+                           ws->items, ws->rcptab, nitems, qpw, c.bytes, lo, c.bytes);
         lo = c.bytes;
     }
     const int grid = (nitems + 15) / 16;
