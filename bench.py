@@ -211,7 +211,7 @@ def main():
                 pmc = json.load(f)
             w = pmc["workload"]
             if (w["blocks"], w["block_size"], w["data"], w["order"]) == (nblk, bs, args.data, order):
-                key = "k_dec_chain<true, 3>" if kname == "k_dec_chain" else "k_enc_chain<true>"
+                key = "k_dec_chain<true, 2>" if kname == "k_dec_chain" else "k_enc_chain<true>"
                 traffic = pmc["kernels"][key]["traffic_bytes"]
         except (OSError, KeyError, ValueError):
             pass
