@@ -72,8 +72,22 @@ typedef int32_t  i32;
 static inline __host__ __device__ u32 img_levels(u32 n) { return n <= 50 ? 2u : 4u; }
 static inline __host__ __device__ u32 img_alpha_bytes(u32 n) { return (2u * n + 15u) & ~15u; }
 static inline __host__ __device__ u32 img_leaf_off(u32 lv) { return lv == 2 ? 8u : 304u; }
-static inline __host__ __device__ u32 img_leaf_len(u32 n) { return img_levels(n) == 2 ? 10u * ((n - 1u) / 10u) + 12u : n + 4u; }   // u16 entries
-static inline __host__ __device__ u32 img_row_bytes(u32 n) { return (img_leaf_off(img_levels(n)) + 2u * img_leaf_len(n) + 7u) & ~7u; }
+// u16 entries of the cumulative array.  Two levels: group b is read as the six dwords cum[10b .. 10b+11];
+// the last dword of the LAST group is only ever looked at when n is a multiple of ten (otherwise no
+// symbol of rank 10b+9 exists), so it is left out then and that read runs into whatever follows
+// the row (the next row, or the word ring) — 4 bytes per row that decide whether 14 or 16 streams
+// of a 45-symbol alphabet fit a wave's share of LDS.
+static inline __host__ __device__ u32 img_leaf_len(u32 n)
+{
+    if (img_levels(n) != 2) return n + 4u;
+    const u32 q = (n - 1u) / 10u;
+    return n % 10u == 0 ? 10u * q + 12u : 10u * q + 10u;
+}
+// rows are 4-byte aligned (two levels) or 8-byte aligned (four levels)
+static inline __host__ __device__ u32 img_row_bytes(u32 n)
+{
+    return img_levels(n) == 2 ? 8u + 2u * img_leaf_len(n) : (304u + 2u * img_leaf_len(n) + 7u) & ~7u;
+}
 static inline __host__ __device__ u32 img_bytes(u32 n, u32 rows) { return img_alpha_bytes(n) + rows * img_row_bytes(n); }
 #define IMG_O0_BYTES  1344u                       // 256 symbols, one row
 #define IMG_MAX_BYTES (512u + 256u * 824u)        // 256 symbols, 256 rows

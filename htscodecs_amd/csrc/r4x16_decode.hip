@@ -19,13 +19,13 @@ struct GImg {
     gcu8 *p;
     __device__ __forceinline__ u32 ld16(u32 off) const { return *(GAS const u16 *)(p + off); }
     __device__ __forceinline__ u32 ld32(u32 off) const { return *(gcu32 *)(p + off); }
-    __device__ __forceinline__ u32x2 ld64(u32 off) const { return *(GAS const u32x2 *)(p + off); }
+    __device__ __forceinline__ u32x2 ld64(u32 off) const { return *(GAS const u32x2_a4 *)(p + off); }
 };
 struct LImg {
     const u8 *p;     // points into __shared__
     __device__ __forceinline__ u32 ld16(u32 off) const { return *(const u16 *)(p + off); }
     __device__ __forceinline__ u32 ld32(u32 off) const { return *(const u32 *)(p + off); }
-    __device__ __forceinline__ u32x2 ld64(u32 off) const { return *(const u32x2 *)(p + off); }
+    __device__ __forceinline__ u32x2 ld64(u32 off) const { return *(const u32x2_a4 *)(p + off); }
 };
 
 // number of the four u16 separators in v that are <= m, without compares: separators are stored
@@ -41,7 +41,8 @@ __device__ __forceinline__ u32 count_le(u32 mmh /* (m | m << 16) | 0x80008000 */
 // described in r4x16_common.h.  `row` is the byte offset of the context's row in the image.
 // Returns the compact symbol index; x becomes freq * (x >> look) + m - start.
 template <int LV, class IMG>
-__device__ __forceinline__ u32 lookup_step(const IMG &img, u32 row, u32 look, u32 mask, u32 &x)
+__device__ __forceinline__ u32 lookup_step(const IMG &img, u32 row, u32 look, u32 mask, u32 &x,
+                                           const u32x2 *root = nullptr /* LV 2: img.ld64(row), read ahead */)
 {
     const u32 m = x & mask;
     const u32 mm = m | (m << 16) | 0x80008000u;
@@ -56,7 +57,7 @@ __device__ __forceinline__ u32 lookup_step(const IMG &img, u32 row, u32 look, u3
         c0 = c01 & 0xffffu; c1 = c01 >> 16; c2 = c23 & 0xffffu;
     } else {
         // root, then the whole group of ten: dwords E_k = cum[10b+2k] | cum[10b+2k+1] << 16, k = 0..5
-        const u32 b = count_le(mm, img.ld64(row));
+        const u32 b = count_le(mm, root ? *root : img.ld64(row));
         const u32 g = row + 8 + 20 * b;
         const u32 E0 = img.ld32(g), E1 = img.ld32(g + 4), E2 = img.ld32(g + 8), E3 = img.ld32(g + 12),
                   E4 = img.ld32(g + 16), E5 = img.ld32(g + 20);
@@ -203,6 +204,9 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     __syncthreads();
 
     u32 row = rows, cursor = 0, bad = 0, t = 0;
+    // root separators of `row`, read as soon as the row is known (one step ahead of their use,
+    // so that this LDS round trip runs beside the renormalisation instead of after it)
+    u32x2 root = img.ld64(row);
     u32 acc = 0;                                          // order-1: the last (up to) 4 decoded bytes
     u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;                   // order-1: completed dwords not yet stored (a3 newest)
     u32 hdr = 0;                                          // order-1: alpha[] word of the symbol decoded last step
@@ -227,7 +231,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             const u32 sh = (cb & 3u) * 8u;
 
             u32 xn = x;
-            const u32 s = lookup_step<LV>(img, row, look, mask, xn);
+            const u32 s = lookup_step<LV>(img, row, look, mask, xn, LV == 2 ? &root : nullptr);
             const u32 hn = img.ld16(2 * s);               // byte value | ROW_EMPTY of the new context
             u32 byte0 = 0;
             if (ORDER == 0) {
@@ -252,6 +256,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
                 const u32 rown = rows + __umul24(s, roww);
                 hdr = live ? hn : hdr;
                 row = live ? rown : row;
+                if (LV == 2) root = img.ld64(row);
             }
             x = live ? xn : x;
             const bool want = live && x < RANS_LOW;
@@ -265,8 +270,9 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             const u32 wlo = __builtin_amdgcn_alignbit(d1, d0, sh), whi = __builtin_amdgcn_alignbit(d2, d1, sh);
             const u32 w2 = (pre & 2u) ? whi : wlo;
             const u32 w = (w2 >> ((pre & 1u) * 16u)) & 0xffffu;
-            const u32 xr = (x << 16) | w;
-            x = __builtin_unpredictable(take) ? xr : x;
+            u32 xr = (x << 16) | w;
+            asm volatile("" : "+v"(xr));                  // keeps the refill arithmetic out of a branch
+            x = take ? xr : x;
             cursor += __popc(wm);
 
             if (ORDER == 0) {
@@ -1032,7 +1038,7 @@ extern "C" void r4x16_launch_dec_front(const BatchArgs *a, const DecWs *ws, int 
 // images at least 21 KB (or the lone 1.3 KB row of a large order-0 alphabet), so the two groups of
 // classes are walked separately.
 static const struct { u32 bytes; int qpw; int lv; } DEC_CLASSES[] = {
-    {640, 16, 2}, {1280, 16, 2}, {2560, 16, 2}, {3840, 16, 2}, {5440, 14, 2}, {6400, 12, 2},
+    {640, 16, 2}, {1280, 16, 2}, {2560, 16, 2}, {3840, 16, 2}, {5120, 16, 2}, {5440, 15, 2}, {6400, 12, 2},
     {22528, 1, 4}, {32768, 1, 4}, {53248, 1, 4}, {81920, 1, 4}, {163840, 1, 4},
 };
 extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t s)
@@ -1046,7 +1052,7 @@ extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t 
     u32 lo3 = 0, lo4 = 0;                                  // each tree depth walks its own classes from 0
     static const int force_qpw = getenv("R4X16_DEC_QPW") ? atoi(getenv("R4X16_DEC_QPW")) : 0;   // tuning aid
     for (const auto &c : DEC_CLASSES) {
-        const int qpw = (force_qpw && c.bytes == 5440) ? force_qpw : c.qpw;
+        const int qpw = (force_qpw && c.bytes == 5120) ? force_qpw : c.qpw;
         const int grid = (nitems + qpw - 1) / qpw;
         if (c.lv == 2) {
             hipLaunchKernelGGL((k_dec_chain<true, 2>), dim3(grid), dim3(WAVE), (size_t)qpw * c.bytes, s,

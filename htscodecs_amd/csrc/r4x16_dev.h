@@ -17,6 +17,7 @@ typedef GAS u32       gu32;
 typedef GAS const u32 gcu32;
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef u32 u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));   // two dwords at a 4-byte aligned address
 typedef GAS const u32x4 gcu32x4;
 typedef u32 __attribute__((aligned(1))) u32_unaligned;
 typedef u32 u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));

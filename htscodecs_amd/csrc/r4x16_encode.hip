@@ -195,36 +195,81 @@ __device__ __forceinline__ u32 chain_encode(gcu8 *data, u32 n, gcu8 *image, u32 
 // the backward walk; (B') its last 0..3 steps; (C) the quarter starts in context 0.  Streams of
 // different lengths in one wave simply drop out of (B) at different trips.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, gcu8 *data, u32 n, u32 ns, u32 bits,
+// Emitted 16-bit words are staged in a 128-byte LDS ring per stream and copied out 64 bytes at a
+// time (16 bytes per lane): the hot loop issues no global store, so the only vector-memory
+// operations in flight are prefetches whose results are not needed for a whole trip.
+// Word j of a stream (emission order) belongs at scratch_end - 2 (j + 1); in the ring it sits
+// at byte 126 - 2 (j & 63), which keeps each 64-byte half in memory order.
+#define ENC_RING_BYTES 144u          // ring + a 2-byte dump slot for lanes that do not emit (+ pad)
+struct EncOut {
+    u8 *ring;            // LDS
+    gu8 *send;           // scratch_end of the stream
+    u32 written;         // words emitted by the quad so far
+    u32 flushed;         // 64-byte halves already copied out
+    u32 k, mybit;
+    bool active;
+    // rANS_word.h:281-321 for one symbol {rcp, start | freq << 16}; x is this lane's state
+    __device__ __forceinline__ void step(u32 &x, bool live, u32 rcp, u32 pk, u32 bits)
+    {
+        const bool emit = live && enc_wants_emit(x, pk, bits);
+        const u32 em = quad_mask_dpp(emit, mybit);
+        const u32 j = written + __popc(em >> (k + 1));
+        const u32 slot = emit ? 126u - 2u * (j & 63u) : 128u;
+        *(u16 *)(ring + slot) = (u16)x;
+        const u32 xs = emit ? x >> 16 : x;
+        written += __popc(em);
+        const u32 xn = enc_advance(xs, rcp, pk, bits);
+        x = live ? xn : xs;
+    }
+    // copy out the half that has just been completed, if any (at most one per four steps)
+    __device__ __forceinline__ void flush()
+    {
+        const bool due = active && (written >> 5) != flushed;
+        if (wave_any(due)) {
+            if (due) {
+                const u32x4 v = *(const u32x4 *)(ring + ((flushed & 1u) ? 0u : 64u) + 16u * k);
+                *(GAS u32x4_unaligned *)(send - 64ull * (flushed + 1u) + 16u * k) = v;
+                flushed++;
+            }
+        }
+    }
+    // the words still in the ring, then the four states (RansEncFlush in order 3,2,1,0, :482-485)
+    __device__ __forceinline__ u32 finish(u32 x)
+    {
+        flush();
+        const u32 first = 32u * flushed;
+        const u32 rem = active ? written - first : 0u;
+        for (u32 i = k; wave_any(i < rem); i += 4) {
+            if (i < rem) {
+                const u32 j = first + i;
+                *(gu16 *)(send - 2ull * (j + 1u)) = *(const u16 *)(ring + 126u - 2u * (j & 63u));
+            }
+        }
+        if (active) *(gu32 *)(send - 2ull * written - 16 + 4 * k) = x;
+        return active ? 2 * written + 16 : 0;
+    }
+};
+
+__device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, u8 *ring, gcu8 *data, u32 n, u32 ns, u32 bits,
                                                    gcu32 *rcptab, gu8 *scratch_end, bool active, u32 lane)
 {
     const u32 k = lane & 3;
-    const u32 mybit = 1u << k;
     const u8 *idx = img_lds;
-    const u16 *cum = (const u16 *)(img_lds + ENC_IMG_IDX);
+    const u8 *cumb = img_lds + ENC_IMG_IDX;
+    const u16 *cum = (const u16 *)cumb;
     const u32 rs = ns + 1;                                // u16 per context row
-    auto fetch = [&](u32 ci, u32 si) -> u32x2 {           // {rcp, start | freq << 16} of symbol si in context ci
-        const u32 i = ci * rs + si;
-        const u32 c0 = cum[i], c1 = cum[i + 1];
-        u32x2 r = {enc_rcp(rcptab, c1 - c0), c0 | ((c1 - c0) << 16)};
+    // start | next << 16 of symbol si in context ci: one dword read at a 2-byte aligned LDS address
+    auto pair = [&](u32 ci, u32 si) -> u32 { return *(LAS const u32 *)(cumb + 2u * (ci * rs + si)); };
+    auto fetch = [&](u32 ci, u32 si) -> u32x2 {           // {rcp, start | freq << 16}
+        const u32 p = pair(ci, si);
+        const u32 pk = p - (p << 16);
+        u32x2 r = {enc_rcp(rcptab, pk >> 16), pk};
         return r;
     };
-    u32 x = RANS_LOW, written = 0;
+    EncOut o{ring, scratch_end, 0u, 0u, k, 1u << k, active};
+    u32 x = RANS_LOW;
     const u32 q = active ? n >> 2 : 0;
     const u32 tail = active ? n - 4 * q : 0;
-
-    auto step = [&](bool live, u32 rcp, u32 pk) {
-        const bool emit = live && enc_wants_emit(x, pk, bits);
-        const u32 em = quad_mask_dpp(emit, mybit);
-        if (emit) {
-            const u32 above = __popc(em >> (k + 1));
-            *(gu16 *)(scratch_end - 2 * (written + above + 1)) = (u16)x;
-            x >>= 16;
-        }
-        written += __popc(em);
-        const u32 xn = enc_advance(x, rcp, pk, bits);
-        x = live ? xn : x;
-    };
 
     // (A) tail bytes n-1 .. 4q on chain 3, context = previous byte (:806-811)
     u32 cur = 0;
@@ -238,52 +283,68 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, gcu8 *data
             rcp = e.x; pk = e.y;
             cur = ci;
         }
-        step(live, rcp, pk);
+        o.step(x, live, rcp, pk, bits);
     }
 
     // (B) backward walk over offsets q-1 .. 1 of each quarter (:813-829); chain k codes byte
-    // k*q + r in context byte k*q + r - 1.
+    // k*q + r in context byte k*q + r - 1.  Trip t codes offsets r0-4t .. r0-4t-3.
     gcu8 *qbase = data + (u64)k * q;
-    u32 r = q ? q - 1 : 0;                      // offset of the next symbol to code; stops at 0
-    const u32 main = q ? q - 1 : 0;              // steps in (B)+(B')
-    u32 done = 0;
-    cur = (active && q) ? idx[qbase[r]] : 0u;
-    if (wave_any(main >= 4)) {
-        // bytes r-1 .. r-4 are the next four contexts (and the following four symbols)
-        auto load4 = [&](u32 rr) -> u32 {        // dword holding bytes rr-4 .. rr-1, 0 when out of range
-            return (main >= 4 && rr >= 4) ? *(GAS const u32_unaligned *)(qbase + rr - 4) : 0u;
+    const u32 r0 = q ? q - 1 : 0;
+    const u32 main = r0;                         // steps in (B)+(B')
+    const u32 ntrip = main >> 2;
+    cur = (active && q) ? idx[qbase[r0]] : 0u;
+    if (wave_any(ntrip > 0)) {
+        // Four-stage software pipeline, one stage per trip, every memory access issued at the top
+        // of a trip and first looked at during the next one:
+        //   trip t+4: input dword (HBM)        trip t+3: byte -> compact index (LDS)
+        //   trip t+2: cumulative pair (LDS)    trip t+1: reciprocal (L1)        trip t: 4 state updates
+        auto load4 = [&](u32 t) -> u32 {         // bytes r0-4t-4 .. r0-4t-1: contexts of trip t
+            return t < ntrip ? *(GAS const u32_unaligned *)(qbase + (r0 - 4 * t) - 4) : 0u;
         };
-        u32 w = load4(r);                        // contexts of trip 0
-        u32 wn = (r >= 4) ? load4(r - 4) : 0u;   // contexts of trip 1
-        // entries of trip 0
-        u32x2 E0, E1, E2, E3;
-        u32 c0, c1, c2, c3;
-        auto lookup = [&](u32 ww, u32 sym, u32x2 &e0, u32x2 &e1, u32x2 &e2, u32x2 &e3, u32 &last) {
-            c0 = idx[ww >> 24]; c1 = idx[(ww >> 16) & 0xff]; c2 = idx[(ww >> 8) & 0xff]; c3 = idx[ww & 0xff];
-            e0 = fetch(c0, sym); e1 = fetch(c1, c0); e2 = fetch(c2, c1); e3 = fetch(c3, c2);
-            last = c3;
+        struct I4 { u32 c0, c1, c2, c3; };
+        auto idx4 = [&](u32 ww) -> I4 {
+            I4 r = {idx[ww >> 24], idx[(ww >> 16) & 0xff], idx[(ww >> 8) & 0xff], idx[ww & 0xff]};
+            return r;
         };
-        u32 nxt_cur = 0;
-        lookup(w, cur, E0, E1, E2, E3, nxt_cur);
-        while (wave_any(done + 4 <= main)) {
-            const bool live = done + 4 <= main;
-            // prefetch for the next trip (entries) and the one after (input dword)
-            const u32 rn = r - 4;                               // symbol offset at the next trip
-            const bool more = live && done + 8 <= main;
-            u32x2 N0 = {0, 0}, N1 = {0, 0}, N2 = {0, 0}, N3 = {0, 0};
-            u32 ncur2 = 0;
-            const u32 wnn = (more && rn >= 8) ? load4(rn - 4) : 0u;
-            if (more) lookup(wn, nxt_cur, N0, N1, N2, N3, ncur2);
-            step(live, E0.x, E0.y);
-            step(live, E1.x, E1.y);
-            step(live, E2.x, E2.y);
-            step(live, E3.x, E3.y);
-            if (live) { done += 4; r = rn; cur = nxt_cur; }
-            E0 = N0; E1 = N1; E2 = N2; E3 = N3;
-            nxt_cur = ncur2; wn = wnn;
+        auto cum4 = [&](const I4 &c, u32 sym) -> u32x4 {
+            u32x4 r = {pair(c.c0, sym), pair(c.c1, c.c0), pair(c.c2, c.c1), pair(c.c3, c.c2)};
+            return r - (r << 16);                // start | freq << 16
+        };
+        auto rcp4 = [&](u32x4 p) -> u32x4 {
+            u32x4 r = {enc_rcp(rcptab, p.x >> 16), enc_rcp(rcptab, p.y >> 16), enc_rcp(rcptab, p.z >> 16), enc_rcp(rcptab, p.w >> 16)};
+            return r;
+        };
+        u32 W3, cur1, cur2;
+        I4 I2;
+        u32x4 P0, P1, R0;
+        {
+            const u32 w0 = load4(0), w1 = load4(1), w2 = load4(2);
+            W3 = load4(3);
+            const I4 i0 = idx4(w0), i1 = idx4(w1);
+            I2 = idx4(w2);
+            P0 = cum4(i0, cur);
+            P1 = cum4(i1, i0.c3);
+            cur1 = i0.c3; cur2 = i1.c3;
+            R0 = rcp4(P0);
+        }
+        for (u32 t = 0; wave_any(t < ntrip); t++) {
+            const bool live = t < ntrip;
+            const u32 Wn = load4(t + 4);
+            const I4 In = idx4(W3);
+            const u32x4 Pn = cum4(I2, cur2);
+            const u32x4 Rn = rcp4(P1);
+            o.step(x, live, R0.x, P0.x, bits);
+            o.step(x, live, R0.y, P0.y, bits);
+            o.step(x, live, R0.z, P0.z, bits);
+            o.step(x, live, R0.w, P0.w, bits);
+            if (live) cur = cur1;
+            cur1 = cur2; cur2 = I2.c3;
+            I2 = In; W3 = Wn; P0 = P1; P1 = Pn; R0 = Rn;
+            o.flush();
         }
     }
     // (B') remaining walk steps, one at a time
+    u32 r = r0 - 4 * ntrip, done = 4 * ntrip;
     for (; wave_any(done < main); ) {
         const bool live = done < main;
         u32 rcp = 0, pk = 0;
@@ -293,17 +354,16 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, gcu8 *data
             rcp = e.x; pk = e.y;
             cur = ci; r--; done++;
         }
-        step(live, rcp, pk);
+        o.step(x, live, rcp, pk, bits);
     }
     // (C) first byte of each quarter in context 0 (:831-834)
     {
         const bool live = active && q > 0;
         u32 rcp = 0, pk = 0;
         if (live) { const u32x2 e = fetch(0, cur); rcp = e.x; pk = e.y; }
-        step(live, rcp, pk);
+        o.step(x, live, rcp, pk, bits);
     }
-    if (active) *(gu32 *)(scratch_end - 2 * written - 16 + 4 * k) = x;
-    return active ? 2 * written + 16 : 0;
+    return o.finish(x);
 }
 
 // Hot form, order-0: one row of entries in LDS; chain k takes bytes 4g+k for descending g.
@@ -1088,7 +1148,8 @@ __global__ __launch_bounds__(WAVE) void k_enc_chain(EncItem *items, const u32 *r
     EncItem *I = &items[mine ? it : 0];
     bool active = mine && I->active;
     const u32 img_bytes = active ? I->img_bytes : 0u;
-    active = active && img_bytes > cls_lo && img_bytes <= cls_hi;
+    const u32 need = img_bytes + ENC_RING_BYTES;
+    active = active && need > cls_lo && need <= cls_hi;
     if (!wave_any(active)) return;
 
     const u32 order = active ? I->order : 2u;
@@ -1108,8 +1169,11 @@ __global__ __launch_bounds__(WAVE) void k_enc_chain(EncItem *items, const u32 *r
             for (u32 j = lane; j < ((nb + 15) >> 4); j += WAVE) dd[j] = s[j];
         }
         __syncthreads();
-        const u8 *im = lds + (u64)quad * lds_per_item;
-        pay = chain_encode_o1_lds(im, data, n, ns, bits, rcptab, send, order == 1, lane);
+        // lanes without a stream read and write the LDS of stream 0 (nothing of theirs is ever used)
+        const u32 slot = active ? quad : 0u;
+        const u8 *im = lds + (u64)slot * lds_per_item;
+        u8 *ring = lds + (u64)slot * lds_per_item + (lds_per_item - ENC_RING_BYTES);
+        pay = chain_encode_o1_lds(im, ring, data, n, ns, bits, rcptab, send, order == 1, lane);
         pay |= chain_encode_o0_lds(im, data, n, bits, rcptab, send, order == 0, lane);
     } else {
         gcu8 *im = (gcu8 *)I->image;

@@ -12,8 +12,12 @@ __global__ __launch_bounds__(64) void spin(unsigned long long ticks, unsigned *s
 int main(int argc, char **argv) {
     unsigned *sink; hipMalloc(&sink, 4);
     hipFuncSetAttribute((const void *)spin, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-    int sizes[] = {7232, 7296, 7680, 8192, 14464, 14592, 14848, 15360, 16384, 17920, 18176, 18432, 20480, 28928, 30720, 36160};
-    for (int s : sizes) {
+    int dflt[] = {7232, 7296, 7680, 8192, 14464, 14592, 14848, 15360, 16384, 17920, 18176, 18432, 20480, 28928, 30720, 36160};
+    int sizes[64], nsz = 0;
+    for (int i = 1; i < argc && nsz < 64; i++) sizes[nsz++] = atoi(argv[i]);      // sizes to probe on the command line
+    if (!nsz) for (int v : dflt) sizes[nsz++] = v;
+    for (int si = 0; si < nsz; si++) {
+        const int s = sizes[si];
         int best = 0;
         for (int k = 1; k <= 40; k++) {
             hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
