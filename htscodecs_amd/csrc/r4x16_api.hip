@@ -191,6 +191,7 @@ static size_t enc_ws_layout(u8 *base, size_t nblk, u64 scratch_stride, u64 xf_st
     w->metatab = cv.take<u8>(nblk, xf_stride ? META_TAB_BYTES : 0);
     w->scratch2 = cv.take<u8>(nblk, scratch2_stride);
     w->stat = cv.take<EncStat>(nblk);
+    w->dump = cv.take<u8>(1, ENC_DUMP_BYTES);
     w->xf_stride = xf_stride;
     w->scratch2_stride = scratch2_stride;
     return align_up(cv.off, 256);

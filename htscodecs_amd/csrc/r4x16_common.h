@@ -228,7 +228,9 @@ struct EncWs {
     u8 *metatab;        // [nblk][1024]        order-0 table of the meta stream
     u8 *scratch2;       // [nblk][scratch2_stride]  backward-written meta stream
     EncStat *stat;      // [nblk]
+    u8 *dump;           // [ENC_DUMP_BYTES]  target of the chain coder's idle output slots (never read)
     u64 xf_stride, scratch2_stride;
 };
 #define META_TAB_BYTES 1024u
+#define ENC_DUMP_BYTES 65536u
 

@@ -196,32 +196,50 @@ __device__ __forceinline__ u32 chain_encode(gcu8 *data, u32 n, gcu8 *image, u32 
 // different lengths in one wave simply drop out of (B) at different trips.
 // ---------------------------------------------------------------------------------------------
 // Emitted 16-bit words are staged in a 128-byte LDS ring per stream and copied out 64 bytes at a
-// time (16 bytes per lane): the hot loop issues no global store, so the only vector-memory
-// operations in flight are prefetches whose results are not needed for a whole trip.
-// Word j of a stream (emission order) belongs at scratch_end - 2 (j + 1); in the ring it sits
-// at byte 126 - 2 (j & 63), which keeps each 64-byte half in memory order.
+// time (16 bytes per lane).  Word j of a stream (emission order) belongs at scratch_end - 2 (j + 1);
+// in the ring it sits at byte 126 - 2 (j & 63), which keeps each 64-byte half in memory order.
+//
+// Why: the wave's vector-memory counter retires in order, so ONE outstanding HBM access (an
+// input prefetch, a store waiting for its acknowledgement) stalls every later wait on that
+// counter.  The hot loop therefore keeps everything it consumes per trip in LDS (tables, the
+// reciprocal table, the emitted words) and touches global memory exactly twice per eight steps,
+// unconditionally and in a fixed order: one 8-byte input load three double-trips ahead and one
+// 16-byte store (a completed half of the ring, or a dump slot nobody reads).
 #define ENC_RING_BYTES 144u          // ring + a 2-byte dump slot for lanes that do not emit (+ pad)
+#define ENC_LRCP_BYTES 16400u        // RCPTAB_ENTRIES dwords, padded to 16
 struct EncOut {
     u8 *ring;            // LDS
     gu8 *send;           // scratch_end of the stream
+    gu8 *dump;           // this lane's 16 bytes of the dump area
     u32 written;         // words emitted by the quad so far
-    u32 flushed;         // 64-byte halves already copied out
+    u32 flushed;         // 64-byte halves already read out of the ring
     u32 k, mybit;
     bool active;
-    // rANS_word.h:281-321 for one symbol {rcp, start | freq << 16}; x is this lane's state
+    u32x4 held;          // a half read out of the ring, stored one double-trip later
+    gu8 *held_dst;
+    // rANS_word.h:281-321 for one symbol; x is this lane's state.  pk = start | freq << 16.
+    // q = x / freq < 2^21 once x < x_max, so q * (M - freq) is a 24-bit multiply (mod 2^32).
     __device__ __forceinline__ void step(u32 &x, bool live, u32 rcp, u32 pk, u32 bits)
     {
-        const bool emit = live && enc_wants_emit(x, pk, bits);
+        const u32 f = pk >> 16, start = pk & 0xffffu;
+        const bool emit = live && x >= (f << (31u - bits));
         const u32 em = quad_mask_dpp(emit, mybit);
         const u32 j = written + __popc(em >> (k + 1));
-        const u32 slot = emit ? 126u - 2u * (j & 63u) : 128u;
+        const u32 slot = emit ? ((~j << 1) & 126u) : 128u;
         *(u16 *)(ring + slot) = (u16)x;
         const u32 xs = emit ? x >> 16 : x;
         written += __popc(em);
-        const u32 xn = enc_advance(xs, rcp, pk, bits);
+        // exact x / f: Alverson reciprocal for f >= 2; f == 1 has rcp = 2^32 - 1 and shift 0, which
+        // gives x - 1, and the missing (M - 1) is added to the bias (rANS_word.h:232-240 does the same)
+        const u32 fm1 = f - 1u;
+        const u32 rsh = 31u - (u32)__clz((int)(fm1 | 1u));
+        const u32 q = __umulhi(xs, rcp) >> rsh;
+        const u32 cmpl = (1u << bits) - f;
+        const u32 bias = start + (fm1 ? 0u : cmpl);
+        const u32 xn = __umul24(q, cmpl) + (xs + bias);
         x = live ? xn : xs;
     }
-    // copy out the half that has just been completed, if any (at most one per four steps)
+    // conditional form: copy out the half that has just been completed, if any
     __device__ __forceinline__ void flush()
     {
         const bool due = active && (written >> 5) != flushed;
@@ -233,6 +251,20 @@ struct EncOut {
             }
         }
     }
+    // unconditional form for the main loop: store what was read out last time, read out the next
+    __device__ __forceinline__ void flush_pipelined()
+    {
+        *(GAS u32x4_unaligned *)held_dst = held;
+        const bool due = active && (written >> 5) != flushed;
+        held = *(const u32x4 *)(ring + ((flushed & 1u) ? 0u : 64u) + 16u * k);
+        held_dst = due ? send - 64ull * (flushed + 1u) + 16u * k : dump;
+        flushed += due ? 1u : 0u;
+    }
+    __device__ __forceinline__ void flush_drain()
+    {
+        *(GAS u32x4_unaligned *)held_dst = held;
+        held_dst = dump;
+    }
     // the words still in the ring, then the four states (RansEncFlush in order 3,2,1,0, :482-485)
     __device__ __forceinline__ u32 finish(u32 x)
     {
@@ -242,7 +274,7 @@ struct EncOut {
         for (u32 i = k; wave_any(i < rem); i += 4) {
             if (i < rem) {
                 const u32 j = first + i;
-                *(gu16 *)(send - 2ull * (j + 1u)) = *(const u16 *)(ring + 126u - 2u * (j & 63u));
+                *(gu16 *)(send - 2ull * (j + 1u)) = *(const u16 *)(ring + ((~j << 1) & 126u));
             }
         }
         if (active) *(gu32 *)(send - 2ull * written - 16 + 4 * k) = x;
@@ -250,23 +282,23 @@ struct EncOut {
     }
 };
 
-__device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, u8 *ring, gcu8 *data, u32 n, u32 ns, u32 bits,
-                                                   gcu32 *rcptab, gu8 *scratch_end, bool active, u32 lane)
+__device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, u8 *ring, const u32 *lrcp, gcu8 *data, u32 n, u32 ns,
+                                                   u32 bits, gcu8 *safe, gu8 *scratch_end, gu8 *dump, bool active, u32 lane)
 {
     const u32 k = lane & 3;
     const u8 *idx = img_lds;
     const u8 *cumb = img_lds + ENC_IMG_IDX;
-    const u16 *cum = (const u16 *)cumb;
     const u32 rs = ns + 1;                                // u16 per context row
     // start | next << 16 of symbol si in context ci: one dword read at a 2-byte aligned LDS address
     auto pair = [&](u32 ci, u32 si) -> u32 { return *(LAS const u32 *)(cumb + 2u * (ci * rs + si)); };
+    auto rcpof = [&](u32 pk) -> u32 { const u32 f = pk >> 16; return lrcp[f < RCPTAB_ENTRIES ? f : 0u]; };
+    auto topk = [&](u32 p) -> u32 { u32 hi = p << 16; asm volatile("" : "+v"(hi)); return p - hi; };   // start | freq << 16
     auto fetch = [&](u32 ci, u32 si) -> u32x2 {           // {rcp, start | freq << 16}
-        const u32 p = pair(ci, si);
-        const u32 pk = p - (p << 16);
-        u32x2 r = {enc_rcp(rcptab, pk >> 16), pk};
+        const u32 pk = topk(pair(ci, si));
+        u32x2 r = {rcpof(pk), pk};
         return r;
     };
-    EncOut o{ring, scratch_end, 0u, 0u, k, 1u << k, active};
+    EncOut o{ring, scratch_end, dump, 0u, 0u, k, 1u << k, active, {0, 0, 0, 0}, dump};
     u32 x = RANS_LOW;
     const u32 q = active ? n >> 2 : 0;
     const u32 tail = active ? n - 4 * q : 0;
@@ -287,19 +319,21 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, u8 *ring, 
     }
 
     // (B) backward walk over offsets q-1 .. 1 of each quarter (:813-829); chain k codes byte
-    // k*q + r in context byte k*q + r - 1.  Trip t codes offsets r0-4t .. r0-4t-3.
+    // k*q + r in context byte k*q + r - 1.  Trip t codes offsets r0-4t .. r0-4t-3; the pipelined
+    // loop takes an even number of trips, the rest goes to (B').
     gcu8 *qbase = data + (u64)k * q;
     const u32 r0 = q ? q - 1 : 0;
     const u32 main = r0;                         // steps in (B)+(B')
-    const u32 ntrip = main >> 2;
+    const u32 npair = main >> 3;                 // double trips
+    const u32 ntrip = 2 * npair;
     cur = (active && q) ? idx[qbase[r0]] : 0u;
-    if (wave_any(ntrip > 0)) {
-        // Four-stage software pipeline, one stage per trip, every memory access issued at the top
-        // of a trip and first looked at during the next one:
-        //   trip t+4: input dword (HBM)        trip t+3: byte -> compact index (LDS)
-        //   trip t+2: cumulative pair (LDS)    trip t+1: reciprocal (L1)        trip t: 4 state updates
-        auto load4 = [&](u32 t) -> u32 {         // bytes r0-4t-4 .. r0-4t-1: contexts of trip t
-            return t < ntrip ? *(GAS const u32_unaligned *)(qbase + (r0 - 4 * t) - 4) : 0u;
+    if (wave_any(npair > 0)) {
+        // Software pipeline, every access issued at least one trip before its first use:
+        //   input piece of double-trip D+3 (HBM, 8 bytes)   byte -> compact index of trip t+3 (LDS)
+        //   cumulative pair of trip t+2 (LDS)               reciprocal of trip t+1 (LDS)      trip t: 4 state updates
+        auto load8 = [&](u32 j) -> u32x2 {       // bytes r0-8j-8 .. r0-8j-1: .y = contexts of trip 2j, .x = of trip 2j+1
+            gcu8 *p = j < npair ? qbase + (r0 - 8 * j) - 8 : safe;
+            return *(GAS const u32x2_unaligned *)p;
         };
         struct I4 { u32 c0, c1, c2, c3; };
         auto idx4 = [&](u32 ww) -> I4 {
@@ -307,30 +341,32 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, u8 *ring, 
             return r;
         };
         auto cum4 = [&](const I4 &c, u32 sym) -> u32x4 {
-            u32x4 r = {pair(c.c0, sym), pair(c.c1, c.c0), pair(c.c2, c.c1), pair(c.c3, c.c2)};
-            return r - (r << 16);                // start | freq << 16
-        };
-        auto rcp4 = [&](u32x4 p) -> u32x4 {
-            u32x4 r = {enc_rcp(rcptab, p.x >> 16), enc_rcp(rcptab, p.y >> 16), enc_rcp(rcptab, p.z >> 16), enc_rcp(rcptab, p.w >> 16)};
+            u32x4 r = {topk(pair(c.c0, sym)), topk(pair(c.c1, c.c0)), topk(pair(c.c2, c.c1)), topk(pair(c.c3, c.c2))};
             return r;
         };
-        u32 W3, cur1, cur2;
+        auto rcp4 = [&](u32x4 p) -> u32x4 {
+            u32x4 r = {rcpof(p.x), rcpof(p.y), rcpof(p.z), rcpof(p.w)};
+            return r;
+        };
+        u32 cur1, cur2;
         I4 I2;
         u32x4 P0, P1, R0;
+        // input pieces live in a ring of four register pairs, piece j in Q[j % 4]; the loop is unrolled
+        // four double-trips so that no piece is ever copied (a copy would have to wait for the load)
+        u32x2 Q0, Q1, Q2, Q3;
         {
-            const u32 w0 = load4(0), w1 = load4(1), w2 = load4(2);
-            W3 = load4(3);
-            const I4 i0 = idx4(w0), i1 = idx4(w1);
-            I2 = idx4(w2);
+            Q0 = load8(0); Q1 = load8(1); Q2 = load8(2); Q3 = load8(3);
+            const I4 i0 = idx4(Q0.y), i1 = idx4(Q0.x);
+            I2 = idx4(Q1.y);
             P0 = cum4(i0, cur);
             P1 = cum4(i1, i0.c3);
             cur1 = i0.c3; cur2 = i1.c3;
             R0 = rcp4(P0);
         }
-        for (u32 t = 0; wave_any(t < ntrip); t++) {
+        u32 t = 0;
+        auto trip = [&](u32 wnext3) {
             const bool live = t < ntrip;
-            const u32 Wn = load4(t + 4);
-            const I4 In = idx4(W3);
+            const I4 In = idx4(wnext3);
             const u32x4 Pn = cum4(I2, cur2);
             const u32x4 Rn = rcp4(P1);
             o.step(x, live, R0.x, P0.x, bits);
@@ -339,9 +375,19 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, u8 *ring, 
             o.step(x, live, R0.w, P0.w, bits);
             if (live) cur = cur1;
             cur1 = cur2; cur2 = I2.c3;
-            I2 = In; W3 = Wn; P0 = P1; P1 = Pn; R0 = Rn;
-            o.flush();
+            I2 = In; P0 = P1; P1 = Pn; R0 = Rn;
+            t++;
+        };
+        // double-trip d: trip 2d looks up the bytes of trip 2d+3 (piece d+1, low dword), trip 2d+1
+        // those of trip 2d+4 (piece d+2, high dword); piece d+4 is requested into the slot of piece d
+        for (u32 d = 0; wave_any(d < npair); d += 4) {
+            Q0 = load8(d + 4); o.flush_pipelined(); trip(Q1.x); trip(Q2.y);
+            Q1 = load8(d + 5); o.flush_pipelined(); trip(Q2.x); trip(Q3.y);
+            Q2 = load8(d + 6); o.flush_pipelined(); trip(Q3.x); trip(Q0.y);
+            Q3 = load8(d + 7); o.flush_pipelined(); trip(Q0.x); trip(Q1.y);
         }
+        o.flush_drain();
+        o.flush();                               // fewer than 32 words may stay in the ring from here on
     }
     // (B') remaining walk steps, one at a time
     u32 r = r0 - 4 * ntrip, done = 4 * ntrip;
@@ -355,6 +401,7 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, u8 *ring, 
             cur = ci; r--; done++;
         }
         o.step(x, live, rcp, pk, bits);
+        o.flush();
     }
     // (C) first byte of each quarter in context 0 (:831-834)
     {
@@ -1136,13 +1183,16 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
 // ---------------------------------------------------------------------------------------------
 // k_enc_chain: QPW streams per wave, one launch per LDS size class (see k_dec_chain).
 // ---------------------------------------------------------------------------------------------
+// LDS_IMG: a workgroup of up to four waves shares one LDS copy of the reciprocal table; each quad
+// owns lds_per_item bytes (image, then the word ring).  Waves never meet again after the set-up.
 template <bool LDS_IMG>
-__global__ __launch_bounds__(WAVE) void k_enc_chain(EncItem *items, const u32 *rcptab_, int nitems, int qpw,
-                                                    u32 lds_per_item, u32 cls_lo, u32 cls_hi)
+__global__ __launch_bounds__(256) void k_enc_chain(EncItem *items, const u32 *rcptab_, u8 *dump_, int nitems, int qpw,
+                                                   u32 lds_per_item, u32 cls_lo, u32 cls_hi)
 {
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
-    const u32 lane = threadIdx.x;
-    const u32 quad = lane >> 2;
+    const u32 tid = threadIdx.x;
+    const u32 lane = tid & (WAVE - 1);
+    const u32 quad = tid >> 2;
     const int it = (int)blockIdx.x * qpw + (int)quad;
     const bool mine = quad < (u32)qpw && it < nitems;
     EncItem *I = &items[mine ? it : 0];
@@ -1150,7 +1200,8 @@ __global__ __launch_bounds__(WAVE) void k_enc_chain(EncItem *items, const u32 *r
     const u32 img_bytes = active ? I->img_bytes : 0u;
     const u32 need = img_bytes + ENC_RING_BYTES;
     active = active && need > cls_lo && need <= cls_hi;
-    if (!wave_any(active)) return;
+    if (LDS_IMG) { if (!__syncthreads_or(active ? 1 : 0)) return; }
+    else if (!wave_any(active)) return;
 
     const u32 order = active ? I->order : 2u;
     gcu32 *rcptab = to_global(rcptab_);
@@ -1159,21 +1210,27 @@ __global__ __launch_bounds__(WAVE) void k_enc_chain(EncItem *items, const u32 *r
     const u32 n = I->n, ns = I->ns, bits = active ? I->bits : 12u;
     u32 pay;
     if (LDS_IMG) {
+        u32 *lrcp = (u32 *)lds;
+        u8 *slots = lds + ENC_LRCP_BYTES;
+        for (u32 j = tid; j < RCPTAB_ENTRIES; j += blockDim.x) lrcp[j] = rcptab[j];
+        // each wave copies the images of its own quads (16-byte pieces)
         const u64 my_img = active ? I->image : 0ull;
-        for (int qd = 0; qd < qpw; qd++) {
-            const u64 src = __shfl(my_img, qd * 4);
-            const u32 nb = __shfl(img_bytes, qd * 4);
+        const u32 wq0 = (tid & ~(WAVE - 1)) >> 2;          // first quad of this wave
+        for (u32 qd = 0; qd < WAVE / 4; qd++) {
+            const u64 src = __shfl(my_img, (int)qd * 4);
+            const u32 nb = __shfl(img_bytes, (int)qd * 4);
             if (!src) continue;
             gcu32x4 *s = (gcu32x4 *)src;
-            u32x4 *dd = (u32x4 *)(lds + (u64)qd * lds_per_item);
+            u32x4 *dd = (u32x4 *)(slots + (u64)(wq0 + qd) * lds_per_item);
             for (u32 j = lane; j < ((nb + 15) >> 4); j += WAVE) dd[j] = s[j];
         }
         __syncthreads();
         // lanes without a stream read and write the LDS of stream 0 (nothing of theirs is ever used)
         const u32 slot = active ? quad : 0u;
-        const u8 *im = lds + (u64)slot * lds_per_item;
-        u8 *ring = lds + (u64)slot * lds_per_item + (lds_per_item - ENC_RING_BYTES);
-        pay = chain_encode_o1_lds(im, ring, data, n, ns, bits, rcptab, send, order == 1, lane);
+        const u8 *im = slots + (u64)slot * lds_per_item;
+        u8 *ring = slots + (u64)slot * lds_per_item + (lds_per_item - ENC_RING_BYTES);
+        gu8 *dump = to_global(dump_) + 16u * ((blockIdx.x * blockDim.x + tid) & (ENC_DUMP_BYTES / 16u - 1u));
+        pay = chain_encode_o1_lds(im, ring, lrcp, data, n, ns, bits, (gcu8 *)rcptab, send, dump, order == 1, lane);
         pay |= chain_encode_o0_lds(im, data, n, bits, rcptab, send, order == 0, lane);
     } else {
         gcu8 *im = (gcu8 *)I->image;
@@ -1267,9 +1324,15 @@ extern "C" void r4x16_launch_enc_front(const BatchArgs *a, const EncWs *ws, int 
 }
 // {LDS bytes per stream, streams per wave}; LDS is allocated in 1,280-byte granules.
 // q4/q8 images are ~0.4 KB, an order-0 row 0.8 KB, q40 4.6 KB (16 x 4,800 = 60 granules: 2 waves, 32 streams per CU — fuller waves measured faster than more waves)
-static const struct { u32 bytes; int qpw; } ENC_CLASSES[] = {
-    {640, 16}, {1280, 16}, {2560, 16}, {4800, 16}, {6400, 12}, {12800, 6}, {33280, 2}, {81920, 1}, {163840, 1},
-};
+// LDS size classes: bytes per stream (image + word ring).  A workgroup takes as many streams as
+// fit beside the shared reciprocal table, up to 64 (four waves); 1,280-byte allocation granules.
+static const u32 ENC_CLASSES[] = {640, 1280, 2560, 4736, 6400, 12800, 33280, 73472, 147072};
+static int enc_class_qpw(u32 bytes)
+{
+    const u32 room = 163840u - ENC_LRCP_BYTES - 256u;      // 256: static LDS the compiler adds (workgroup vote)
+    const u32 fit = room / bytes;
+    return (int)(fit > 64 ? 64 : fit);
+}
 extern "C" void r4x16_launch_enc_tables(const BatchArgs *a, const EncWs *ws, int base, int nblk, hipStream_t s)
 {
     hipLaunchKernelGGL(k_enc_tables, dim3(nblk), dim3(WAVE), TABLES_DYN_LDS, s, *a, *ws, base);
@@ -1278,20 +1341,21 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
 {
     static bool once = false;
     if (!once) {
-        (void)hipFuncSetAttribute((const void *)k_enc_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void *)k_enc_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840 - 256);
         once = true;
     }
     u32 lo = 0;
     static const int force_qpw = getenv("R4X16_ENC_QPW") ? atoi(getenv("R4X16_ENC_QPW")) : 0;   // tuning aid
-    for (const auto &c : ENC_CLASSES) {
-        const int qpw = (force_qpw && c.bytes == 4800) ? force_qpw : c.qpw;
+    for (const u32 bytes : ENC_CLASSES) {
+        const int qpw = (force_qpw && bytes == 4736) ? force_qpw : enc_class_qpw(bytes);
         const int grid = (nitems + qpw - 1) / qpw;
-        hipLaunchKernelGGL(k_enc_chain<true>, dim3(grid), dim3(WAVE), (size_t)qpw * c.bytes, s,
-                           ws->items, ws->rcptab, nitems, qpw, c.bytes, lo, c.bytes);
-        lo = c.bytes;
+        const int threads = WAVE * ((qpw + 15) / 16);
+        hipLaunchKernelGGL(k_enc_chain<true>, dim3(grid), dim3(threads), (size_t)ENC_LRCP_BYTES + (size_t)qpw * bytes, s,
+                           ws->items, ws->rcptab, ws->dump, nitems, qpw, bytes, lo, bytes);
+        lo = bytes;
     }
     const int grid = (nitems + 15) / 16;
-    hipLaunchKernelGGL(k_enc_chain<false>, dim3(grid), dim3(WAVE), 0, s, ws->items, ws->rcptab, nitems, 16, 0u, lo, 0xffffffffu);
+    hipLaunchKernelGGL(k_enc_chain<false>, dim3(grid), dim3(WAVE), 0, s, ws->items, ws->rcptab, ws->dump, nitems, 16, 0u, lo, 0xffffffffu);
 }
 extern "C" void r4x16_launch_enc_finish(const BatchArgs *a, const EncWs *ws, int base, int nblk, hipStream_t s)
 {
