@@ -292,7 +292,9 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, u8 *ring, 
     // start | next << 16 of symbol si in context ci: one dword read at a 2-byte aligned LDS address
     auto pair = [&](u32 ci, u32 si) -> u32 { return *(LAS const u32 *)(cumb + 2u * (ci * rs + si)); };
     auto rcpof = [&](u32 pk) -> u32 { const u32 f = pk >> 16; return lrcp[f < RCPTAB_ENTRIES ? f : 0u]; };
-    auto topk = [&](u32 p) -> u32 { u32 hi = p << 16; asm volatile("" : "+v"(hi)); return p - hi; };   // start | freq << 16
+    // start | next << 16  ->  start | freq << 16 (the empty asm keeps this a shift and a subtract
+    // instead of a quarter-rate multiply by 0xFFFF0001)
+    auto topk = [&](u32 p) -> u32 { u32 hi = p << 16; asm("" : "+v"(hi)); return p - hi; };
     auto fetch = [&](u32 ci, u32 si) -> u32x2 {           // {rcp, start | freq << 16}
         const u32 pk = topk(pair(ci, si));
         u32x2 r = {rcpof(pk), pk};
@@ -340,8 +342,12 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, u8 *ring, 
             I4 r = {idx[ww >> 24], idx[(ww >> 16) & 0xff], idx[(ww >> 8) & 0xff], idx[ww & 0xff]};
             return r;
         };
-        auto cum4 = [&](const I4 &c, u32 sym) -> u32x4 {
-            u32x4 r = {topk(pair(c.c0, sym)), topk(pair(c.c1, c.c0)), topk(pair(c.c2, c.c1)), topk(pair(c.c3, c.c2))};
+        auto cum4 = [&](const I4 &c, u32 sym) -> u32x4 {     // raw pairs start | next << 16
+            u32x4 r = {pair(c.c0, sym), pair(c.c1, c.c0), pair(c.c2, c.c1), pair(c.c3, c.c2)};
+            return r;
+        };
+        auto topk4 = [&](u32x4 p) -> u32x4 {
+            u32x4 r = {topk(p.x), topk(p.y), topk(p.z), topk(p.w)};
             return r;
         };
         auto rcp4 = [&](u32x4 p) -> u32x4 {
@@ -350,7 +356,7 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, u8 *ring, 
         };
         u32 cur1, cur2;
         I4 I2;
-        u32x4 P0, P1, R0;
+        u32x4 P0, Praw, R0;
         // input pieces live in a ring of four register pairs, piece j in Q[j % 4]; the loop is unrolled
         // four double-trips so that no piece is ever copied (a copy would have to wait for the load)
         u32x2 Q0, Q1, Q2, Q3;
@@ -358,25 +364,30 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, u8 *ring, 
             Q0 = load8(0); Q1 = load8(1); Q2 = load8(2); Q3 = load8(3);
             const I4 i0 = idx4(Q0.y), i1 = idx4(Q0.x);
             I2 = idx4(Q1.y);
-            P0 = cum4(i0, cur);
-            P1 = cum4(i1, i0.c3);
+            P0 = topk4(cum4(i0, cur));
+            Praw = cum4(i1, i0.c3);
             cur1 = i0.c3; cur2 = i1.c3;
             R0 = rcp4(P0);
         }
         u32 t = 0;
         auto trip = [&](u32 wnext3) {
             const bool live = t < ntrip;
-            const I4 In = idx4(wnext3);
-            const u32x4 Pn = cum4(I2, cur2);
+            const I4 In = idx4(wnext3);              // bytes of trip t+3
+            const u32x4 Pn = cum4(I2, cur2);         // pairs of trip t+2
+            const u32x4 P1 = topk4(Praw);            // trip t+1, read during the previous trip
             const u32x4 Rn = rcp4(P1);
+            // the look-ups above belong to later trips: keep the scheduler from pulling next trip's
+            // (which depend on them) up behind them, which would put their latency on this trip
+            __builtin_amdgcn_sched_barrier(0);
             o.step(x, live, R0.x, P0.x, bits);
             o.step(x, live, R0.y, P0.y, bits);
             o.step(x, live, R0.z, P0.z, bits);
             o.step(x, live, R0.w, P0.w, bits);
             if (live) cur = cur1;
             cur1 = cur2; cur2 = I2.c3;
-            I2 = In; P0 = P1; P1 = Pn; R0 = Rn;
+            I2 = In; P0 = P1; Praw = Pn; R0 = Rn;
             t++;
+            __builtin_amdgcn_sched_barrier(0);
         };
         // double-trip d: trip 2d looks up the bytes of trip 2d+3 (piece d+1, low dword), trip 2d+1
         // those of trip 2d+4 (piece d+2, high dword); piece d+4 is requested into the slot of piece d
@@ -1200,8 +1211,18 @@ __global__ __launch_bounds__(256) void k_enc_chain(EncItem *items, const u32 *rc
     const u32 img_bytes = active ? I->img_bytes : 0u;
     const u32 need = img_bytes + ENC_RING_BYTES;
     active = active && need > cls_lo && need <= cls_hi;
-    if (LDS_IMG) { if (!__syncthreads_or(active ? 1 : 0)) return; }
-    else if (!wave_any(active)) return;
+    if (LDS_IMG) {
+        // workgroup-wide "does anybody have work here" through one dword of the dynamic LDS
+        // (__syncthreads_or would bring 256 bytes of static LDS with it: one stream's worth of room)
+        volatile u32 *flag = (volatile u32 *)lds;
+        if (tid == 0) *flag = 0;
+        __syncthreads();
+        if (active) *flag = 1;
+        __syncthreads();
+        const u32 any = *flag;
+        __syncthreads();
+        if (!any) return;
+    } else if (!wave_any(active)) return;
 
     const u32 order = active ? I->order : 2u;
     gcu32 *rcptab = to_global(rcptab_);
@@ -1326,10 +1347,12 @@ extern "C" void r4x16_launch_enc_front(const BatchArgs *a, const EncWs *ws, int 
 // q4/q8 images are ~0.4 KB, an order-0 row 0.8 KB, q40 4.6 KB (16 x 4,800 = 60 granules: 2 waves, 32 streams per CU — fuller waves measured faster than more waves)
 // LDS size classes: bytes per stream (image + word ring).  A workgroup takes as many streams as
 // fit beside the shared reciprocal table, up to 64 (four waves); 1,280-byte allocation granules.
-static const u32 ENC_CLASSES[] = {640, 1280, 2560, 4736, 6400, 12800, 33280, 73472, 147072};
+// (sizes are 16 mod 128: consecutive streams start four LDS banks apart, so that the eight streams of a
+// 32-lane access group do not all hit the same bank when they touch the same offset)
+static const u32 ENC_CLASSES[] = {656, 1296, 2576, 4752, 6416, 12816, 33296, 73616, 147344};
 static int enc_class_qpw(u32 bytes)
 {
-    const u32 room = 163840u - ENC_LRCP_BYTES - 256u;      // 256: static LDS the compiler adds (workgroup vote)
+    const u32 room = 163840u - ENC_LRCP_BYTES;
     const u32 fit = room / bytes;
     return (int)(fit > 64 ? 64 : fit);
 }
@@ -1341,13 +1364,13 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
 {
     static bool once = false;
     if (!once) {
-        (void)hipFuncSetAttribute((const void *)k_enc_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840 - 256);
+        (void)hipFuncSetAttribute((const void *)k_enc_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         once = true;
     }
     u32 lo = 0;
     static const int force_qpw = getenv("R4X16_ENC_QPW") ? atoi(getenv("R4X16_ENC_QPW")) : 0;   // tuning aid
     for (const u32 bytes : ENC_CLASSES) {
-        const int qpw = (force_qpw && bytes == 4736) ? force_qpw : enc_class_qpw(bytes);
+        const int qpw = (force_qpw && bytes == 4752) ? force_qpw : enc_class_qpw(bytes);
         const int grid = (nitems + qpw - 1) / qpw;
         const int threads = WAVE * ((qpw + 15) / 16);
         hipLaunchKernelGGL(k_enc_chain<true>, dim3(grid), dim3(threads), (size_t)ENC_LRCP_BYTES + (size_t)qpw * bytes, s,
