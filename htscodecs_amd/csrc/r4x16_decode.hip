@@ -22,11 +22,12 @@ struct GImg {
     __device__ __forceinline__ u32x2 ld64(u32 off) const { return *(GAS const u32x2_a4 *)(p + off); }
 };
 struct LImg {
-    const u8 *p;     // points into __shared__
-    __device__ __forceinline__ u32 ld16(u32 off) const { return *(const u16 *)(p + off); }
-    __device__ __forceinline__ u32 ld32(u32 off) const { return *(const u32 *)(p + off); }
-    __device__ __forceinline__ u32x2 ld64(u32 off) const { return *(const u32x2_a4 *)(p + off); }
+    u32 base;        // LDS byte address (32-bit arithmetic keeps row addressing to one multiply-add)
+    __device__ __forceinline__ u32 ld16(u32 off) const { return *(LAS const u16 *)(unsigned long)(base + off); }
+    __device__ __forceinline__ u32 ld32(u32 off) const { return *(LAS const u32 *)(unsigned long)(base + off); }
+    __device__ __forceinline__ u32x2 ld64(u32 off) const { return *(LAS const u32x2_a4 *)(unsigned long)(base + off); }
 };
+__device__ __forceinline__ u32 lds_addr(const void *p) { return (u32)(unsigned long)(LAS const u8 *)p; }
 
 // number of the four u16 separators in v that are <= m, without compares: separators are stored
 // clamped to 0x7FFF (m < 4096, so the clamp changes no answer), hence in each 16-bit half
@@ -45,7 +46,7 @@ __device__ __forceinline__ u32 lookup_step(const IMG &img, u32 row, u32 look, u3
                                            const u32x2 *root = nullptr /* LV 2: img.ld64(row), read ahead */)
 {
     const u32 m = x & mask;
-    const u32 mm = m | (m << 16) | 0x80008000u;
+    const u32 mm = __umul24(m, 0x10001u) + 0x80008000u;     // m | m << 16 | flags (m < 2^15: no overlap)
     u32 e, c0, c1, c2;
     if (LV == 4) {
         const u32 a = count_le(mm, img.ld64(row)) + count_le(mm, img.ld64(row + 8));
@@ -165,10 +166,11 @@ template <int ORDER, int LV>
 __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 *ring, gcu8 *words, u32 words_len,
                                                 gu8 *out, u32 out_sz, u32 x, u32 look, bool active, u32 lane)
 {
-    const LImg img{img_lds};
+    const LImg img{lds_addr(img_lds)};                     // alpha[] reads
+    const LImg img0{0u};                                   // row reads: `row` is an absolute LDS address
     const u32 k = lane & 3;
     const u32 mask = (1u << look) - 1;
-    const u32 rows = img_alpha_bytes(nsym), roww = img_row_bytes(nsym);
+    const u32 rows = lds_addr(img_lds) + img_alpha_bytes(nsym), roww = img_row_bytes(nsym);
     const u32 nwords = words_len >> 1;
     const u32 below = (1u << k) - 1u;                      // quad lanes below this one
     const u32 mybit = 1u << k;
@@ -206,7 +208,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     u32 row = rows, cursor = 0, bad = 0, t = 0;
     // root separators of `row`, read as soon as the row is known (one step ahead of their use,
     // so that this LDS round trip runs beside the renormalisation instead of after it)
-    u32x2 root = img.ld64(row);
+    u32x2 root = img0.ld64(row);
     u32 acc = 0;                                          // order-1: the last (up to) 4 decoded bytes
     u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;                   // order-1: completed dwords not yet stored (a3 newest)
     u32 hdr = 0;                                          // order-1: alpha[] word of the symbol decoded last step
@@ -224,14 +226,16 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             // before the table lookups so that their latency hides under them
             const u32 cb = off0 + 2 * cursor;
             const u32 ra = cb & 124u;
-            // (volatile: keeps the compiler from sinking these reads into a branch, which would
-            //  put their latency back on the dependent path)
-            lvcu32 *rp = (lvcu32 *)(ring + ra);       // explicit LDS pointer: a volatile generic access would go FLAT
+            // Three ALIGNED dwords and a funnel shift: a dword read at a misaligned LDS address costs far
+            // more than the extra read (measured: +12 % on the whole kernel per misaligned read and step).
+            // (volatile: keeps the compiler from sinking these reads into a branch, which would put their
+            //  latency back on the dependent path; explicit LDS pointer: a volatile generic access goes FLAT)
+            lvcu32 *rp = (lvcu32 *)(ring + ra);
             const u32 d0 = rp[0], d1 = rp[1], d2 = rp[2];
             const u32 sh = (cb & 3u) * 8u;
 
             u32 xn = x;
-            const u32 s = lookup_step<LV>(img, row, look, mask, xn, LV == 2 ? &root : nullptr);
+            const u32 s = lookup_step<LV>(img0, row, look, mask, xn, LV == 2 ? &root : nullptr);
             const u32 hn = img.ld16(2 * s);               // byte value | ROW_EMPTY of the new context
             u32 byte0 = 0;
             if (ORDER == 0) {
@@ -256,7 +260,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
                 const u32 rown = rows + __umul24(s, roww);
                 hdr = live ? hn : hdr;
                 row = live ? rown : row;
-                if (LV == 2) root = img.ld64(row);
+                if (LV == 2) root = img0.ld64(row);
             }
             x = live ? xn : x;
             const bool want = live && x < RANS_LOW;
@@ -269,7 +273,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             const bool take = FAST ? want : (want && cursor + pre < nwords);
             const u32 wlo = __builtin_amdgcn_alignbit(d1, d0, sh), whi = __builtin_amdgcn_alignbit(d2, d1, sh);
             const u32 w2 = (pre & 2u) ? whi : wlo;
-            const u32 w = (w2 >> ((pre & 1u) * 16u)) & 0xffffu;
+            const u32 w = __builtin_amdgcn_ubfe(w2, pre << 4, 16);       // offset is taken mod 32: 16 * (pre & 1)
             u32 xr = (x << 16) | w;
             asm volatile("" : "+v"(xr));                  // keeps the refill arithmetic out of a branch
             x = take ? xr : x;
