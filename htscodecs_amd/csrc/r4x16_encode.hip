@@ -209,6 +209,7 @@ __device__ __forceinline__ u32 chain_encode(gcu8 *data, u32 n, gcu8 *image, u32 
 #define ENC_LRCP_BYTES 16400u        // RCPTAB_ENTRIES dwords, padded to 16
 struct EncOut {
     u8 *ring;            // LDS
+    u32 ring126;         // LDS address of the ring's last word slot
     gu8 *send;           // scratch_end of the stream
     gu8 *dump;           // this lane's 16 bytes of the dump area
     u32 written;         // words emitted by the quad so far
@@ -225,8 +226,8 @@ struct EncOut {
         const bool emit = live && x >= (f << (31u - bits));
         const u32 em = quad_mask_dpp(emit, mybit);
         const u32 j = written + __popc(em >> (k + 1));
-        const u32 slot = emit ? ((~j << 1) & 126u) : 128u;
-        *(u16 *)(ring + slot) = (u16)x;
+        const u32 j63 = emit ? (j & 63u) : ~0u;                          // -1: the dump slot at ring + 128
+        *(LAS u16 *)(unsigned long)(ring126 - 2u * j63) = (u16)x;
         const u32 xs = emit ? x >> 16 : x;
         written += __popc(em);
         // exact x / f: Alverson reciprocal for f >= 2; f == 1 has rcp = 2^32 - 1 and shift 0, which
@@ -290,8 +291,8 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, u8 *ring, 
     const u8 *cumb = img_lds + ENC_IMG_IDX;
     const u32 rs = ns + 1;                                // u16 per context row
     // start | next << 16 of symbol si in context ci: one dword read at a 2-byte aligned LDS address
-    auto pair = [&](u32 ci, u32 si) -> u32 { return *(LAS const u32 *)(cumb + 2u * (ci * rs + si)); };
-    auto rcpof = [&](u32 pk) -> u32 { const u32 f = pk >> 16; return lrcp[f < RCPTAB_ENTRIES ? f : 0u]; };
+    auto pair = [&](u32 ci, u32 si) -> u32 { return *(LAS const u32 *)(cumb + 2u * (__umul24(ci, rs) + si)); };
+    auto rcpof = [&](u32 pk) -> u32 { const u32 f = pk >> 16; return lrcp[f < RCPTAB_ENTRIES - 1u ? f : RCPTAB_ENTRIES - 1u]; };   // (clamp: idle lanes hold garbage)
     // start | next << 16  ->  start | freq << 16 (the empty asm keeps this a shift and a subtract
     // instead of a quarter-rate multiply by 0xFFFF0001)
     auto topk = [&](u32 p) -> u32 { u32 hi = p << 16; asm("" : "+v"(hi)); return p - hi; };
@@ -300,7 +301,7 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, u8 *ring, 
         u32x2 r = {rcpof(pk), pk};
         return r;
     };
-    EncOut o{ring, scratch_end, dump, 0u, 0u, k, 1u << k, active, {0, 0, 0, 0}, dump};
+    EncOut o{ring, (u32)(unsigned long)(LAS u8 *)ring + 126u, scratch_end, dump, 0u, 0u, k, 1u << k, active, {0, 0, 0, 0}, dump};
     u32 x = RANS_LOW;
     const u32 q = active ? n >> 2 : 0;
     const u32 tail = active ? n - 4 * q : 0;
