@@ -104,8 +104,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    # 14336 = 2 full rounds of the decoder's 7168 resident streams (28 per CU), 1.75 of the encoder's 8192
-    ap.add_argument("--blocks", type=int, default=int(os.environ.get("R4X16_BLOCKS", 14336)))
+    # 15360 = 2 full rounds of the decoder's 7680 resident streams (30 per CU); the encoder holds 7936 (31 per CU)
+    ap.add_argument("--blocks", type=int, default=int(os.environ.get("R4X16_BLOCKS", 15360)))
     ap.add_argument("--block-size", type=int, default=1 << 20)
     ap.add_argument("--data", default="q40+dir")
     ap.add_argument("--order", type=int, default=1)

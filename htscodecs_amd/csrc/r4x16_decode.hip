@@ -20,12 +20,18 @@ struct GImg {
     __device__ __forceinline__ u32 ld16(u32 off) const { return *(GAS const u16 *)(p + off); }
     __device__ __forceinline__ u32 ld32(u32 off) const { return *(gcu32 *)(p + off); }
     __device__ __forceinline__ u32x2 ld64(u32 off) const { return *(GAS const u32x2_a4 *)(p + off); }
+    __device__ __forceinline__ u32x2 ld64_now(u32 off) const { return ld64(off); }
 };
 struct LImg {
     u32 base;        // LDS byte address (32-bit arithmetic keeps row addressing to one multiply-add)
     __device__ __forceinline__ u32 ld16(u32 off) const { return *(LAS const u16 *)(unsigned long)(base + off); }
     __device__ __forceinline__ u32 ld32(u32 off) const { return *(LAS const u32 *)(unsigned long)(base + off); }
     __device__ __forceinline__ u32x2 ld64(u32 off) const { return *(LAS const u32x2_a4 *)(unsigned long)(base + off); }
+    // two dwords, read where the source says (volatile: not sunk below later arithmetic or into a branch)
+    __device__ __forceinline__ u32x2 ld64_now(u32 off) const
+    {
+        return *(LAS const volatile u32x2_a4 *)(unsigned long)(base + off);
+    }
 };
 __device__ __forceinline__ u32 lds_addr(const void *p) { return (u32)(unsigned long)(LAS const u8 *)p; }
 
@@ -41,9 +47,20 @@ __device__ __forceinline__ u32 count_le(u32 mmh /* (m | m << 16) | 0x80008000 */
 // One table lookup + state update (rANS_static4x16pr.c:576-579 / :1033-1035) on the search tree
 // described in r4x16_common.h.  `row` is the byte offset of the context's row in the image.
 // Returns the compact symbol index; x becomes freq * (x >> look) + m - start.
+// Order-1, two levels: the next step's root separators depend on the symbol found here, and their
+// LDS round trip is the longest thing between two steps.  The symbol is e or e + 1, and e is known
+// a dozen instructions before the last compare: both candidate roots are requested at that point.
+struct RootSpec {
+    u32 rows, roww;      // in: address of row 0, row stride
+    u32 rowE;            // out: address of row e
+    u32x2 ra, rb;        // out: roots of rows e and e + 1
+    bool up;             // out: the symbol is e + 1
+};
+
 template <int LV, class IMG>
 __device__ __forceinline__ u32 lookup_step(const IMG &img, u32 row, u32 look, u32 mask, u32 &x,
-                                           const u32x2 *root = nullptr /* LV 2: img.ld64(row), read ahead */)
+                                           const u32x2 *root = nullptr /* LV 2: img.ld64(row), read ahead */,
+                                           RootSpec *spec = nullptr)
 {
     const u32 m = x & mask;
     const u32 mm = __umul24(m, 0x10001u) + 0x80008000u;     // m | m << 16 | flags (m < 2^15: no overlap)
@@ -66,15 +83,22 @@ __device__ __forceinline__ u32 lookup_step(const IMG &img, u32 row, u32 look, u3
         const u32 p01 = __builtin_amdgcn_perm(E2, E1, 0x05040100u);     // lo16(E1) | lo16(E2) << 16
         const u32 p23 = __builtin_amdgcn_perm(E4, E3, 0x05040100u);
         const u32 dd = __popc((mm - p01) & 0x80008000u) + __popc((mm - p23) & 0x80008000u);
+        e = 10 * b + 2 * dd;
+        if (spec) {
+            spec->rowE = spec->rows + __umul24(e, spec->roww);
+            spec->ra = img.ld64_now(spec->rowE);
+            spec->rb = img.ld64_now(spec->rowE + spec->roww);
+            __builtin_amdgcn_sched_barrier(0);      // the select chain below must not be scheduled ahead of these reads
+        }
         u32 Ed = E0, En = E1;
         if (dd >= 1) { Ed = E1; En = E2; }
         if (dd >= 2) { Ed = E2; En = E3; }
         if (dd >= 3) { Ed = E3; En = E4; }
         if (dd >= 4) { Ed = E4; En = E5; }
-        e = 10 * b + 2 * dd;
         c0 = Ed & 0xffffu; c1 = Ed >> 16; c2 = En & 0xffffu;
     }
     const bool up = m >= c1;
+    if (spec) spec->up = up;
     const u32 start = up ? c1 : c0;
     const u32 next = up ? c2 : c1;
     x = __umul24(next - start, x >> look) + (m - start);   // freq <= 2^15, x>>look < 2^22: exact mod 2^32
@@ -235,7 +259,10 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             const u32 sh = (cb & 3u) * 8u;
 
             u32 xn = x;
-            const u32 s = lookup_step<LV>(img0, row, look, mask, xn, LV == 2 ? &root : nullptr);
+            RootSpec spec;
+            spec.rows = rows; spec.roww = roww;
+            const bool speculate = ORDER == 1 && LV == 2;
+            const u32 s = lookup_step<LV>(img0, row, look, mask, xn, LV == 2 ? &root : nullptr, speculate ? &spec : nullptr);
             const u32 hn = img.ld16(2 * s);               // byte value | ROW_EMPTY of the new context
             u32 byte0 = 0;
             if (ORDER == 0) {
@@ -257,10 +284,17 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
                         op += 16;
                     }
                 }
-                const u32 rown = rows + __umul24(s, roww);
                 hdr = live ? hn : hdr;
-                row = live ? rown : row;
-                if (LV == 2) root = img0.ld64(row);
+                if (speculate) {
+                    const u32 rown = spec.rowE + (spec.up ? roww : 0u);
+                    const u32x2 rootn = {spec.up ? spec.rb.x : spec.ra.x, spec.up ? spec.rb.y : spec.ra.y};
+                    row = live ? rown : row;
+                    root.x = live ? rootn.x : root.x;
+                    root.y = live ? rootn.y : root.y;
+                } else {
+                    const u32 rown = rows + __umul24(s, roww);
+                    row = live ? rown : row;
+                }
             }
             x = live ? xn : x;
             const bool want = live && x < RANS_LOW;
