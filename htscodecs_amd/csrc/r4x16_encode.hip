@@ -1198,15 +1198,17 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
 // LDS_IMG: a workgroup of up to four waves shares one LDS copy of the reciprocal table; each quad
 // owns lds_per_item bytes (image, then the word ring).  Waves never meet again after the set-up.
 template <bool LDS_IMG>
-__global__ __launch_bounds__(256) void k_enc_chain(EncItem *items, const u32 *rcptab_, u8 *dump_, int nitems, int qpw,
+__global__ __launch_bounds__(256) void k_enc_chain(EncItem *items, const u32 *rcptab_, u8 *dump_, int nitems, int qpw, int spw,
                                                    u32 lds_per_item, u32 cls_lo, u32 cls_hi)
 {
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
     const u32 tid = threadIdx.x;
     const u32 lane = tid & (WAVE - 1);
-    const u32 quad = tid >> 2;
+    // qpw streams per workgroup, spw per wave (the first spw quads of each wave)
+    const u32 wq = lane >> 2;
+    const u32 quad = (tid >> 6) * (u32)spw + wq;
     const int it = (int)blockIdx.x * qpw + (int)quad;
-    const bool mine = quad < (u32)qpw && it < nitems;
+    const bool mine = wq < (u32)spw && quad < (u32)qpw && it < nitems;
     EncItem *I = &items[mine ? it : 0];
     bool active = mine && I->active;
     const u32 img_bytes = active ? I->img_bytes : 0u;
@@ -1237,7 +1239,7 @@ __global__ __launch_bounds__(256) void k_enc_chain(EncItem *items, const u32 *rc
         for (u32 j = tid; j < RCPTAB_ENTRIES; j += blockDim.x) lrcp[j] = rcptab[j];
         // each wave copies the images of its own quads (16-byte pieces)
         const u64 my_img = active ? I->image : 0ull;
-        const u32 wq0 = (tid & ~(WAVE - 1)) >> 2;          // first quad of this wave
+        const u32 wq0 = (tid >> 6) * (u32)spw;             // first stream slot of this wave
         for (u32 qd = 0; qd < WAVE / 4; qd++) {
             const u64 src = __shfl(my_img, (int)qd * 4);
             const u32 nb = __shfl(img_bytes, (int)qd * 4);
@@ -1369,17 +1371,21 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
         once = true;
     }
     u32 lo = 0;
-    static const int force_qpw = getenv("R4X16_ENC_QPW") ? atoi(getenv("R4X16_ENC_QPW")) : 0;   // tuning aid
+    static const int force_qpw = getenv("R4X16_ENC_QPW") ? atoi(getenv("R4X16_ENC_QPW")) : 0;   // tuning aids
+    static const int force_waves = getenv("R4X16_ENC_WAVES") ? atoi(getenv("R4X16_ENC_WAVES")) : 0;
     for (const u32 bytes : ENC_CLASSES) {
         const int qpw = (force_qpw && bytes == 4752) ? force_qpw : enc_class_qpw(bytes);
         const int grid = (nitems + qpw - 1) / qpw;
-        const int threads = WAVE * ((qpw + 15) / 16);
-        hipLaunchKernelGGL(k_enc_chain<true>, dim3(grid), dim3(threads), (size_t)ENC_LRCP_BYTES + (size_t)qpw * bytes, s,
-                           ws->items, ws->rcptab, ws->dump, nitems, qpw, bytes, lo, bytes);
+        int waves = (qpw + 7) / 8;                         // about eight streams per wave measured best (fewer
+        if (waves > 4) waves = 4;                          // lanes per LDS access, one wave per SIMD)
+        if (force_waves && bytes == 4752) waves = force_waves;
+        const int spw = (qpw + waves - 1) / waves;
+        hipLaunchKernelGGL(k_enc_chain<true>, dim3(grid), dim3(WAVE * waves), (size_t)ENC_LRCP_BYTES + (size_t)qpw * bytes, s,
+                           ws->items, ws->rcptab, ws->dump, nitems, qpw, spw, bytes, lo, bytes);
         lo = bytes;
     }
     const int grid = (nitems + 15) / 16;
-    hipLaunchKernelGGL(k_enc_chain<false>, dim3(grid), dim3(WAVE), 0, s, ws->items, ws->rcptab, ws->dump, nitems, 16, 0u, lo, 0xffffffffu);
+    hipLaunchKernelGGL(k_enc_chain<false>, dim3(grid), dim3(WAVE), 0, s, ws->items, ws->rcptab, ws->dump, nitems, 16, 16, 0u, lo, 0xffffffffu);
 }
 extern "C" void r4x16_launch_enc_finish(const BatchArgs *a, const EncWs *ws, int base, int nblk, hipStream_t s)
 {
