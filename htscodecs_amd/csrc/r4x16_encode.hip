@@ -1207,7 +1207,10 @@ __global__ __launch_bounds__(256) void k_enc_chain(EncItem *items, const u32 *rc
     // qpw streams per workgroup, spw per wave (the first spw quads of each wave)
     const u32 wq = lane >> 2;
     const u32 quad = (tid >> 6) * (u32)spw + wq;
-    const int it = (int)blockIdx.x * qpw + (int)quad;
+    // persistent: as many workgroups as are resident at once, each walking its share (see k_dec_chain)
+    const int nwg = (nitems + qpw - 1) / qpw;
+    for (int wg = (int)blockIdx.x; wg < nwg; wg += (int)gridDim.x) {
+    const int it = wg * qpw + (int)quad;
     const bool mine = wq < (u32)spw && quad < (u32)qpw && it < nitems;
     EncItem *I = &items[mine ? it : 0];
     bool active = mine && I->active;
@@ -1224,8 +1227,8 @@ __global__ __launch_bounds__(256) void k_enc_chain(EncItem *items, const u32 *rc
         __syncthreads();
         const u32 any = *flag;
         __syncthreads();
-        if (!any) return;
-    } else if (!wave_any(active)) return;
+        if (!any) continue;
+    } else if (!wave_any(active)) continue;
 
     const u32 order = active ? I->order : 2u;
     gcu32 *rcptab = to_global(rcptab_);
@@ -1262,6 +1265,8 @@ __global__ __launch_bounds__(256) void k_enc_chain(EncItem *items, const u32 *rc
         pay |= chain_encode<0>(data, n, im, ns, bits, rcptab, send, order == 0, lane);
     }
     if (active && (lane & 3) == 0) I->pay_len = pay;
+    if (LDS_IMG) __syncthreads();                          // LDS is reused by the next share
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1363,6 +1368,7 @@ extern "C" void r4x16_launch_enc_tables(const BatchArgs *a, const EncWs *ws, int
 {
     hipLaunchKernelGGL(k_enc_tables, dim3(nblk), dim3(WAVE), TABLES_DYN_LDS, s, *a, *ws, base);
 }
+extern "C" int r4x16_resident_grid(size_t lds_bytes, int waves_per_wg, int wanted);      // r4x16_decode.hip
 extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t s)
 {
     static bool once = false;
@@ -1375,12 +1381,13 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
     static const int force_waves = getenv("R4X16_ENC_WAVES") ? atoi(getenv("R4X16_ENC_WAVES")) : 0;
     for (const u32 bytes : ENC_CLASSES) {
         const int qpw = (force_qpw && bytes == 4752) ? force_qpw : enc_class_qpw(bytes);
-        const int grid = (nitems + qpw - 1) / qpw;
         int waves = (qpw + 7) / 8;                         // about eight streams per wave measured best (fewer
         if (waves > 4) waves = 4;                          // lanes per LDS access, one wave per SIMD)
         if (force_waves && bytes == 4752) waves = force_waves;
         const int spw = (qpw + waves - 1) / waves;
-        hipLaunchKernelGGL(k_enc_chain<true>, dim3(grid), dim3(WAVE * waves), (size_t)ENC_LRCP_BYTES + (size_t)qpw * bytes, s,
+        const size_t ldsb = (size_t)ENC_LRCP_BYTES + (size_t)qpw * bytes;
+        const int grid = r4x16_resident_grid(ldsb, waves, (nitems + qpw - 1) / qpw);
+        hipLaunchKernelGGL(k_enc_chain<true>, dim3(grid), dim3(WAVE * waves), ldsb, s,
                            ws->items, ws->rcptab, ws->dump, nitems, qpw, spw, bytes, lo, bytes);
         lo = bytes;
     }
