@@ -22,6 +22,8 @@ typedef GAS const u32x4 gcu32x4;
 typedef u32 __attribute__((aligned(1))) u32_unaligned;
 typedef u32 u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
 typedef u32 u32x2_unaligned __attribute__((ext_vector_type(2), aligned(1)));
+typedef u64 __attribute__((aligned(1))) u64_unaligned;
+typedef u16 __attribute__((aligned(1))) u16_unaligned;
 #define LAS __attribute__((address_space(3)))                   // LDS
 typedef LAS const volatile u32 lvcu32;          // volatile LDS dword (keep it 4-byte aligned: misaligned LDS reads are slow)
 template <class T> __device__ __forceinline__ GAS T *to_global(T *p) { return (GAS T *)p; }

@@ -762,6 +762,181 @@ __device__ void wave_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end
 }
 
 // ---------------------------------------------------------------------------------------------
+// Workgroup forms of the two transforms (all FRONT_THREADS threads).  The one-wave forms above
+// stay for reference; they were latency-bound (one dependent byte load per 64 bytes: 86 ms for
+// 4,096 x 1 MiB blocks with X_PACK|X_RLE).
+// ---------------------------------------------------------------------------------------------
+// hts_pack, pack.c:56-151.  S.F holds the byte histogram of data[0..n).  Each thread packs 16-byte
+// pieces of the input (2 / 4 / 8 output bytes).  Ends on a workgroup barrier.
+__device__ void wg_pack(const u8 *data, u32 n, u8 *meta, u8 *out, EncShared &S, u32 tid)
+{
+    if (tid == 0) {
+        u32 ns = 0;
+        for (u32 j = 0; j < 256; j++)
+            if (S.F[j]) { S.idx_of[j] = (u8)ns; S.alpha[ns] = (u8)j; ns++; }
+        meta[0] = (u8)ns;                                 // 256 wraps to 0 (pack.c:74)
+        if (ns <= 16) for (u32 j = 0; j < ns; j++) meta[1 + j] = S.alpha[j];
+        S.pk_n = ns;
+        S.pk_meta_len = ns > 16 ? 1 : ns + 1;
+        const u32 per = ns > 16 ? 1 : ns > 4 ? 2 : ns > 2 ? 4 : ns > 1 ? 8 : 0;
+        S.pk_len = ns > 16 ? n : per ? (n + per - 1) / per : 0;
+    }
+    __syncthreads();
+    const u32 ns = S.pk_n;
+    if (ns > 16 || ns <= 1) return;                       // copy case (caller keeps `data`) / constant input
+    const u32 per = ns > 4 ? 2 : ns > 2 ? 4 : 8;
+    const u32 width = 8 / per;
+    const u32 pieces = n >> 4;
+    for (u32 pi = tid; pi < pieces; pi += FRONT_THREADS) {
+        const u32x4 v = *(const u32x4_unaligned *)(data + 16ull * pi);
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+        u64 acc = 0;                                      // 16 symbols of `width` bits, first in the low bits
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const u32 i0 = S.idx_of[w[c] & 0xff], i1 = S.idx_of[(w[c] >> 8) & 0xff],
+                      i2 = S.idx_of[(w[c] >> 16) & 0xff], i3 = S.idx_of[w[c] >> 24];
+            const u64 four = (u64)(i0 | (i1 << width) | (i2 << (2 * width)) | (i3 << (3 * width)));
+            acc |= four << (4 * width * c);
+        }
+        u8 *o = out + (u64)pi * (16 / per);
+        if (per == 2)      *(u64_unaligned *)o = acc;
+        else if (per == 4) *(u32_unaligned *)o = (u32)acc;
+        else               *(u16_unaligned *)o = (u16)acc;
+    }
+    if (tid == 0) {                                       // the last n % 16 bytes
+        const u32 nout = S.pk_len;
+        for (u32 ob = (pieces * 16) / per; ob < nout; ob++) {
+            u32 v = 0;
+            const u32 i0 = ob * per;
+            for (u32 k = 0; k < per && i0 + k < n; k++) v |= (u32)S.idx_of[data[i0 + k]] << (k * width);
+            out[ob] = (u8)v;
+        }
+    }
+    __threadfence();
+    __syncthreads();
+}
+
+// rle_encode with automatic symbol choice, rle.c:48-138.  S.F holds the byte histogram.  The repeat
+// counts are taken by all threads; the back-to-front split is one wave's work (its bookkeeping is
+// serial from trip to trip) but it reads the input from LDS tiles that all threads stage, the next
+// tile travelling from HBM while the current one is swept.  `tiles`: 2 x (RLE_TILE + 32) bytes of LDS.
+// Results as wave_rle_split.  Ends on a workgroup barrier.
+#define RLE_TILE 16384u
+__device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, EncShared &S, u8 *tiles, u32 tid)
+{
+    const u32 lane = tid & (WAVE - 1);
+    u32 *rep = S.T;                                      // repeats per symbol
+    rep[tid] = 0;                                        // FRONT_THREADS == 256
+    __syncthreads();
+    {
+        const u32 pieces = (n + 15) >> 4;
+        for (u32 pi = tid; pi < pieces; pi += FRONT_THREADS) {
+            const u32 off = pi * 16;
+            const u32 cnt = n - off < 16 ? n - off : 16;
+            u32 w[4] = {0, 0, 0, 0};
+            if (cnt == 16) { const u32x4 v = *(const u32x4_unaligned *)(data + off); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+            else for (u32 c = 0; c < cnt; c++) w[c >> 2] |= (u32)data[off + c] << (8 * (c & 3));
+            u32 prev = off ? data[off - 1] : 256u;
+            u32 run = 0;                                  // repeats of `prev` not yet added
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                const u32 cur = (w[c >> 2] >> (8 * (c & 3))) & 0xff;
+                if (c < (int)cnt) {
+                    if (cur == prev) run++;
+                    else { if (run) atomicAdd(&rep[prev], run); run = 0; prev = cur; }
+                }
+            }
+            if (run) atomicAdd(&rep[prev], run);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        u32 ns = 0;
+        for (u32 j = 0; j < 256; j++) {
+            const bool use = 2 * (u64)rep[j] > (u64)S.F[j];
+            S.present[j] = use;
+            if (use) S.alpha[ns++] = (u8)j;
+        }
+        S.rl_nsyms = ns;
+    }
+    __syncthreads();
+
+    // tiles from the top: tile covers data[tb, tt); LDS keeps the 16-byte phase of global memory and
+    // starts one byte early (the predecessor of the tile's first byte)
+    const u32 per_thread = (RLE_TILE + 32) / 16 / FRONT_THREADS + 1;     // 16-byte chunks per thread (5)
+    u32x4 stage[per_thread];
+    auto tile_bounds = [&](u32 k, u32 &tb, u32 &tt) { tt = n - k * RLE_TILE; tb = tt > RLE_TILE ? tt - RLE_TILE : 0; };
+    auto tile_fetch = [&](u32 k) {                        // global -> registers
+        u32 tb, tt; tile_bounds(k, tb, tt);
+        const u64 lo = (u64)(data + tb) - (tb ? 1 : 0);
+        const u64 a0 = lo & ~15ull, a1 = ((u64)(data + tt) + 15) & ~15ull;
+        const u32 chunks = (u32)((a1 - a0) >> 4);
+#pragma unroll
+        for (u32 c = 0; c < per_thread; c++) {
+            const u32 ci = tid + c * FRONT_THREADS;
+            u32x4 v = {0, 0, 0, 0};
+            if (ci < chunks) v = *(const u32x4 *)(a0 + 16ull * ci);       // aligned; stays inside the 16-byte
+            stage[c] = v;                                                 // granules the block touches
+        }
+    };
+    auto tile_store = [&](u8 *buf) {                      // registers -> LDS
+#pragma unroll
+        for (u32 c = 0; c < per_thread; c++) {
+            const u32 ci = tid + c * FRONT_THREADS;
+            if (ci < (RLE_TILE + 32) / 16) *(u32x4 *)(buf + 16 * ci) = stage[c];
+        }
+    };
+    const u32 ntiles = (n + RLE_TILE - 1) / RLE_TILE;
+    u8 *bufs[2] = {tiles, tiles + RLE_TILE + 32};
+    tile_fetch(0);
+    tile_store(bufs[0]);
+    __syncthreads();
+
+    u32 next_lit = n, nl = 0, nrb = 0;
+    for (u32 k = 0; k < ntiles; k++) {
+        if (k + 1 < ntiles) tile_fetch(k + 1);
+        if (tid < WAVE) {
+            u32 tb, tt; tile_bounds(k, tb, tt);
+            const u64 lo = (u64)(data + tb) - (tb ? 1 : 0);
+            // LDS address of data[i]: buf + (address of data[i] - a0)
+            const u8 *img = bufs[k & 1] + (u32)(lo & 15ull) - tb + (tb ? 1 : 0);
+            for (u32 top = tt; top > tb; ) {
+                const u32 base = top - tb > WAVE ? top - WAVE : tb;
+                const u32 cnt = top - base;
+                const u32 i = base + lane;
+                const bool valid = lane < cnt;
+                const u32 cur = valid ? img[i] : 0u;
+                const u32 prev = (valid && i > 0) ? img[i - 1] : 256u;
+                const bool isl = valid && !(S.present[cur] && cur == prev);
+                const u64 L = __ballot(isl);
+                const u64 above = lane == WAVE - 1 ? 0ull : (L >> (lane + 1));
+                const u32 nxt = above ? i + (u32)__ffsll((unsigned long long)above) : next_lit;
+                const bool isr = isl && S.present[cur];
+                const u32 run = nxt - i - 1;
+                const u32 vl = isr ? var_len(run) : 0u;
+                u32 suf = vl;                             // bytes of run varints of the lanes above (suffix sum)
+#pragma unroll
+                for (int dd = 1; dd < WAVE; dd <<= 1) {
+                    const u32 t2 = __shfl_down(suf, dd);
+                    if (lane + (u32)dd < WAVE) suf += t2;
+                }
+                if (isl) lits_end[-(long)(nl + (u32)__popcll(above) + 1)] = (u8)cur;
+                if (isr) var_put(runs_end - (nrb + suf), run);
+                nl += (u32)__popcll(L);
+                nrb += __shfl(suf, 0);
+                if (L) next_lit = base + (u32)__ffsll((unsigned long long)L) - 1;
+                top = base;
+            }
+        }
+        if (k + 1 < ntiles) tile_store(bufs[(k + 1) & 1]);
+        __syncthreads();
+    }
+    if (tid == 0) { S.rl_lits = nl; S.rl_runs = nrb; }
+    __threadfence();
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_enc_front
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ double approx_log(double a)            // fast_log :620-623
@@ -796,9 +971,8 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
     u8 *scratch = ws.scratch + (u64)b * ws.scratch_stride;
     u8 *scratch_end = scratch + ws.scratch_stride;
 
-    if (w0) do {
     // ---- container header (:1144-1237) ---------------------------------------------------------
-    if (lane == 0) {
+    if (tid == 0) {
         H.run = 0;
         ws.stat[b].run = 0;
         I0->active = 0; I1->active = 0; I0->pay_len = 0; I1->pay_len = 0;
@@ -829,9 +1003,11 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
         D->status = st;
         H.status = st; H.go = go;
     }
-    wsync();
-    if (H.status != ST_OK || !H.go) break;
+    __syncthreads();
+    if (H.status != ST_OK || !H.go) return;
 
+    // From here to the histograms every branch depends on shared values only (uniform over the
+    // workgroup); the transforms use all four waves, the rest is wave 0 between barriers.
     const u8 *data = in;
     u32 n = in_size;
     u32 flags = H.flags, hl = H.hl;
@@ -841,16 +1017,16 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
         if (n == 0) flags &= ~(u32)X_PACK;
         else {
             u8 *pbuf = ws.packed + (u64)b * ws.xf_stride;
-            wave_hist8(data, n, S.F, lane);
-            wave_pack(data, n, D->hdr + hl, pbuf, S, lane);
-            wsync();
+            wg_hist8(data, n, S.F, (u32 *)dyn, tid);
+            wg_pack(data, n, D->hdr + hl, pbuf, S, tid);
             if (S.pk_meta_len == 1 && S.pk_n != 256) flags &= ~(u32)X_PACK;    // > 16 symbols (:1249); 256 wraps to 0 and stays
             else {
                 if (S.pk_n <= 16) data = pbuf;
                 n = S.pk_len;
                 hl += S.pk_meta_len;
-                if (lane == 0) H.hl = hl + var_put(D->hdr + hl, n);
-                wsync();
+                __syncthreads();
+                if (tid == 0) H.hl = hl + var_put(D->hdr + hl, n);
+                __syncthreads();
                 hl = H.hl;
             }
         }
@@ -862,36 +1038,36 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
         else {
             u8 *lits_end = ws.lits + (u64)b * ws.xf_stride + ws.xf_stride;
             u8 *meta_end = ws.meta + (u64)b * (ws.xf_stride + 768) + (ws.xf_stride + 768);
-            __threadfence();
-            wsync();
-            wave_hist8(data, n, S.F, lane);
-            wave_rle_split(data, n, lits_end, meta_end, S, lane);
+            wg_hist8(data, n, S.F, (u32 *)dyn, tid);
+            wg_rle_split(data, n, lits_end, meta_end, S, dyn, tid);
             const u32 nsy = S.rl_nsyms, nlits = S.rl_lits, nruns = S.rl_runs;
             const u32 mlen = nruns + nsy + 1;                              // :1282-1285
             if ((double)((u64)nlits + mlen) >= .99 * (double)n) {          // :1287
                 flags &= ~(u32)X_RLE;
             } else {
                 u8 *m = meta_end - mlen;
-                if (lane == 0) m[0] = (u8)nsy;
-                for (u32 j = lane; j < nsy; j += WAVE) m[1 + j] = S.alpha[j];
+                if (tid == 0) m[0] = (u8)nsy;
+                if (tid < nsy) m[1 + tid] = S.alpha[tid];                  // nsy <= 256 == FRONT_THREADS
                 __threadfence();
-                wsync();
+                __syncthreads();
                 // the meta is coded as an order-0 stream by the chain kernel (item I1)
                 u8 *mtab = ws.metatab + (u64)b * META_TAB_BYTES;
                 u8 *imgm = img + ENC_IMG_META;
-                enc_o0_front(m, mlen, mtab, imgm, S, lane);
-                if (lane == 0) {
-                    D->rle_on = 1; D->rle_mlen = mlen; D->rle_lits = nlits;
-                    D->rle_meta = (u64)m; D->meta_tab = (u64)mtab; D->meta_tab_len = S.tab_len;
-                    if (S.status != ST_OK) D->status = S.status;
-                    I1->data = (u64)m; I1->n = mlen; I1->image = (u64)imgm; I1->bits = O0_BITS; I1->order = 0;
-                    I1->ns = 256; I1->img_bytes = ENC_IMG_IDX + 2u * 257u;
-                    I1->scratch_end = (u64)(ws.scratch2 + (u64)b * ws.scratch2_stride + ws.scratch2_stride);
-                    __threadfence();
-                    I1->active = S.status == ST_OK;
+                if (w0) {
+                    enc_o0_front(m, mlen, mtab, imgm, S, lane);
+                    if (lane == 0) {
+                        D->rle_on = 1; D->rle_mlen = mlen; D->rle_lits = nlits;
+                        D->rle_meta = (u64)m; D->meta_tab = (u64)mtab; D->meta_tab_len = S.tab_len;
+                        if (S.status != ST_OK) D->status = S.status;
+                        I1->data = (u64)m; I1->n = mlen; I1->image = (u64)imgm; I1->bits = O0_BITS; I1->order = 0;
+                        I1->ns = 256; I1->img_bytes = ENC_IMG_IDX + 2u * 257u;
+                        I1->scratch_end = (u64)(ws.scratch2 + (u64)b * ws.scratch2_stride + ws.scratch2_stride);
+                        __threadfence();
+                        I1->active = S.status == ST_OK;
+                    }
                 }
-                wsync();
-                if (S.status != ST_OK) break;
+                __syncthreads();
+                if (S.status != ST_OK) return;
                 data = lits_end - nlits;
                 n = nlits;
             }
@@ -901,19 +1077,20 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
     {
         u32 o = order & 1;
         if (o && n < 8) { flags &= ~1u; o = 0; }                           // :1322-1325
-        if (lane == 0) {
+        __syncthreads();
+        if (tid == 0) {
             D->flags = flags; D->hdr[0] = (u8)flags; D->hdr_len = hl;
             D->data = (u64)data; D->dlen = n;
             H.order = o; H.data = (u64)data; H.dlen = n;
             H.run = n != 0;
         }
     }
-    } while (0);
+    __threadfence();
     __syncthreads();                                                      // all four waves meet here
     if (!H.run) return;
 
-    const u8 *data = (const u8 *)H.data;
-    const u32 n = H.dlen;
+    data = (const u8 *)H.data;
+    n = H.dlen;
 
     // pass 1 over the block: byte histogram (hist8 / present8, utils.h:80-131), all waves
     wg_hist8(data, n, S.F, (u32 *)dyn, tid);
