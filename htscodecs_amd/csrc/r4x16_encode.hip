@@ -899,7 +899,7 @@ __device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, 
             u32 tb, tt; tile_bounds(k, tb, tt);
             const u64 lo = (u64)(data + tb) - (tb ? 1 : 0);
             // LDS address of data[i]: buf + (address of data[i] - a0)
-            const u8 *img = bufs[k & 1] + (u32)(lo & 15ull) - tb + (tb ? 1 : 0);
+            LAS const u8 *img = (LAS const u8 *)bufs[k & 1] + (u32)(lo & 15ull) - tb + (tb ? 1 : 0);
             for (u32 top = tt; top > tb; ) {
                 const u32 base = top - tb > WAVE ? top - WAVE : tb;
                 const u32 cnt = top - base;
@@ -914,16 +914,19 @@ __device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, 
                 const bool isr = isl && S.present[cur];
                 const u32 run = nxt - i - 1;
                 const u32 vl = isr ? var_len(run) : 0u;
-                u32 suf = vl;                             // bytes of run varints of the lanes above (suffix sum)
+                // bytes of run varints of this lane and the lanes above it (suffix sum), from ballots of
+                // "at least k bytes" (a shuffle scan goes through the LDS crossbar six times per trip)
+                u32 suf = vl, tot = 0;
 #pragma unroll
-                for (int dd = 1; dd < WAVE; dd <<= 1) {
-                    const u32 t2 = __shfl_down(suf, dd);
-                    if (lane + (u32)dd < WAVE) suf += t2;
+                for (u32 kk = 1; kk <= 5; kk++) {
+                    const u64 mk = __ballot(vl >= kk);
+                    suf += lane == WAVE - 1 ? 0u : (u32)__popcll(mk >> (lane + 1));
+                    tot += (u32)__popcll(mk);
                 }
                 if (isl) lits_end[-(long)(nl + (u32)__popcll(above) + 1)] = (u8)cur;
                 if (isr) var_put(runs_end - (nrb + suf), run);
                 nl += (u32)__popcll(L);
-                nrb += __shfl(suf, 0);
+                nrb += tot;
                 if (L) next_lit = base + (u32)__ffsll((unsigned long long)L) - 1;
                 top = base;
             }
