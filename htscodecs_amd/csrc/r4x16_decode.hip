@@ -1122,7 +1122,8 @@ extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t 
     u32 lo3 = 0, lo4 = 0;                                  // each tree depth walks its own classes from 0
     static const int force_qpw = getenv("R4X16_DEC_QPW") ? atoi(getenv("R4X16_DEC_QPW")) : 0;   // tuning aid
     for (const auto &c : DEC_CLASSES) {
-        const int qpw = (force_qpw && c.bytes == 5264) ? force_qpw : c.qpw;
+        static const int force_small = getenv("R4X16_DEC_QPW_SMALL") ? atoi(getenv("R4X16_DEC_QPW_SMALL")) : 0;
+        const int qpw = (force_qpw && c.bytes == 5264) ? force_qpw : (force_small && c.bytes < 5264) ? force_small : c.qpw;
         const size_t ldsb = (size_t)qpw * c.bytes;
         const int grid = r4x16_resident_grid(ldsb, 1, (nitems + qpw - 1) / qpw);
         if (c.lv == 2) {

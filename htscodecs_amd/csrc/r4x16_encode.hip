@@ -425,6 +425,112 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, u8 *ring, 
     return o.finish(x);
 }
 
+// Hot form, order-0, for the chain kernel: the same software pipeline as chain_encode_o1_lds over
+// the one-row image (:442-459: step s codes group g = gtop - s, chain k takes byte 4g + k; the top
+// group may be partial).  A trip of four steps covers four whole groups = 16 contiguous bytes, of
+// which this lane uses byte k of each dword.
+__device__ __forceinline__ u32 chain_encode_o0_pipe(const u8 *img_lds, u8 *ring, const u32 *lrcp, gcu8 *data, u32 n,
+                                                    u32 bits, gcu8 *safe, gu8 *scratch_end, gu8 *dump, bool active, u32 lane)
+{
+    const u32 k = lane & 3;
+    const u8 *idx = img_lds;
+    const u8 *cumb = img_lds + ENC_IMG_IDX;
+    auto pair = [&](u32 si) -> u32 { return *(LAS const u32 *)(cumb + 2u * si); };
+    auto rcpof = [&](u32 pk) -> u32 { const u32 f = pk >> 16; return lrcp[f < RCPTAB_ENTRIES - 1u ? f : RCPTAB_ENTRIES - 1u]; };
+    auto topk = [&](u32 p) -> u32 { u32 hi = p << 16; asm("" : "+v"(hi)); return p - hi; };
+    auto fetch = [&](u32 si) -> u32x2 {
+        const u32 pk = topk(pair(si));
+        u32x2 r = {rcpof(pk), pk};
+        return r;
+    };
+    EncOut o{ring, (u32)(unsigned long)(LAS u8 *)ring + 126u, scratch_end, dump, 0u, 0u, k, 1u << k, active, {0, 0, 0, 0}, dump};
+    u32 x = RANS_LOW;
+    const u32 Q = active ? n >> 2 : 0;                    // whole groups
+    const u32 rem = active ? n & 3u : 0;                  // bytes of the partial top group
+
+    // (A) the partial top group: chains k < rem code byte 4Q + k
+    if (wave_any(rem != 0)) {
+        const bool live = k < rem;
+        u32 rcp = 0, pk = 0;
+        if (live) { const u32x2 e = fetch(idx[data[4 * Q + k]]); rcp = e.x; pk = e.y; }
+        o.step(x, live, rcp, pk, bits);
+    }
+
+    // (B) whole groups Q-1 .. 0; trip t covers groups Q-1-4t .. Q-4-4t = bytes [4 (Q-4t-4), 4 (Q-4t))
+    const u32 npair = Q >> 3;                             // double trips
+    const u32 ntrip = 2 * npair;
+    if (wave_any(npair > 0)) {
+        struct DT { u32x4 a, b; };                        // the pieces of trips 2j and 2j+1
+        auto load_dt = [&](u32 j) -> DT {
+            gcu8 *p = j < npair ? data + 4ull * (Q - 8 * j) - 32 : safe;
+            DT r = {*(GAS const u32x4_unaligned *)(p + 16), *(GAS const u32x4_unaligned *)p};
+            return r;
+        };
+        struct I4 { u32 c0, c1, c2, c3; };
+        const u32 sh = 8 * k;
+        auto idx4 = [&](u32x4 v) -> I4 {                  // steps run from the highest group (v.w) down
+            I4 r = {idx[(v.w >> sh) & 0xff], idx[(v.z >> sh) & 0xff], idx[(v.y >> sh) & 0xff], idx[(v.x >> sh) & 0xff]};
+            return r;
+        };
+        auto cum4 = [&](const I4 &c) -> u32x4 {
+            u32x4 r = {pair(c.c0), pair(c.c1), pair(c.c2), pair(c.c3)};
+            return r;
+        };
+        auto topk4 = [&](u32x4 p) -> u32x4 {
+            u32x4 r = {topk(p.x), topk(p.y), topk(p.z), topk(p.w)};
+            return r;
+        };
+        auto rcp4 = [&](u32x4 p) -> u32x4 {
+            u32x4 r = {rcpof(p.x), rcpof(p.y), rcpof(p.z), rcpof(p.w)};
+            return r;
+        };
+        I4 I2;
+        u32x4 P0, Praw, R0;
+        DT Q0, Q1, Q2, Q3;                                // piece pair j lives in Q[j % 4]
+        {
+            Q0 = load_dt(0); Q1 = load_dt(1); Q2 = load_dt(2); Q3 = load_dt(3);
+            const I4 i0 = idx4(Q0.a), i1 = idx4(Q0.b);
+            I2 = idx4(Q1.a);
+            P0 = topk4(cum4(i0));
+            Praw = cum4(i1);
+            R0 = rcp4(P0);
+        }
+        u32 t = 0;
+        auto trip = [&](u32x4 wnext3) {
+            const bool live = t < ntrip;
+            const I4 In = idx4(wnext3);                   // bytes of trip t+3
+            const u32x4 Pn = cum4(I2);                    // pairs of trip t+2
+            const u32x4 P1 = topk4(Praw);                 // trip t+1, read during the previous trip
+            const u32x4 Rn = rcp4(P1);
+            __builtin_amdgcn_sched_barrier(0);
+            o.step(x, live, R0.x, P0.x, bits);
+            o.step(x, live, R0.y, P0.y, bits);
+            o.step(x, live, R0.z, P0.z, bits);
+            o.step(x, live, R0.w, P0.w, bits);
+            I2 = In; P0 = P1; Praw = Pn; R0 = Rn;
+            t++;
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        for (u32 d = 0; wave_any(d < npair); d += 4) {
+            Q0 = load_dt(d + 4); o.flush_pipelined(); trip(Q1.b); trip(Q2.a);
+            Q1 = load_dt(d + 5); o.flush_pipelined(); trip(Q2.b); trip(Q3.a);
+            Q2 = load_dt(d + 6); o.flush_pipelined(); trip(Q3.b); trip(Q0.a);
+            Q3 = load_dt(d + 7); o.flush_pipelined(); trip(Q0.b); trip(Q1.a);
+        }
+        o.flush_drain();
+        o.flush();
+    }
+    // (B') the groups below the pipelined trips, one step each
+    for (u32 g = Q - 4 * ntrip; wave_any(g > 0); ) {
+        const bool live = g > 0;
+        u32 rcp = 0, pk = 0;
+        if (live) { g--; const u32x2 e = fetch(idx[data[4 * g + k]]); rcp = e.x; pk = e.y; }
+        o.step(x, live, rcp, pk, bits);
+        o.flush();
+    }
+    return o.finish(x);
+}
+
 // Hot form, order-0: one row of entries in LDS; chain k takes bytes 4g+k for descending g.
 template <class DP>     // DP: gcu8* (stream in HBM) or const u8* (small stream staged in LDS)
 __device__ __forceinline__ u32 chain_encode_o0_lds(const u8 *img_lds, DP data, u32 n, u32 bits,
@@ -1438,7 +1544,7 @@ __global__ __launch_bounds__(256) void k_enc_chain(EncItem *items, const u32 *rc
         u8 *ring = slots + (u64)slot * lds_per_item + (lds_per_item - ENC_RING_BYTES);
         gu8 *dump = to_global(dump_) + 16u * ((blockIdx.x * blockDim.x + tid) & (ENC_DUMP_BYTES / 16u - 1u));
         pay = chain_encode_o1_lds(im, ring, lrcp, data, n, ns, bits, (gcu8 *)rcptab, send, dump, order == 1, lane);
-        pay |= chain_encode_o0_lds(im, data, n, bits, rcptab, send, order == 0, lane);
+        pay |= chain_encode_o0_pipe(im, ring, lrcp, data, n, bits, (gcu8 *)rcptab, send, dump, order == 0, lane);
     } else {
         gcu8 *im = (gcu8 *)I->image;
         pay = chain_encode<1>(data, n, im, ns, bits, rcptab, send, order == 1, lane);
@@ -1542,7 +1648,8 @@ static int enc_class_qpw(u32 bytes)
 {
     const u32 room = 163840u - ENC_LRCP_BYTES;
     const u32 fit = room / bytes;
-    return (int)(fit > 64 ? 64 : fit);
+    static const int cap = getenv("R4X16_ENC_QPW_CAP") ? atoi(getenv("R4X16_ENC_QPW_CAP")) : 64;   // tuning aid
+    return (int)(fit > (u32)cap ? (u32)cap : fit);
 }
 extern "C" void r4x16_launch_enc_tables(const BatchArgs *a, const EncWs *ws, int base, int nblk, hipStream_t s)
 {
