@@ -34,17 +34,34 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 
 def build_batch(torch, dev, name, nblk, blk_size, first_block):
     """nblk blocks of the cyclic repetition of base text `name`, built in HBM: block b
-    is bytes [b*S, (b+1)*S) of the infinitely repeated text (what `rans4x16pr -t` sees on a tiled file)."""
+    is bytes [b*S, (b+1)*S) of the infinitely repeated text (what `rans4x16pr -t` sees on a tiled file).
+    `mixed` cycles q4, q8, q40+dir by b mod 3 (BASELINE.json configs[4])."""
     import datagen
-    base = datagen.base_text(name)
-    total = nblk * blk_size
-    start = (first_block * blk_size) % len(base)
-    reps = (start + total + len(base) - 1) // len(base) + 1
-    d_base = torch.from_numpy(np.ascontiguousarray(base)).to(dev)
-    d_in = d_base.repeat(reps)[start:start + total].contiguous()
+    names = ["q4", "q8", "q40+dir"] if name == "mixed" else [name]
+    per = (nblk + len(names) - 1) // len(names)
+    parts = []
+    for nm in names:
+        base = datagen.base_text(nm)
+        total = per * blk_size
+        start = (first_block * blk_size) % len(base)
+        reps = (start + total + len(base) - 1) // len(base) + 1
+        d_base = torch.from_numpy(np.ascontiguousarray(base)).to(dev)
+        parts.append(d_base.repeat(reps)[start:start + total].view(per, blk_size))
+    if len(parts) == 1:
+        d_in = parts[0].reshape(-1)[:nblk * blk_size].contiguous()
+    else:
+        d_in = torch.stack(parts, dim=1).reshape(-1)[:nblk * blk_size].contiguous()   # block b <- text b % 3
     in_off = torch.arange(nblk, dtype=torch.int64, device=dev) * blk_size
     in_size = torch.full((nblk,), blk_size, dtype=torch.int32, device=dev)
     return d_in, in_off, in_size
+
+
+def block_bytes(name, blk_size, b, first_block=0):
+    """Host copy of block b of build_batch(name, ..., first_block)."""
+    import datagen
+    if name == "mixed":
+        return np.ascontiguousarray(datagen.tile(["q4", "q8", "q40+dir"][b % 3], blk_size, first_block + b // 3))
+    return np.ascontiguousarray(datagen.tile(name, blk_size, first_block + b))
 
 
 def cpu_baseline(order, blk_size, name, seconds_target=12.0):
@@ -57,7 +74,7 @@ def cpu_baseline(order, blk_size, name, seconds_target=12.0):
         lib, kind = cpu_libs.oracle(), "port"
     # one GPU's share of the host is 16 cores on the bench pool; never oversubscribe beyond that
     cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("R4X16_CPU_THREADS", 16)))
-    blocks = [np.ascontiguousarray(datagen.tile(name, blk_size, b)) for b in range(cores)]
+    blocks = [block_bytes(name, blk_size, b) for b in range(cores)]
     cap = lib.bound(blk_size, order)
 
     def one(idx, reps):
@@ -182,7 +199,7 @@ def main():
         import datagen
         chk = cpu_libs.reference() or cpu_libs.oracle()
         for b in (0, nblk // 2, nblk - 1):
-            want = chk.compress(datagen.tile(args.data, bs, rank * nblk + b).tobytes(), order)
+            want = chk.compress(block_bytes(args.data, bs, b, rank * nblk).tobytes(), order)
             got = d_comp[b * slot:b * slot + int(csz[b])].cpu().numpy().tobytes()
             assert got == want, f"block {b}: device stream differs from the CPU reference"
 
