@@ -682,7 +682,7 @@ __device__ void enc_o0_front(const u8 *data, u32 n, u8 *tab, u8 *image, EncShare
 
 // `priv`: 16 x 256 scratch counters; threads spread over 16 private copies (tid & 15) so that the
 // few hot symbols of quality data do not serialise the LDS atomics of a whole wave.
-__device__ void wg_hist8(const u8 *data, u32 n, u32 *Fout, u32 *priv, u32 tid)
+__device__ __forceinline__ void wg_hist8(const u8 *data, u32 n, u32 *Fout, u32 *priv, u32 tid)
 {
     for (u32 j = tid; j < 4096; j += FRONT_THREADS) priv[j] = 0;
     __syncthreads();
@@ -718,7 +718,7 @@ __device__ void wg_hist8(const u8 *data, u32 n, u32 *Fout, u32 *priv, u32 tid)
 // Fp0 points at `copies` x ns*ns zeroed counters (LDS, or global with copies == 1); threads spread
 // over the copies by tid, and the copies are summed into the first one at the end.
 template <class FP>
-__device__ void wg_hist1(const u8 *data, u32 n, FP Fp0, u32 ns, u32 copies, const u8 *idx_of, u32 tid)
+__device__ __forceinline__ void wg_hist1(const u8 *data, u32 n, FP Fp0, u32 ns, u32 copies, const u8 *idx_of, u32 tid)
 {
     FP Fp = Fp0 + (tid & (copies - 1)) * ns * ns;
     const u32 pieces = (n + 15) >> 4;
