@@ -4,7 +4,7 @@
 # tools/summarize_trace.py and tools/pmc_traffic.py, then copy the summaries into profiles/.
 set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/refresh
+O=$R/gpurun_out/refresh   # (delete the local copy first: gpurun merges new files into it)
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
