@@ -214,9 +214,13 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     gcu8 *abase = (gcu8 *)((u64)words & ~15ull);
     const u32 off0 = (u32)((u64)words & 15ull);
     const u32 avail = off0 + words_len;                   // bytes of abase[] that belong to the input
-    auto load_chunk = [&](u32 c) -> u32x4 {               // 16-byte chunk c, zeros past the input
+    // 16-byte chunk c of the stream; past the input the last chunk repeats (those ring bytes are never
+    // taken: the fast trips stop 16 words before the end and the others check every word against nwords)
+    const u32 lastc = avail ? (avail - 1u) >> 4 : 0u;
+    const bool loadable = active && avail != 0;
+    auto load_chunk = [&](u32 c) -> u32x4 {
         u32x4 v = {0, 0, 0, 0};
-        if (active && c * 16u < avail) v = *(gcu32x4 *)(abase + (u64)c * 16u);
+        if (loadable) v = *(gcu32x4 *)(abase + 16ull * (c < lastc ? c : lastc));
         return v;
     };
     if (active) {
