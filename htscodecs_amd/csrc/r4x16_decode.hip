@@ -182,7 +182,8 @@ __device__ __forceinline__ u32 chain_decode(IMG img, u32 nsym, gcu8 *words, u32 
 //     wave issues one store per four symbols instead of four.
 // LDS per stream: image, then RING_BYTES.
 // ---------------------------------------------------------------------------------------------
-#define RING_BYTES 144u      // 128-byte ring + 8-byte mirror of its head (+8 pad)
+#define RING_BYTES 272u      // 256-byte ring (four 64-byte quarters) + 8-byte mirror of its head (+8 pad)
+#define TRIP_STEPS 8         // steps per loop trip: at most 64 bytes of words, one quarter of the ring
 
 typedef u32 GAS __attribute__((aligned(1))) gu32_unaligned;   // global dword store at any byte address
 
@@ -223,14 +224,17 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
         if (loadable) v = *(gcu32x4 *)(abase + 16ull * (c < lastc ? c : lastc));
         return v;
     };
+    // Quarters h, h+1, h+2 of the stream are in the ring while the cursor is in quarter h (a trip moves it
+    // by at most 64 bytes and reads 12 bytes ahead); quarter h+3 waits in `pend` for the next crossing.
     if (active) {
-        const u32x4 c0 = load_chunk(k), c1 = load_chunk(k + 4);
+        const u32x4 c0 = load_chunk(k), c1 = load_chunk(k + 4), c2 = load_chunk(k + 8);
         *(u32x4 *)(ring + 16 * k) = c0;
         *(u32x4 *)(ring + 64 + 16 * k) = c1;
-        if (k == 0) *(u32x2 *)(ring + 128) = c0.xy;
+        *(u32x4 *)(ring + 128 + 16 * k) = c2;
+        if (k == 0) *(u32x2 *)(ring + 256) = c0.xy;
     }
-    u32x4 pend = load_chunk(8 + k);                       // half 2, written at the first crossing
-    u32 half = 0;                                         // index of the 64-byte half holding the cursor
+    u32x4 pend = load_chunk(12 + k);
+    u32 half = 0;                                         // index of the 64-byte quarter holding the cursor
     __syncthreads();
 
     u32 row = rows, cursor = 0, bad = 0, t = 0;
@@ -248,12 +252,13 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     auto trip = [&](auto fastc) {
         constexpr bool FAST = decltype(fastc)::value;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const bool live = FAST ? true : (t + u) < count;
+        for (int u = 0; u < TRIP_STEPS; u++) {
+            const u32 T = t + (u32)u;                     // index of this step
+            const bool live = FAST ? true : T < count;
             // next four candidate words (8 bytes at any byte alignment) from the ring; issued
             // before the table lookups so that their latency hides under them
             const u32 cb = off0 + 2 * cursor;
-            const u32 ra = cb & 124u;
+            const u32 ra = cb & 252u;
             // Three ALIGNED dwords and a funnel shift: a dword read at a misaligned LDS address costs far
             // more than the extra read (measured: +12 % on the whole kernel per misaligned read and step).
             // (volatile: keeps the compiler from sinking these reads into a branch, which would put their
@@ -275,14 +280,14 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
                 // the byte of the symbol decoded one step ago and the flags of the row in use now
                 if (u > 0 || t > 0) {
                     bad |= live ? hdr : 0u;               // ROW_EMPTY bit is tested after the loop
-                    acc = (FAST || t + u <= count) ? __builtin_amdgcn_alignbit(hdr, acc, 8) : acc;
+                    acc = (FAST || T <= count) ? __builtin_amdgcn_alignbit(hdr, acc, 8) : acc;
                 }
                 // symbols t-4 .. t-1 are now in acc, oldest in the low byte: queue the dword, and every
                 // fourth trip store 16 bytes at once (4-byte stores to 16 different lines per wave made
                 // the L2 write each line to HBM 3.5 times over; see profiles/)
-                if (u == 0 && t >= 4 && (FAST || t <= count)) {
+                if ((u & 3) == 0 && T >= 4 && (FAST || T <= count)) {
                     a0 = a1; a1 = a2; a2 = a3; a3 = acc;
-                    if ((t & 15u) == 0 && active) {
+                    if (u == 0 && (t & 15u) == 0 && active) {       // t is a multiple of TRIP_STEPS: T % 16 == 0 only at u == 0
                         const u32x4 v = {a0, a1, a2, a3};
                         *(GAS u32x4_unaligned *)op = v;
                         op += 16;
@@ -322,26 +327,26 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
                 const u32 b1 = quad_bcast1(byte0), b2 = quad_bcast2(byte0), b3 = quad_bcast3(byte0);
                 const u32 l3 = FAST ? 1u : quad_bcast3(live ? 1u : 0u);
                 const u32 dw = byte0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-                if (l3) { if (k == 0 && active) *(gu32_unaligned *)(op + 4 * (u64)(t + u)) = dw; }
-                else if (live) op[4 * (u64)(t + u)] = (u8)byte0;
+                if (l3) { if (k == 0 && active) *(gu32_unaligned *)(op + 4 * (u64)T) = dw; }
+                else if (live) op[4 * (u64)T] = (u8)byte0;
             }
         }
-        t += 4;
+        t += TRIP_STEPS;
     };
     while (wave_any(t < count)) {
-        const bool slow = active && (t + 4 > count || cursor + 16 > nwords);
+        const bool slow = active && (t + TRIP_STEPS > count || cursor + 4 * TRIP_STEPS > nwords);
         if (!wave_any(slow)) trip(std::true_type{});
         else trip(std::false_type{});
 
-        // ring refill when the cursor has entered a new 64-byte half (at most 32 bytes ago)
+        // ring refill when the cursor has entered a new 64-byte quarter (at most 64 bytes ago)
         const u32 nh = (off0 + 2 * cursor) >> 6;
         if (wave_any(active && nh != half)) {
             if (active && nh != half) {                   // idle lanes hold garbage cursors: they must not write LDS
-                // half `nh+1` was requested at the previous crossing: park it in the slots just vacated
-                const u32 slot = ((nh + 1) & 1u) * 64u + 16u * k;
+                // quarter `nh+2` was requested at the previous crossing: park it in the slots just vacated
+                const u32 slot = ((nh + 2) & 3u) * 64u + 16u * k;
                 *(u32x4 *)(ring + slot) = pend;
-                if (slot == 0) *(u32x2 *)(ring + 128) = pend.xy;
-                pend = load_chunk(4 * (nh + 2) + k);
+                if (slot == 0) *(u32x2 *)(ring + 256) = pend.xy;
+                pend = load_chunk(4 * (nh + 3) + k);
                 half = nh;
             }
             __syncthreads();
@@ -1089,7 +1094,7 @@ extern "C" void r4x16_launch_dec_front(const BatchArgs *a, const DecWs *ws, int 
 // images at least 21 KB (or the lone 1.3 KB row of a large order-0 alphabet), so the two groups of
 // classes are walked separately.
 static const struct { u32 bytes; int qpw; int lv; } DEC_CLASSES[] = {
-    {656, 16, 2}, {1296, 16, 2}, {2576, 16, 2}, {3856, 16, 2}, {5008, 16, 2}, {5264, 10, 2}, {5392, 15, 2}, {6416, 12, 2},
+    {656, 16, 2}, {1296, 16, 2}, {2576, 16, 2}, {3856, 16, 2}, {5008, 16, 2}, {5360, 10, 2}, {5392, 15, 2}, {6416, 12, 2},
     {22528, 1, 4}, {32768, 1, 4}, {53248, 1, 4}, {81920, 1, 4}, {163840, 1, 4},
 };
 // workgroups of `lds_bytes` each that one CU holds at once (1,280-byte LDS granules, 32 wave slots)
@@ -1127,7 +1132,7 @@ extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t 
     static const int force_qpw = getenv("R4X16_DEC_QPW") ? atoi(getenv("R4X16_DEC_QPW")) : 0;   // tuning aid
     for (const auto &c : DEC_CLASSES) {
         static const int force_small = getenv("R4X16_DEC_QPW_SMALL") ? atoi(getenv("R4X16_DEC_QPW_SMALL")) : 0;
-        const int qpw = (force_qpw && c.bytes == 5264) ? force_qpw : (force_small && c.bytes < 5264) ? force_small : c.qpw;
+        const int qpw = (force_qpw && c.bytes == 5360) ? force_qpw : (force_small && c.bytes < 5360) ? force_small : c.qpw;
         const size_t ldsb = (size_t)qpw * c.bytes;
         const int grid = r4x16_resident_grid(ldsb, 1, (nitems + qpw - 1) / qpw);
         if (c.lv == 2) {
