@@ -198,7 +198,6 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     const u32 rows = lds_addr(img_lds) + img_alpha_bytes(nsym), roww = img_row_bytes(nsym);
     const u32 nwords = words_len >> 1;
     const u32 below = (1u << k) - 1u;                      // quad lanes below this one
-    const u32 mybit = 1u << k;
     u32 count;
     gu8 *op;                                               // next output byte of this chain
     if (ORDER == 0) {
@@ -311,7 +310,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             // renormalise: chains refill in order 0..3 from the shared cursor.  After the first
             // refusal (stream exhausted) no later request can succeed either, so the cursor may
             // simply advance by the number of requests (rANS_word.h:402-410).
-            const u32 wm = quad_mask_dpp(want, mybit);
+            const u32 wm = quad_ballot(want, lane);
             const u32 pre = __popc(wm & below);
             const bool take = FAST ? want : (want && cursor + pre < nwords);
             const u32 wlo = __builtin_amdgcn_alignbit(d1, d0, sh), whi = __builtin_amdgcn_alignbit(d2, d1, sh);

@@ -122,19 +122,12 @@ __device__ __forceinline__ u32 quad_bcast1(u32 v) { return dpp_mov<QP(1, 1, 1, 1
 __device__ __forceinline__ u32 quad_bcast2(u32 v) { return dpp_mov<QP(2, 2, 2, 2)>(v); }
 __device__ __forceinline__ u32 quad_bcast3(u32 v) { return dpp_mov<QP(3, 3, 3, 3)>(v); }
 
-// 4-bit mask of a predicate over this lane's quad without leaving the vector unit: each lane
-// contributes its own bit (bit = 1 << (lane & 3)) and two DPP quad_perm ORs spread them.
-__device__ __forceinline__ u32 quad_mask_dpp(bool p, u32 mybit)
-{
-    u32 v = p ? mybit : 0u;
-    v |= dpp_mov<QP(1, 0, 3, 2)>(v);
-    v |= dpp_mov<QP(2, 3, 0, 1)>(v);
-    return v;
-}
-
 typedef u16 u16x2 __attribute__((ext_vector_type(2)));
 
-// For a per-lane predicate: 4-bit mask of the predicate over this lane's quad.
+// For a per-lane predicate: 4-bit mask of the predicate over this lane's quad.  The compare writes a
+// scalar pair, one 64-bit shift by the quad's first lane and one `and` bring it back: three
+// instructions.  (Two DPP quad_perm ORs on a per-lane bit measured 2-5 % slower in the hot loops:
+// more instructions, and each DPP read of a just-written register costs two wait states.)
 __device__ __forceinline__ u32 quad_ballot(bool p, u32 lane)
 {
     u64 m = __ballot(p);

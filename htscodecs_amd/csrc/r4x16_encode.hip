@@ -214,7 +214,7 @@ struct EncOut {
     gu8 *dump;           // this lane's 16 bytes of the dump area
     u32 written;         // words emitted by the quad so far
     u32 flushed;         // 64-byte halves already read out of the ring
-    u32 k, mybit;
+    u32 k, lane;
     bool active;
     u32x4 held;          // a half read out of the ring, stored one double-trip later
     gu8 *held_dst;
@@ -224,7 +224,7 @@ struct EncOut {
     {
         const u32 f = pk >> 16, start = pk & 0xffffu;
         const bool emit = live && x >= (f << (31u - bits));
-        const u32 em = quad_mask_dpp(emit, mybit);
+        const u32 em = quad_ballot(emit, lane);
         const u32 j = written + __popc(em >> (k + 1));
         const u32 j63 = emit ? (j & 63u) : ~0u;                          // -1: the dump slot at ring + 128
         *(LAS u16 *)(unsigned long)(ring126 - 2u * j63) = (u16)x;
@@ -301,7 +301,7 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, u8 *ring, 
         u32x2 r = {rcpof(pk), pk};
         return r;
     };
-    EncOut o{ring, (u32)(unsigned long)(LAS u8 *)ring + 126u, scratch_end, dump, 0u, 0u, k, 1u << k, active, {0, 0, 0, 0}, dump};
+    EncOut o{ring, (u32)(unsigned long)(LAS u8 *)ring + 126u, scratch_end, dump, 0u, 0u, k, lane, active, {0, 0, 0, 0}, dump};
     u32 x = RANS_LOW;
     const u32 q = active ? n >> 2 : 0;
     const u32 tail = active ? n - 4 * q : 0;
@@ -443,7 +443,7 @@ __device__ __forceinline__ u32 chain_encode_o0_pipe(const u8 *img_lds, u8 *ring,
         u32x2 r = {rcpof(pk), pk};
         return r;
     };
-    EncOut o{ring, (u32)(unsigned long)(LAS u8 *)ring + 126u, scratch_end, dump, 0u, 0u, k, 1u << k, active, {0, 0, 0, 0}, dump};
+    EncOut o{ring, (u32)(unsigned long)(LAS u8 *)ring + 126u, scratch_end, dump, 0u, 0u, k, lane, active, {0, 0, 0, 0}, dump};
     u32 x = RANS_LOW;
     const u32 Q = active ? n >> 2 : 0;                    // whole groups
     const u32 rem = active ? n & 3u : 0;                  // bytes of the partial top group
@@ -537,7 +537,6 @@ __device__ __forceinline__ u32 chain_encode_o0_lds(const u8 *img_lds, DP data, u
                                                    gcu32 *rcptab, gu8 *scratch_end, bool active, u32 lane)
 {
     const u32 k = lane & 3;
-    const u32 mybit = 1u << k;
     const u8 *idx = img_lds;
     const u16 *cum = (const u16 *)(img_lds + ENC_IMG_IDX);
     u32 x = RANS_LOW, written = 0;
@@ -553,7 +552,7 @@ __device__ __forceinline__ u32 chain_encode_o0_lds(const u8 *img_lds, DP data, u
         const u32x2 e = {enc_rcp(rcptab, c1 - c0), c0 | ((c1 - c0) << 16)};
         const u32 nb = (live && p >= 4) ? data[p - 4] : 0u;          // next group's byte, a step ahead
         const bool emit = live && enc_wants_emit(x, e.y, bits);
-        const u32 em = quad_mask_dpp(emit, mybit);
+        const u32 em = quad_ballot(emit, lane);
         if (emit) {
             const u32 above = __popc(em >> (k + 1));
             *(gu16 *)(scratch_end - 2 * (written + above + 1)) = (u16)x;
