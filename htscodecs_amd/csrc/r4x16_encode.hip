@@ -223,21 +223,24 @@ struct EncOut {
     __device__ __forceinline__ void step(u32 &x, bool live, u32 rcp, u32 pk, u32 bits)
     {
         const u32 f = pk >> 16, start = pk & 0xffffu;
-        const bool emit = live && x >= (f << (31u - bits));
-        const u32 em = quad_ballot(emit, lane);
+        // the compare's own lane mask, and-ed with the live lanes on the scalar side (a ballot of the
+        // combined predicate would be rebuilt through a select and a second compare)
+        const bool over = x >= (f << (31u - bits));
+        const u64 m = __ballot(over) & __ballot(live);
+        const u32 em = (u32)(m >> (lane & ~3u)) & 0xfu;
+        const bool emit = live && over;
         const u32 j = written + __popc(em >> (k + 1));
         const u32 j63 = emit ? (j & 63u) : ~0u;                          // -1: the dump slot at ring + 128
         *(LAS u16 *)(unsigned long)(ring126 - 2u * j63) = (u16)x;
         const u32 xs = emit ? x >> 16 : x;
         written += __popc(em);
         // exact x / f: Alverson reciprocal for f >= 2; f == 1 has rcp = 2^32 - 1 and shift 0, which
-        // gives x - 1, and the missing (M - 1) is added to the bias (rANS_word.h:232-240 does the same)
+        // gives x - 1: the compare's carry puts the 1 back (an add-with-carry, no select)
         const u32 fm1 = f - 1u;
         const u32 rsh = 31u - (u32)__clz((int)(fm1 | 1u));
-        const u32 q = __umulhi(xs, rcp) >> rsh;
+        const u32 q = (__umulhi(xs, rcp) >> rsh) + (fm1 == 0u ? 1u : 0u);
         const u32 cmpl = (1u << bits) - f;
-        const u32 bias = start + (fm1 ? 0u : cmpl);
-        const u32 xn = __umul24(q, cmpl) + (xs + bias);
+        const u32 xn = __umul24(q, cmpl) + (xs + start);
         x = live ? xn : xs;
     }
     // conditional form: copy out the half that has just been completed, if any
