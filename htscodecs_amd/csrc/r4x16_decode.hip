@@ -40,8 +40,9 @@ __device__ __forceinline__ u32 lds_addr(const void *p) { return (u32)(unsigned l
 // (m | 0x8000) - sep cannot borrow from its neighbour and keeps bit 15 exactly when sep <= m.
 __device__ __forceinline__ u32 count_le(u32 mmh /* (m | m << 16) | 0x80008000 */, u32x2 v)
 {
-    const u32 vx = v.x, vy = v.y;
-    return __popc((mmh - vx) & 0x80008000u) + __popc((mmh - vy) & 0x80008000u);
+    // the four flag bits sit in bytes 1 and 3 of the two differences: one byte permute gathers them
+    const u32 g = __builtin_amdgcn_perm(mmh - v.y, mmh - v.x, 0x07050301u);
+    return __popc(g & 0x80808080u);
 }
 
 // One table lookup + state update (rANS_static4x16pr.c:576-579 / :1033-1035) on the search tree
@@ -82,7 +83,7 @@ __device__ __forceinline__ u32 lookup_step(const IMG &img, u32 row, u32 look, u3
         // even-ranked entries 2,4,6,8 of the group are its inner separators
         const u32 p01 = __builtin_amdgcn_perm(E2, E1, 0x05040100u);     // lo16(E1) | lo16(E2) << 16
         const u32 p23 = __builtin_amdgcn_perm(E4, E3, 0x05040100u);
-        const u32 dd = __popc((mm - p01) & 0x80008000u) + __popc((mm - p23) & 0x80008000u);
+        const u32 dd = __popc(__builtin_amdgcn_perm(mm - p23, mm - p01, 0x07050301u) & 0x80808080u);
         e = 10 * b + 2 * dd;
         if (spec) {
             spec->rowE = spec->rows + __umul24(e, spec->roww);
