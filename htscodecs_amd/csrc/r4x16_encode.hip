@@ -686,9 +686,10 @@ __device__ void enc_o0_front(const u8 *data, u32 n, u8 *tab, u8 *image, EncShare
 // few hot symbols of quality data do not serialise the LDS atomics of a whole wave.
 __device__ __forceinline__ void wg_hist8(const u8 *data, u32 n, u32 *Fout, u32 *priv, u32 tid)
 {
-    for (u32 j = tid; j < 4096; j += FRONT_THREADS) priv[j] = 0;
+    // (copy stride 257 dwords: each copy starts one LDS bank further; with 256 all sixteen sat on the same banks)
+    for (u32 j = tid; j < 16 * 257; j += FRONT_THREADS) priv[j] = 0;
     __syncthreads();
-    u32 *F = priv + 256 * (tid & 15);
+    u32 *F = priv + 257 * (tid & 15);
     u32 head = (u32)((16 - ((u64)data & 15)) & 15);
     if (head > n) head = n;
     if (tid < head) atomicAdd(&F[data[tid]], 1u);
@@ -711,7 +712,7 @@ __device__ __forceinline__ void wg_hist8(const u8 *data, u32 n, u32 *Fout, u32 *
     {
         u32 t = 0;
 #pragma unroll
-        for (int c = 0; c < 16; c++) t += priv[256 * c + tid];
+        for (int c = 0; c < 16; c++) t += priv[257 * c + tid];
         Fout[tid] = t;                                   // FRONT_THREADS == 256
     }
     __syncthreads();
@@ -719,10 +720,14 @@ __device__ __forceinline__ void wg_hist8(const u8 *data, u32 n, u32 *Fout, u32 *
 
 // Fp0 points at `copies` x ns*ns zeroed counters (LDS, or global with copies == 1); threads spread
 // over the copies by tid, and the copies are summed into the first one at the end.
+// counters of one copy: ns*ns, padded so that the copies start eight LDS banks apart
+__device__ __forceinline__ u32 hist1_copy_stride(u32 ns, u32 copies) { return copies > 1 ? ((ns * ns + 31u) & ~31u) + 8u : ns * ns; }
+
 template <class FP>
 __device__ __forceinline__ void wg_hist1(const u8 *data, u32 n, FP Fp0, u32 ns, u32 copies, const u8 *idx_of, u32 tid)
 {
-    FP Fp = Fp0 + (tid & (copies - 1)) * ns * ns;
+    const u32 cs = hist1_copy_stride(ns, copies);
+    FP Fp = Fp0 + (tid & (copies - 1)) * cs;
     const u32 pieces = (n + 15) >> 4;
     for (u32 pi = tid; pi < pieces; pi += FRONT_THREADS) {
         const u32 off = pi * 16;
@@ -756,7 +761,7 @@ __device__ __forceinline__ void wg_hist1(const u8 *data, u32 n, FP Fp0, u32 ns, 
     if (copies > 1) {
         for (u32 j = tid; j < ns * ns; j += FRONT_THREADS) {
             u32 t = Fp0[j];
-            for (u32 c = 1; c < copies; c++) t += Fp0[c * ns * ns + j];
+            for (u32 c = 1; c < copies; c++) t += Fp0[c * cs + j];
             Fp0[j] = t;
         }
         __syncthreads();
@@ -1227,8 +1232,8 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
     const u32 ns = S.nsym;
     const bool f_in_lds = ns <= FRONT_LDS_NSYM;
     u32 *Fg = ws.F + (u64)b * 65536u;
-    const u32 copies = !f_in_lds ? 1u : (16u * ns * ns <= FRONT_DYN_LDS ? 4u : (8u * ns * ns <= FRONT_DYN_LDS ? 2u : 1u));
-    if (f_in_lds) { for (u32 j = tid; j < copies * ns * ns; j += FRONT_THREADS) ((u32 *)dyn)[j] = 0; }
+    const u32 copies = !f_in_lds ? 1u : (16u * hist1_copy_stride(ns, 4) <= FRONT_DYN_LDS ? 4u : (8u * hist1_copy_stride(ns, 2) <= FRONT_DYN_LDS ? 2u : 1u));
+    if (f_in_lds) { for (u32 j = tid; j < copies * hist1_copy_stride(ns, copies); j += FRONT_THREADS) ((u32 *)dyn)[j] = 0; }
     else          { for (u32 j = tid; j < ns * ns; j += FRONT_THREADS) Fg[j] = 0; }
     __syncthreads();
     // pass 2 over the block: order-1 pair histogram, all waves
