@@ -690,13 +690,16 @@ __device__ __forceinline__ void wg_hist8(const u8 *data, u32 n, u32 *Fout, u32 *
     for (u32 j = tid; j < 16 * 257; j += FRONT_THREADS) priv[j] = 0;
     __syncthreads();
     u32 *F = priv + 257 * (tid & 15);
-    u32 head = (u32)((16 - ((u64)data & 15)) & 15);
-    if (head > n) head = n;
-    if (tid < head) atomicAdd(&F[data[tid]], 1u);
-    const u32 body = (n - head) >> 4;
-    const uint4 *v = (const uint4 *)(data + head);
-    for (u32 i = tid; i < body; i += FRONT_THREADS) {
-        const uint4 w = v[i];
+    // 16-byte pieces, four in flight per thread (each is requested three pieces before it is counted: the
+    // passes are memory-latency bound otherwise, eight waves per CU cannot hide an HBM round trip per piece)
+    const u32 full = n >> 4;
+    auto ld = [&](u32 pi) -> u32x4 {
+        u32x4 v = {0, 0, 0, 0};
+        if (pi < full) v = *(const u32x4_unaligned *)(data + 16ull * pi);
+        return v;
+    };
+    auto count = [&](u32x4 w, u32 pi) {
+        if (pi >= full) return;
         const u32 ww[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
         for (int c = 0; c < 4; c++) {
@@ -705,8 +708,16 @@ __device__ __forceinline__ void wg_hist8(const u8 *data, u32 n, u32 *Fout, u32 *
             atomicAdd(&F[(ww[c] >> 16) & 0xff], 1u);
             atomicAdd(&F[ww[c] >> 24], 1u);
         }
+    };
+    const u32 T = FRONT_THREADS;
+    u32x4 q0 = ld(tid), q1 = ld(tid + T), q2 = ld(tid + 2 * T), q3 = ld(tid + 3 * T);
+    for (u32 pi = tid; pi < full; pi += 4 * T) {
+        count(q0, pi);         q0 = ld(pi + 4 * T);
+        count(q1, pi + T);     q1 = ld(pi + 5 * T);
+        count(q2, pi + 2 * T); q2 = ld(pi + 6 * T);
+        count(q3, pi + 3 * T); q3 = ld(pi + 7 * T);
     }
-    const u32 done = head + body * 16;
+    const u32 done = full * 16;
     if (done + tid < n) atomicAdd(&F[data[done + tid]], 1u);
     __syncthreads();
     {
@@ -728,30 +739,44 @@ __device__ __forceinline__ void wg_hist1(const u8 *data, u32 n, FP Fp0, u32 ns, 
 {
     const u32 cs = hist1_copy_stride(ns, copies);
     FP Fp = Fp0 + (tid & (copies - 1)) * cs;
-    const u32 pieces = (n + 15) >> 4;
-    for (u32 pi = tid; pi < pieces; pi += FRONT_THREADS) {
-        const u32 off = pi * 16;
-        const u32 cnt = (n - off < 16) ? n - off : 16;
+    // 16-byte pieces with the byte before them, four in flight per thread (see wg_hist8)
+    const u32 full = n >> 4;
+    struct Piece { u32x4 w; u32 before; };
+    auto ld = [&](u32 pi) -> Piece {
+        Piece p = {{0, 0, 0, 0}, 0};
+        if (pi < full) { p.w = *(const u32x4_unaligned *)(data + 16ull * pi); p.before = pi ? data[16ull * pi - 1] : 0u; }
+        return p;
+    };
+    auto count = [&](const Piece &p, u32 pi) {
+        if (pi >= full) return;
+        const u32 ww[4] = {p.w.x, p.w.y, p.w.z, p.w.w};
         u32 ci[16];                                  // compact indices of this thread's bytes
-        if (cnt == 16 && ((u64)(data + off) & 3) == 0) {
-            const u32 *w = (const u32 *)(data + off);
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const u32 ww = w[c];
-                ci[4 * c] = idx_of[ww & 0xff]; ci[4 * c + 1] = idx_of[(ww >> 8) & 0xff];
-                ci[4 * c + 2] = idx_of[(ww >> 16) & 0xff]; ci[4 * c + 3] = idx_of[ww >> 24];
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 16; c++) ci[c] = (c < (int)cnt) ? idx_of[data[off + c]] : 0u;
+        for (int c = 0; c < 4; c++) {
+            ci[4 * c] = idx_of[ww[c] & 0xff]; ci[4 * c + 1] = idx_of[(ww[c] >> 8) & 0xff];
+            ci[4 * c + 2] = idx_of[(ww[c] >> 16) & 0xff]; ci[4 * c + 3] = idx_of[ww[c] >> 24];
         }
-        u32 prev = off ? idx_of[data[off - 1]] : 0u;     // the first byte of the block is seen in context 0
+        u32 prev = pi ? idx_of[p.before] : 0u;       // the first byte of the block is seen in context 0
 #pragma unroll
         for (int c = 0; c < 16; c++) {
-            if (c < (int)cnt) {
-                atomicAdd(&Fp[prev * ns + ci[c]], 1u);
-                prev = ci[c];
-            }
+            atomicAdd(&Fp[prev * ns + ci[c]], 1u);
+            prev = ci[c];
+        }
+    };
+    const u32 T = FRONT_THREADS;
+    Piece q0 = ld(tid), q1 = ld(tid + T), q2 = ld(tid + 2 * T), q3 = ld(tid + 3 * T);
+    for (u32 pi = tid; pi < full; pi += 4 * T) {
+        count(q0, pi);         q0 = ld(pi + 4 * T);
+        count(q1, pi + T);     q1 = ld(pi + 5 * T);
+        count(q2, pi + 2 * T); q2 = ld(pi + 6 * T);
+        count(q3, pi + 3 * T); q3 = ld(pi + 7 * T);
+    }
+    if (tid == 0) {                                  // the last n % 16 bytes
+        u32 prev = full ? idx_of[data[16 * full - 1]] : 0u;
+        for (u32 i = 16 * full; i < n; i++) {
+            const u32 cur = idx_of[data[i]];
+            atomicAdd(&Fp[(i ? prev : 0u) * ns + cur], 1u);
+            prev = cur;
         }
     }
     __syncthreads();
