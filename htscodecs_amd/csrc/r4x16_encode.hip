@@ -537,7 +537,8 @@ __device__ __forceinline__ u32 chain_encode_o0_pipe(const u8 *img_lds, u8 *ring,
 // Hot form, order-0: one row of entries in LDS; chain k takes bytes 4g+k for descending g.
 template <class DP>     // DP: gcu8* (stream in HBM) or const u8* (small stream staged in LDS)
 __device__ __forceinline__ u32 chain_encode_o0_lds(const u8 *img_lds, DP data, u32 n, u32 bits,
-                                                   gcu32 *rcptab, gu8 *scratch_end, bool active, u32 lane)
+                                                   gcu32 *rcptab, gu8 *scratch_end, bool active, u32 lane,
+                                                   const u32 *rcp_by_sym = nullptr /* LDS: reciprocal per compact symbol */)
 {
     const u32 k = lane & 3;
     const u8 *idx = img_lds;
@@ -552,7 +553,7 @@ __device__ __forceinline__ u32 chain_encode_o0_lds(const u8 *img_lds, DP data, u
         const bool live = s >= first && s < nsteps;
         const u32 si = idx[byte];
         const u32 c0 = cum[si], c1 = cum[si + 1];
-        const u32x2 e = {enc_rcp(rcptab, c1 - c0), c0 | ((c1 - c0) << 16)};
+        const u32x2 e = {rcp_by_sym ? rcp_by_sym[si] : enc_rcp(rcptab, c1 - c0), c0 | ((c1 - c0) << 16)};
         const u32 nb = (live && p >= 4) ? data[p - 4] : 0u;          // next group's byte, a step ahead
         const bool emit = live && enc_wants_emit(x, e.y, bits);
         const u32 em = quad_ballot(emit, lane);
@@ -1277,7 +1278,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
 // ---------------------------------------------------------------------------------------------
 #define TABLES_DYN_LDS 10240u          // pair counters of alphabets up to 50 symbols; later the nested coder
 #define TABLES_LDS_NSYM 50u
-#define TABLES_NEST_MAX 9216u          // nested table bytes that fit next to a 1,024-byte image
+#define TABLES_NEST_MAX 8192u          // nested table bytes that fit next to a 1,024-byte image and 256 reciprocals
 
 __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int base)
 {
@@ -1456,6 +1457,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
             // the counters in `dyn` are spent: reuse the space for the table bytes and the coder's
             // one-row image, so that the 4-lane coder of this small stream never leaves the CU
             u8 *ltab = dyn, *limg = dyn + TABLES_NEST_MAX;
+            u32 *lrcp = (u32 *)(dyn + TABLES_NEST_MAX + ENC_IMG_O0);
             __threadfence();
             wsync();
             wave_copy(ltab, tabraw, tlen, lane);
@@ -1463,8 +1465,14 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
             enc_o0_front(ltab, tlen, ntab, limg, S, lane);
             __threadfence();
             wsync();
+            {   // reciprocals of the row's 256 slots, fetched together (the 4-lane coder would fetch one per
+                // step from L2, each a dependent round trip)
+                const u16 *c = (const u16 *)(limg + ENC_IMG_IDX);
+                for (u32 j = lane; j < 256; j += WAVE) lrcp[j] = enc_rcp(to_global(ws.rcptab), (u32)c[j + 1] - (u32)c[j]);
+                wsync();
+            }
             npay = chain_encode_o0_lds(limg, (const u8 *)ltab, tlen, O0_BITS, to_global(ws.rcptab),
-                                       to_global(scratch_end), lane < 4, lane);
+                                       to_global(scratch_end), lane < 4, lane, lrcp);
         } else {
             u8 *img0 = img + ENC_IMG_NESTED;
             enc_o0_front(tabraw, tlen, ntab, img0, S, lane);
