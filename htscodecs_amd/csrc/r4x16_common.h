@@ -53,6 +53,11 @@ typedef int32_t  i32;
 //                            24 bytes cum[10b .. 10b+11] brings the whole group into registers and the
 //                            rest is register work (a packed compare of the even-ranked entries, two
 //                            select chains).  Rows are ~112 bytes for 46 symbols.
+//       3 reads (n <= 150):  top   : cum[30], cum[60], cum[90], cum[120]               (8 bytes)
+//                            mid a : cum[30a+6], cum[30a+12], cum[30a+18], cum[30a+24]   (a = 0..4, 8 bytes each)
+//                            leaf  : cum[0 .. n+7]; the group's window cum[30a+6b .. 30a+6b+7] is one
+//                                    16-byte read, its entries of rank 2 and 4 are the inner separators.
+//                            Half the size of the 4-level rows for text-like alphabets (~100 symbols).
 //       4 levels (n <= 256): top   : cum[50], cum[100], .., cum[400]                  (8 separators)
 //                            mid a : cum[50a+10], .., cum[50a+40]                        (a = 0..5)
 //                            low ab: cum[50a+10b+2], .., cum[50a+10b+8]                 (30 nodes)
@@ -69,9 +74,9 @@ typedef int32_t  i32;
 // decoder's throughput is made of (each stream is only four dependent chains wide).
 // ---------------------------------------------------------------------------------------------
 #define ROW_EMPTY 0x100u
-static inline __host__ __device__ u32 img_levels(u32 n) { return n <= 50 ? 2u : 4u; }
+static inline __host__ __device__ u32 img_levels(u32 n) { return n <= 50 ? 2u : n <= 150 ? 3u : 4u; }
 static inline __host__ __device__ u32 img_alpha_bytes(u32 n) { return (2u * n + 15u) & ~15u; }
-static inline __host__ __device__ u32 img_leaf_off(u32 lv) { return lv == 2 ? 8u : 304u; }
+static inline __host__ __device__ u32 img_leaf_off(u32 lv) { return lv == 2 ? 8u : lv == 3 ? 48u : 304u; }
 // u16 entries of the cumulative array.  Two levels: group b is read as the six dwords cum[10b .. 10b+11];
 // the last dword of the LAST group is only ever looked at when n is a multiple of ten (otherwise no
 // symbol of rank 10b+9 exists), so it is left out then and that read runs into whatever follows
@@ -79,6 +84,7 @@ static inline __host__ __device__ u32 img_leaf_off(u32 lv) { return lv == 2 ? 8u
 // of a 45-symbol alphabet fit a wave's share of LDS.
 static inline __host__ __device__ u32 img_leaf_len(u32 n)
 {
+    if (img_levels(n) == 3) return (n + 9u) & ~1u;       // cum[0 .. n+7]: the last group's window of eight
     if (img_levels(n) != 2) return n + 4u;
     const u32 q = (n - 1u) / 10u;
     return n % 10u == 0 ? 10u * q + 12u : 10u * q + 10u;
@@ -86,6 +92,7 @@ static inline __host__ __device__ u32 img_leaf_len(u32 n)
 // rows are 4-byte aligned (two levels) or 8-byte aligned (four levels)
 static inline __host__ __device__ u32 img_row_bytes(u32 n)
 {
+    if (img_levels(n) == 3) return 48u + 2u * img_leaf_len(n);
     return img_levels(n) == 2 ? 8u + 2u * img_leaf_len(n) : (304u + 2u * img_leaf_len(n) + 7u) & ~7u;
 }
 static inline __host__ __device__ u32 img_bytes(u32 n, u32 rows) { return img_alpha_bytes(n) + rows * img_row_bytes(n); }

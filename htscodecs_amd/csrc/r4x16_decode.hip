@@ -66,7 +66,19 @@ __device__ __forceinline__ u32 lookup_step(const IMG &img, u32 row, u32 look, u3
     const u32 m = x & mask;
     const u32 mm = __umul24(m, 0x10001u) + 0x80008000u;     // m | m << 16 | flags (m < 2^15: no overlap)
     u32 e, c0, c1, c2;
-    if (LV == 4) {
+    if (LV == 3) {
+        const u32 a = count_le(mm, img.ld64(row));
+        const u32 b = count_le(mm, img.ld64(row + 8 + 8 * a));
+        const u32 g = row + 48u + 60u * a + 12u * b;
+        const u32 E0 = img.ld32(g), E1 = img.ld32(g + 4), E2 = img.ld32(g + 8), E3 = img.ld32(g + 12);
+        const u32 p12 = __builtin_amdgcn_perm(E2, E1, 0x05040100u);     // cum[e0+2] | cum[e0+4] << 16
+        const u32 dd = __popc((mm - p12) & 0x80008000u);
+        u32 Ed = E0, En = E1;
+        if (dd >= 1) { Ed = E1; En = E2; }
+        if (dd >= 2) { Ed = E2; En = E3; }
+        e = 30 * a + 6 * b + 2 * dd;
+        c0 = Ed & 0xffffu; c1 = Ed >> 16; c2 = En & 0xffffu;
+    } else if (LV == 4) {
         const u32 a = count_le(mm, img.ld64(row)) + count_le(mm, img.ld64(row + 8));
         const u32 b = count_le(mm, img.ld64(row + 16 + 8 * a));
         const u32 dd = count_le(mm, img.ld64(row + 64 + 8 * (5 * a + b)));
@@ -457,6 +469,13 @@ __device__ void write_row(u8 *rowp, const FrontShared &S, u32 n, bool empty, u32
         if (lane < 4) w[lane] = N(10 * (lane + 1));
         const u32 len = img_leaf_len(n);
         for (u32 t = lane; t < len; t += WAVE) w[4 + t] = C(t);
+    } else if (lv == 3) {
+        if (lane < 24) {
+            const u32 t = lane;
+            w[t] = t < 4 ? N(30 * (t + 1)) : N(30 * ((t - 4) >> 2) + 6 * (((t - 4) & 3) + 1));
+        }
+        const u32 len = img_leaf_len(n);
+        for (u32 t = lane; t < len; t += WAVE) w[24 + t] = C(t);
     } else {
         for (u32 t = lane; t < 152; t += WAVE) {
             u16 v;
@@ -734,7 +753,10 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
         o0_front(src, H.tab_pos, H.csz, H.usz, nimg, S, lane);
         if (S.status != ST_OK) { if (lane == 0) D->status = S.status; return; }
         u8 *nring = nimg + IMG_O0_BYTES;
-        if (img_levels(S.nsym) == 2)
+        if (img_levels(S.nsym) == 3)
+            chain_decode_lds<0, 3>(nimg, S.nsym, nring, to_global(in + S.words_pos), H.tab_pos + H.csz - S.words_pos,
+                                   to_global(tbuf), H.usz, S.R[lane & 3], O0_BITS, lane < 4, lane);
+        else if (img_levels(S.nsym) == 2)
             chain_decode_lds<0, 2>(nimg, S.nsym, nring, to_global(in + S.words_pos), H.tab_pos + H.csz - S.words_pos,
                                    to_global(tbuf), H.usz, S.R[lane & 3], O0_BITS, lane < 4, lane);
         else
@@ -1095,6 +1117,10 @@ extern "C" void r4x16_launch_dec_front(const BatchArgs *a, const DecWs *ws, int 
 // classes are walked separately.
 static const struct { u32 bytes; int qpw; int lv; } DEC_CLASSES[] = {
     {656, 16, 2}, {1296, 16, 2}, {2576, 16, 2}, {3856, 16, 2}, {5008, 16, 2}, {5360, 10, 2}, {5392, 15, 2}, {6416, 12, 2},
+    // 51..150 symbols, 3 reads: one-row order-0 images, then order-1 images of 9..55 KB (one stream per wave,
+    // as many waves per CU as LDS granules allow)
+    {1296, 16, 3}, {10256, 1, 3}, {12816, 1, 3}, {16656, 1, 3}, {20496, 1, 3}, {25616, 1, 3}, {32016, 1, 3},
+    {40976, 1, 3}, {53648, 1, 3}, {64016, 1, 3},
     {22528, 1, 4}, {32768, 1, 4}, {53248, 1, 4}, {81920, 1, 4}, {163840, 1, 4},
 };
 // workgroups of `lds_bytes` each that one CU holds at once (1,280-byte LDS granules, 32 wave slots)
@@ -1125,30 +1151,27 @@ extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t 
     static bool once = false;
     if (!once) {
         (void)hipFuncSetAttribute((const void *)k_dec_chain<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void *)k_dec_chain<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         (void)hipFuncSetAttribute((const void *)k_dec_chain<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         once = true;
     }
-    u32 lo3 = 0, lo4 = 0;                                  // each tree depth walks its own classes from 0
-    static const int force_qpw = getenv("R4X16_DEC_QPW") ? atoi(getenv("R4X16_DEC_QPW")) : 0;   // tuning aid
+    u32 lo[5] = {0, 0, 0, 0, 0};                           // each tree depth walks its own classes from 0
+    static const int force_qpw = getenv("R4X16_DEC_QPW") ? atoi(getenv("R4X16_DEC_QPW")) : 0;   // tuning aids
+    static const int force_small = getenv("R4X16_DEC_QPW_SMALL") ? atoi(getenv("R4X16_DEC_QPW_SMALL")) : 0;
     for (const auto &c : DEC_CLASSES) {
-        static const int force_small = getenv("R4X16_DEC_QPW_SMALL") ? atoi(getenv("R4X16_DEC_QPW_SMALL")) : 0;
-        const int qpw = (force_qpw && c.bytes == 5360) ? force_qpw : (force_small && c.bytes < 5360) ? force_small : c.qpw;
+        const int qpw = c.lv != 2 ? c.qpw : (force_qpw && c.bytes == 5360) ? force_qpw : (force_small && c.bytes < 5360) ? force_small : c.qpw;
         const size_t ldsb = (size_t)qpw * c.bytes;
         const int grid = r4x16_resident_grid(ldsb, 1, (nitems + qpw - 1) / qpw);
-        if (c.lv == 2) {
-            hipLaunchKernelGGL((k_dec_chain<true, 2>), dim3(grid), dim3(WAVE), ldsb, s,
-                               ws->items, ws->desc, nitems, qpw, c.bytes, lo3, c.bytes);
-            lo3 = c.bytes;
-        } else {
-            hipLaunchKernelGGL((k_dec_chain<true, 4>), dim3(grid), dim3(WAVE), ldsb, s,
-                               ws->items, ws->desc, nitems, qpw, c.bytes, lo4, c.bytes);
-            lo4 = c.bytes;
-        }
+        void (*kern)(const DecItem *, DecDesc *, int, int, u32, u32, u32) =
+            c.lv == 2 ? k_dec_chain<true, 2> : c.lv == 3 ? k_dec_chain<true, 3> : k_dec_chain<true, 4>;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), ldsb, s, ws->items, ws->desc, nitems, qpw, c.bytes, lo[c.lv], c.bytes);
+        lo[c.lv] = c.bytes;
     }
     // images that fit no LDS class: tables stay in global memory (L2)
     const int grid = (nitems + 15) / 16;
-    hipLaunchKernelGGL((k_dec_chain<false, 2>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, nitems, 16, 0u, lo3, 0xffffffffu);
-    hipLaunchKernelGGL((k_dec_chain<false, 4>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, nitems, 16, 0u, lo4, 0xffffffffu);
+    hipLaunchKernelGGL((k_dec_chain<false, 2>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, nitems, 16, 0u, lo[2], 0xffffffffu);
+    hipLaunchKernelGGL((k_dec_chain<false, 3>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, nitems, 16, 0u, lo[3], 0xffffffffu);
+    hipLaunchKernelGGL((k_dec_chain<false, 4>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, nitems, 16, 0u, lo[4], 0xffffffffu);
 }
 extern "C" void r4x16_launch_dec_back(const BatchArgs *a, const DecWs *ws, int base, int nblk, hipStream_t s)
 {
