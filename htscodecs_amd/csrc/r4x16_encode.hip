@@ -1031,45 +1031,125 @@ __device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, 
     tile_store(bufs[0]);
     __syncthreads();
 
+    // Per tile, 64-byte groups from the top (group 0 = the highest addresses), all four waves:
+    //   1. literal mask of every group (a byte is a literal unless it repeats an RLE symbol);
+    //   2. for every group the position of the nearest literal above it (one wave, a scan over the masks);
+    //   3. run lengths and varint sizes -> literals and run bytes per group;
+    //   4. prefix sums of those (one wave) -> where each group's output goes;
+    //   5. the literals and the run varints are written, every group at its final place.
+    // Only the three running values (next literal above, literals so far, run bytes so far) pass from
+    // tile to tile.  Steps 3 and 5 evaluate a group twice; that is cheaper than parking 16 KB of run lengths.
+    u8 *aux = tiles + 2 * (RLE_TILE + 32);
+    u64 *Lm = (u64 *)aux;                                 // [256] literal masks
+    u32 *NL = (u32 *)(aux + 2048);                        // [256] nearest literal above the group
+    u32 *GL = (u32 *)(aux + 3072), *GV = (u32 *)(aux + 4096);   // [256] literals / run bytes of the group
+    u32 *OL = (u32 *)(aux + 5120), *OV = (u32 *)(aux + 6144);   // [256] the same, summed over the groups above
+    u32 *car = (u32 *)(aux + 7168);                       // [3] next_lit, tile literals, tile run bytes
+    const u32 wv = tid >> 6;
     u32 next_lit = n, nl = 0, nrb = 0;
     for (u32 k = 0; k < ntiles; k++) {
         if (k + 1 < ntiles) tile_fetch(k + 1);
-        if (tid < WAVE) {
-            u32 tb, tt; tile_bounds(k, tb, tt);
-            const u64 lo = (u64)(data + tb) - (tb ? 1 : 0);
-            // LDS address of data[i]: buf + (address of data[i] - a0)
-            LAS const u8 *img = (LAS const u8 *)bufs[k & 1] + (u32)(lo & 15ull) - tb + (tb ? 1 : 0);
-            for (u32 top = tt; top > tb; ) {
-                const u32 base = top - tb > WAVE ? top - WAVE : tb;
-                const u32 cnt = top - base;
-                const u32 i = base + lane;
-                const bool valid = lane < cnt;
-                const u32 cur = valid ? img[i] : 0u;
-                const u32 prev = (valid && i > 0) ? img[i - 1] : 256u;
-                const bool isl = valid && !(S.present[cur] && cur == prev);
-                const u64 L = __ballot(isl);
-                const u64 above = lane == WAVE - 1 ? 0ull : (L >> (lane + 1));
-                const u32 nxt = above ? i + (u32)__ffsll((unsigned long long)above) : next_lit;
-                const bool isr = isl && S.present[cur];
-                const u32 run = nxt - i - 1;
-                const u32 vl = isr ? var_len(run) : 0u;
-                // bytes of run varints of this lane and the lanes above it (suffix sum), from ballots of
-                // "at least k bytes" (a shuffle scan goes through the LDS crossbar six times per trip)
-                u32 suf = vl, tot = 0;
-#pragma unroll
-                for (u32 kk = 1; kk <= 5; kk++) {
-                    const u64 mk = __ballot(vl >= kk);
-                    suf += lane == WAVE - 1 ? 0u : (u32)__popcll(mk >> (lane + 1));
-                    tot += (u32)__popcll(mk);
-                }
-                if (isl) lits_end[-(long)(nl + (u32)__popcll(above) + 1)] = (u8)cur;
-                if (isr) var_put(runs_end - (nrb + suf), run);
-                nl += (u32)__popcll(L);
-                nrb += tot;
-                if (L) next_lit = base + (u32)__ffsll((unsigned long long)L) - 1;
-                top = base;
-            }
+        u32 tb, tt; tile_bounds(k, tb, tt);
+        const u64 lo = (u64)(data + tb) - (tb ? 1 : 0);
+        // LDS address of data[i]: buf + (address of data[i] - a0)
+        LAS const u8 *img = (LAS const u8 *)bufs[k & 1] + (u32)(lo & 15ull) - tb + (tb ? 1 : 0);
+        const u32 G = (tt - tb + WAVE - 1) / WAVE;
+        auto group_base = [&](u32 j) -> u32 { const u32 top = tt - WAVE * j; return top - tb > WAVE ? top - WAVE : tb; };
+        auto group_cnt = [&](u32 j) -> u32 { const u32 top = tt - WAVE * j; return top - group_base(j); };
+        // (1)
+        for (u32 j = wv; j < G; j += FRONT_THREADS / WAVE) {
+            const u32 base = group_base(j), cnt = group_cnt(j);
+            const u32 i = base + lane;
+            const bool valid = lane < cnt;
+            const u32 cur = valid ? img[i] : 0u;
+            const u32 prev = (valid && i > 0) ? img[i - 1] : 256u;
+            const bool isl = valid && !(S.present[cur] && cur == prev);
+            const u64 L = __ballot(isl);
+            if (lane == 0) Lm[j] = L;
         }
+        __syncthreads();
+        // (2) lane l owns groups 4l .. 4l+3; "nearest literal above" runs down the groups
+        if (tid < WAVE) {
+            const u32 NONE = 0xffffffffu;
+            u32 low[4], last = NONE;
+#pragma unroll
+            for (u32 c = 0; c < 4; c++) {
+                const u32 j = 4 * lane + c;
+                const u64 L = j < G ? Lm[j] : 0ull;
+                low[c] = L ? group_base(j) + (u32)__ffsll((unsigned long long)L) - 1 : NONE;
+                if (low[c] != NONE) last = low[c];
+            }
+            // exclusive scan over lanes of "the last literal position seen so far"
+            u32 incl = last;
+#pragma unroll
+            for (int dd = 1; dd < WAVE; dd <<= 1) {
+                const u32 t2 = __shfl_up(incl, dd);
+                if (lane >= (u32)dd && incl == NONE) incl = t2;
+            }
+            u32 run = __shfl_up(incl, 1);
+            if (lane == 0) run = NONE;
+            if (run == NONE) run = next_lit;
+#pragma unroll
+            for (u32 c = 0; c < 4; c++) {
+                const u32 j = 4 * lane + c;
+                if (j < G) NL[j] = run;
+                if (low[c] != NONE) run = low[c];
+            }
+            const u32 fin = __shfl(incl, WAVE - 1);
+            if (lane == 0) car[0] = fin == NONE ? next_lit : fin;
+        }
+        __syncthreads();
+        // (3) and (5)
+        auto eval_group = [&](u32 j, bool write, u32 ol, u32 ov) {
+            const u32 base = group_base(j), cnt = group_cnt(j);
+            const u32 i = base + lane;
+            const bool valid = lane < cnt;
+            const u32 cur = valid ? img[i] : 0u;
+            const u64 L = Lm[j];
+            const bool isl = (L >> lane) & 1ull;
+            const u64 above = lane == WAVE - 1 ? 0ull : (L >> (lane + 1));
+            const u32 nxt = above ? i + (u32)__ffsll((unsigned long long)above) : NL[j];
+            const bool isr = isl && S.present[cur];
+            const u32 run = nxt - i - 1;
+            const u32 vl = isr ? var_len(run) : 0u;
+            u32 suf = vl, tot = 0;
+#pragma unroll
+            for (u32 kk = 1; kk <= 5; kk++) {
+                const u64 mk = __ballot(vl >= kk);
+                suf += lane == WAVE - 1 ? 0u : (u32)__popcll(mk >> (lane + 1));
+                tot += (u32)__popcll(mk);
+            }
+            if (!write) {
+                if (lane == 0) { GL[j] = (u32)__popcll(L); GV[j] = tot; }
+            } else {
+                if (isl) lits_end[-(long)(nl + ol + (u32)__popcll(above) + 1)] = (u8)cur;
+                if (isr) var_put(runs_end - (nrb + ov + suf), run);
+            }
+        };
+        for (u32 j = wv; j < G; j += FRONT_THREADS / WAVE) eval_group(j, false, 0, 0);
+        __syncthreads();
+        // (4) exclusive sums down the groups
+        if (tid < WAVE) {
+            u32 l4[4], v4[4], sl = 0, sv = 0;
+#pragma unroll
+            for (u32 c = 0; c < 4; c++) {
+                const u32 j = 4 * lane + c;
+                l4[c] = j < G ? GL[j] : 0u; v4[c] = j < G ? GV[j] : 0u;
+                sl += l4[c]; sv += v4[c];
+            }
+            const u32 il = wave_incl_scan(sl, lane), iv = wave_incl_scan(sv, lane);
+            u32 el = il - sl, ev = iv - sv;
+#pragma unroll
+            for (u32 c = 0; c < 4; c++) {
+                const u32 j = 4 * lane + c;
+                if (j < G) { OL[j] = el; OV[j] = ev; }
+                el += l4[c]; ev += v4[c];
+            }
+            if (lane == WAVE - 1) { car[1] = il; car[2] = iv; }
+        }
+        __syncthreads();
+        for (u32 j = wv; j < G; j += FRONT_THREADS / WAVE) eval_group(j, true, OL[j], OV[j]);
+        next_lit = car[0]; nl += car[1]; nrb += car[2];
         if (k + 1 < ntiles) tile_store(bufs[(k + 1) & 1]);
         __syncthreads();
     }
