@@ -335,12 +335,27 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             cursor += __popc(wm);
 
             if (ORDER == 0) {
-                // the quad's four bytes are consecutive: lane 0 stores them as one dword
-                const u32 b1 = quad_bcast1(byte0), b2 = quad_bcast2(byte0), b3 = quad_bcast3(byte0);
-                const u32 l3 = FAST ? 1u : quad_bcast3(live ? 1u : 0u);
-                const u32 dw = byte0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-                if (l3) { if (k == 0 && active) *(gu32_unaligned *)(op + 4 * (u64)T) = dw; }
-                else if (live) op[4 * (u64)T] = (u8)byte0;
+                if (FAST) {
+                    // Step T puts byte 4T + k on chain k.  Each lane gathers its own four bytes of four
+                    // steps, then the quad transposes the 4 x 4 byte block (four DPP broadcasts, three byte
+                    // permutes with a per-lane selector) so that lane j holds the dword of step T0 + j:
+                    // one 4-byte store per lane, 16 contiguous bytes per stream, every fourth step.
+                    acc = __builtin_amdgcn_alignbit(byte0, acc, 8);
+                    if ((u & 3) == 3) {
+                        const u32 A0 = quad_bcast0(acc), A1 = quad_bcast1(acc), A2 = quad_bcast2(acc), A3 = quad_bcast3(acc);
+                        const u32 sel = k | ((4u + k) << 8);                        // byte k of either source
+                        const u32 p01 = __builtin_amdgcn_perm(A1, A0, sel), p23 = __builtin_amdgcn_perm(A3, A2, sel);
+                        const u32 dw = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+                        if (active) *(gu32_unaligned *)(out + 4 * (u64)(T - 3u + k)) = dw;
+                    }
+                } else {
+                    // the quad's four bytes are consecutive: lane 0 stores them as one dword
+                    const u32 b1 = quad_bcast1(byte0), b2 = quad_bcast2(byte0), b3 = quad_bcast3(byte0);
+                    const u32 l3 = quad_bcast3(live ? 1u : 0u);
+                    const u32 dw = byte0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+                    if (l3) { if (k == 0 && active) *(gu32_unaligned *)(op + 4 * (u64)T) = dw; }
+                    else if (live) op[4 * (u64)T] = (u8)byte0;
+                }
             }
         }
         t += TRIP_STEPS;
