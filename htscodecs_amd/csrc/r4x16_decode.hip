@@ -1156,6 +1156,7 @@ static int cu_count()
     }
     return n;
 }
+extern "C" int r4x16_cu_count(void) { return cu_count(); }
 extern "C" int r4x16_resident_grid(size_t lds_bytes, int waves_per_wg, int wanted)
 {
     const int cap = cu_count() * resident_per_cu(lds_bytes, waves_per_wg);

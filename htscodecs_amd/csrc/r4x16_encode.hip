@@ -1776,6 +1776,7 @@ extern "C" void r4x16_launch_enc_tables(const BatchArgs *a, const EncWs *ws, int
     hipLaunchKernelGGL(k_enc_tables, dim3(nblk), dim3(WAVE), TABLES_DYN_LDS, s, *a, *ws, base);
 }
 extern "C" int r4x16_resident_grid(size_t lds_bytes, int waves_per_wg, int wanted);      // r4x16_decode.hip
+extern "C" int r4x16_cu_count(void);
 extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t s)
 {
     static bool once = false;
@@ -1787,7 +1788,16 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
     static const int force_qpw = getenv("R4X16_ENC_QPW") ? atoi(getenv("R4X16_ENC_QPW")) : 0;   // tuning aids
     static const int force_waves = getenv("R4X16_ENC_WAVES") ? atoi(getenv("R4X16_ENC_WAVES")) : 0;
     for (const u32 bytes : ENC_CLASSES) {
-        const int qpw = (force_qpw && bytes == 4752) ? force_qpw : enc_class_qpw(bytes);
+        int qpw = (force_qpw && bytes == 4752) ? force_qpw : enc_class_qpw(bytes);
+        // One workgroup per CU is the best shape (measured: 30 streams per CU as 1 x 32 beat 2 x 16 by a
+        // third and half-filled 64s by a fifth), so a batch that cannot fill the class's workgroups on
+        // every CU gets smaller ones (items [0, n/2) are the payload streams).
+        {
+            const int cus = r4x16_cu_count();
+            int want = (((nitems + 1) / 2 + cus - 1) / cus + 3) & ~3;
+            if (want < 8) want = 8;
+            if (qpw > want) qpw = want;
+        }
         int waves = (qpw + 7) / 8;                         // about eight streams per wave measured best (fewer
         if (waves > 4) waves = 4;                          // lanes per LDS access, one wave per SIMD)
         if (force_waves && bytes == 4752) waves = force_waves;
