@@ -585,8 +585,8 @@ struct EncShared {
     u8  pmask[256];      // terms present in this row
     u32 nsym, tab_len, bits;
     i32 status;
-    u32 pk_n, pk_meta_len, pk_len;       // wave_pack results
-    u32 rl_nsyms, rl_lits, rl_runs;      // wave_rle_split results
+    u32 pk_n, pk_meta_len, pk_len;       // wg_pack results
+    u32 rl_nsyms, rl_lits, rl_runs;      // wg_rle_split results
 };
 
 // ---- wave histogram of bytes (hist8, utils.h:80-102) into S.F ---------------------------------
@@ -795,115 +795,8 @@ __device__ __forceinline__ void wg_hist1(const u8 *data, u32 n, FP Fp0, u32 ns, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// hts_pack, pack.c:56-151, by one wave.  S.F must hold the byte histogram of data[0..n).
-// Writes the map to meta (meta[0] = symbol count, 256 wraps to 0) and, when 2..16 symbols occur,
-// the packed bytes to `out` (first symbol in the low bits).  Results through the shared scalars:
-//   S.pk_n (symbol count), S.pk_meta_len, S.pk_len (packed length; n for the copy cases).
-// ---------------------------------------------------------------------------------------------
-__device__ void wave_pack(const u8 *data, u32 n, u8 *meta, u8 *out, EncShared &S, u32 lane)
-{
-    if (lane == 0) {
-        u32 ns = 0;
-        for (u32 j = 0; j < 256; j++)
-            if (S.F[j]) { S.idx_of[j] = (u8)ns; S.alpha[ns] = (u8)j; ns++; }
-        meta[0] = (u8)ns;                                 // 256 wraps to 0 (pack.c:74)
-        if (ns <= 16) for (u32 j = 0; j < ns; j++) meta[1 + j] = S.alpha[j];
-        S.pk_n = ns;
-        S.pk_meta_len = ns > 16 ? 1 : ns + 1;
-    }
-    wsync();
-    const u32 ns = S.pk_n;
-    if (ns > 16) { if (lane == 0) S.pk_len = n; return; }     // copy case: caller keeps `data`
-    const u32 per = ns > 4 ? 2 : ns > 2 ? 4 : ns > 1 ? 8 : 0;
-    if (per == 0) { if (lane == 0) S.pk_len = 0; wsync(); return; }
-    const u32 width = 8 / per;
-    const u32 nout = (n + per - 1) / per;
-    for (u32 ob = lane; ob < nout; ob += WAVE) {
-        u32 v = 0;
-        const u32 i0 = ob * per;
-        for (u32 k = 0; k < per && i0 + k < n; k++) v |= (u32)S.idx_of[data[i0 + k]] << (k * width);
-        out[ob] = (u8)v;
-    }
-    if (lane == 0) S.pk_len = nout;
-    __threadfence();
-    wsync();
-}
-
-// ---------------------------------------------------------------------------------------------
-// rle_encode with automatic symbol choice, rle.c:48-138, by one wave.
-// A symbol is run-length coded when it repeats its predecessor more often than not
-// (score = sum over its occurrences of +1 / -1 > 0, i.e. 2 * repeats > count).  The input is swept
-// from the end in 64-byte steps: a literal's run is the distance to the next literal above it, so
-// literals and run varints are produced back to front into lits_end[-..] and runs_end[-..].
-// Results: S.rl_nsyms, S.rl_lits, S.rl_runs (bytes); symbols in S.alpha[0..nsyms).
-// S.F must hold the byte histogram of data[0..n).
-// ---------------------------------------------------------------------------------------------
-__device__ void wave_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, EncShared &S, u32 lane)
-{
-    u32 *rep = S.T;                                      // repeats per symbol
-    for (u32 j = lane; j < 256; j += WAVE) rep[j] = 0;
-    wsync();
-    {
-        u32 carry = 256;                                 // byte before this trip (none at the start)
-        for (u32 base = 0; base < n; base += WAVE) {
-            const u32 i = base + lane;
-            const u32 cur = i < n ? data[i] : 257u;
-            u32 prev = __shfl_up(cur, 1);
-            if (lane == 0) prev = carry;
-            carry = __shfl(cur, WAVE - 1);
-            if (i < n && cur == prev) atomicAdd(&rep[cur], 1u);
-        }
-    }
-    wsync();
-    if (lane == 0) {
-        u32 ns = 0;
-        for (u32 j = 0; j < 256; j++) {
-            const bool use = 2 * (u64)rep[j] > (u64)S.F[j];
-            S.present[j] = use;
-            if (use) S.alpha[ns++] = (u8)j;
-        }
-        S.rl_nsyms = ns;
-    }
-    wsync();
-
-    u32 next_lit = n, nl = 0, nrb = 0;
-    for (u32 top = n; top > 0; ) {
-        const u32 base = top > WAVE ? top - WAVE : 0;
-        const u32 cnt = top - base;
-        const u32 i = base + lane;
-        const bool valid = lane < cnt;
-        const u32 cur = valid ? data[i] : 0u;
-        const u32 prev = (valid && i > 0) ? data[i - 1] : 256u;
-        const bool isl = valid && !(S.present[cur] && cur == prev);
-        const u64 L = __ballot(isl);
-        const u64 above = lane == WAVE - 1 ? 0ull : (L >> (lane + 1));
-        const u32 nxt = above ? i + (u32)__ffsll((unsigned long long)above) : next_lit;
-        const bool isr = isl && S.present[cur];
-        const u32 run = nxt - i - 1;
-        const u32 vl = isr ? var_len(run) : 0u;
-        // bytes of run varints produced by the lanes above this one (suffix sum)
-        u32 suf = vl;
-#pragma unroll
-        for (int dd = 1; dd < WAVE; dd <<= 1) {
-            const u32 tt = __shfl_down(suf, dd);
-            if (lane + (u32)dd < WAVE) suf += tt;
-        }
-        if (isl) lits_end[-(long)(nl + (u32)__popcll(above) + 1)] = (u8)cur;
-        if (isr) var_put(runs_end - (nrb + suf), run);
-        nl += (u32)__popcll(L);
-        nrb += __shfl(suf, 0);
-        if (L) next_lit = base + (u32)__ffsll((unsigned long long)L) - 1;
-        top = base;
-    }
-    if (lane == 0) { S.rl_lits = nl; S.rl_runs = nrb; }
-    __threadfence();
-    wsync();
-}
-
-// ---------------------------------------------------------------------------------------------
-// Workgroup forms of the two transforms (all FRONT_THREADS threads).  The one-wave forms above
-// stay for reference; they were latency-bound (one dependent byte load per 64 bytes: 86 ms for
-// 4,096 x 1 MiB blocks with X_PACK|X_RLE).
+// The two transforms, by all FRONT_THREADS threads of the workgroup.  (One-wave forms were latency-bound:
+// one dependent byte load per 64 bytes, 86 ms for 4,096 x 1 MiB blocks with X_PACK|X_RLE against 15 ms.)
 // ---------------------------------------------------------------------------------------------
 // hts_pack, pack.c:56-151.  S.F holds the byte histogram of data[0..n).  Each thread packs 16-byte
 // pieces of the input (2 / 4 / 8 output bytes).  Ends on a workgroup barrier.
@@ -959,7 +852,7 @@ __device__ void wg_pack(const u8 *data, u32 n, u8 *meta, u8 *out, EncShared &S, 
 // counts are taken by all threads; the back-to-front split is one wave's work (its bookkeeping is
 // serial from trip to trip) but it reads the input from LDS tiles that all threads stage, the next
 // tile travelling from HBM while the current one is swept.  `tiles`: 2 x (RLE_TILE + 32) bytes of LDS.
-// Results as wave_rle_split.  Ends on a workgroup barrier.
+// Results: S.rl_nsyms, S.rl_lits, S.rl_runs (bytes); symbols in S.alpha[0..nsyms).  Ends on a workgroup barrier.
 #define RLE_TILE 16384u
 __device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, EncShared &S, u8 *tiles, u32 tid)
 {
