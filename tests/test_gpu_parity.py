@@ -335,3 +335,27 @@ def test_many_small_blocks_span_several_shares(H, oracle):
     dec, st = H.uncompress_batch(enc, [len(d) for d in datas])
     assert all(s == 0 for s in st)
     assert all(a == b for a, b in zip(dec, datas))
+
+
+def test_alphabet_sizes_at_the_tree_depth_boundaries(H, oracle):
+    """The decoder's lookup tree has 2, 3 or 4 levels (<= 50, <= 150, <= 256 symbols) and two-level rows
+    lose their last dword unless the alphabet is a multiple of ten: alphabets around every boundary, both
+    orders, uniform and skewed, must round-trip bit-exactly."""
+    rs = np.random.RandomState(5150)
+    datas, orders = [], []
+    for nsym in (1, 2, 9, 10, 11, 19, 20, 21, 39, 40, 41, 49, 50, 51, 52, 89, 90, 91, 119, 120, 121, 149, 150, 151, 152, 200, 255, 256):
+        for order in (0, 1):
+            n = 30000 + int(rs.randint(0, 7))
+            datas.append(datagen.rand(n, int(rs.randint(1, 1 << 30)), nsym, int(rs.randint(0, 257 - nsym))).tobytes())
+            orders.append(order)
+            w = [int(rs.randint(1, 3000)) for _ in range(nsym)]
+            datas.append(datagen.weighted(n, w, int(rs.randint(1, 1 << 30))).tobytes())
+            orders.append(order)
+    enc, st = H.compress_batch(datas, orders)
+    assert all(s == 0 for s in st), st
+    bad = [(len(set(d)), o) for d, o, e in zip(datas, orders, enc) if e != oracle.compress(d, o)]
+    assert not bad, bad
+    dec, st = H.uncompress_batch(enc, [len(d) for d in datas])
+    assert all(s == 0 for s in st), st
+    bad = [(len(set(d)), o) for d, o, x in zip(datas, orders, dec) if x != d]
+    assert not bad, bad
