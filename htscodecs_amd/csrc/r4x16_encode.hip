@@ -1306,43 +1306,49 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
     wsync();
 
     // ---- compute_shift (:629-691): row by row; terms in parallel, sums in reference order ------
-    if (lane == 0) { H.e10 = 0; H.e12 = 0; H.max_tot = 0; }
+    if (lane == 0) H.max_tot = 0;
     wsync();
+    double e10 = 0, e12 = 0;                              // running sums, identical in every lane
+    // log(1024 + k), log(4096 + k) for k < 64 sit one per lane (k is a count of "tiny" symbols in a row and
+    // nearly always small); a row's pair is then a lane read instead of two dependent global loads
+    const double ltab10 = ws.logtab[lane], ltab12 = ws.logtab[257 + lane];
     for (u32 r = 0; r < ns; r++) {
         const u32 Tr = S.T[r];
         const int target0 = (int)pow2_ceil(Tr);
         u32 tiny10 = 0, tiny12 = 0, nz = 0;
-        for (u32 j = lane; j < ns; j += WAVE) {
-            const u32 f = Fp[r * ns + j];
-            if (f) {
-                nz++;
-                if ((u32)target0 / f > 1024u) tiny10++;
-                if ((u32)target0 / f > 4096u) tiny12++;
-            }
+        for (u32 jb = 0; jb < ns; jb += WAVE) {                        // counts by ballot, no shuffle reductions
+            const u32 j = jb + lane;
+            const u32 f = j < ns ? Fp[r * ns + j] : 0u;
+            const u32 qd = f ? (u32)target0 / f : 0u;
+            nz += (u32)__popcll(__ballot(f != 0));
+            tiny10 += (u32)__popcll(__ballot(f != 0 && qd > 1024u));
+            tiny12 += (u32)__popcll(__ballot(f != 0 && qd > 4096u));
         }
-        tiny10 = wave_sum(tiny10); tiny12 = wave_sum(tiny12); nz = wave_sum(nz);
-        const double l10 = ws.logtab[tiny10], l12 = ws.logtab[257 + tiny12];
-        for (u32 j = lane; j < ns; j += WAVE) {
-            const u32 f = Fp[r * ns + j];
-            S.pmask[j] = f != 0;
+        const double l10 = tiny10 < WAVE ? __shfl(ltab10, (int)tiny10) : ws.logtab[tiny10];
+        const double l12 = tiny12 < WAVE ? __shfl(ltab12, (int)tiny12) : ws.logtab[257 + tiny12];
+        // Terms in parallel, one symbol per lane; the sum must run in the reference's order (j ascending, one
+        // accumulator over all rows), so it walks the lanes with scalar lane reads - the terms never touch LDS.
+        for (u32 jb = 0; jb < ns; jb += WAVE) {
+            const u32 j = jb + lane;
+            const u32 f = j < ns ? Fp[r * ns + j] : 0u;
+            double t10 = 0, t12 = 0;
             if (f) {
                 int x = (int)((double)1024 * (double)f / (double)Tr);
-                S.t10[j] = (double)f * (approx_log((double)(x > 1 ? x : 1)) - l10);
+                t10 = (double)f * (approx_log((double)(x > 1 ? x : 1)) - l10);
                 x = (int)((double)4096 * (double)f / (double)Tr);
-                S.t12[j] = (double)f * (approx_log((double)(x > 1 ? x : 1)) - l12);
+                t12 = (double)f * (approx_log((double)(x > 1 ? x : 1)) - l12);
             }
-        }
-        wsync();
-        if (lane == 0) {
-            double e10 = H.e10, e12 = H.e12;
-            for (u32 j = 0; j < ns; j++) {
-                if (!S.pmask[j]) continue;
-                e10 -= S.t10[j];
-                e12 -= S.t12[j];
+            u64 m = __ballot(f != 0);
+            while (m) {
+                const int src = __ffsll((unsigned long long)m) - 1;
+                m &= m - 1;
+                e10 -= __shfl(t10, src);
+                e12 -= __shfl(t12, src);
                 e10 += 4;
                 e12 += 6;
             }
-            H.e10 = e10; H.e12 = e12;
+        }
+        if (lane == 0) {
             int target = target0;
             if (nz < 64 && target > 128) target /= 2;                  // :678-681
             if (target > 1024) target /= 2;
@@ -1352,7 +1358,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
         }
         wsync();
     }
-    const u32 bits = (H.e10 / H.e12 < 1.01 || H.max_tot <= 1024) ? 10u : 12u;      // :685
+    const u32 bits = (e10 / e12 < 1.01 || H.max_tot <= 1024) ? 10u : 12u;          // :685
 
     // ---- per-context normalisation (:740-752), one context row per lane ---------------------------
     for (u32 rb = 0; rb < ns; rb += WAVE) {
