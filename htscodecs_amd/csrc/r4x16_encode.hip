@@ -547,15 +547,24 @@ __device__ __forceinline__ u32 chain_encode_o0_lds(const u8 *img_lds, DP data, u
     const u32 gtop = (active && n) ? (n - 1) >> 2 : 0;
     u32 nsteps = (active && n) ? gtop + 1 : 0;
     const u32 first = (active && n && 4 * gtop + k >= n) ? 1 : 0;    // top group may be partial
-    u32 p = 4 * (gtop - first) + k;
-    u32 byte = (nsteps > first) ? data[p] : 0u;
+    const u32 p0 = 4 * (gtop - first) + k;                           // byte of this lane's first step
+    // Three look-ups ahead of the state update, one stage per step (symbols are known in advance):
+    // byte of step s+3, its compact index for step s+2, table entry and reciprocal for step s+1.
+    auto ldbyte = [&](u32 st) -> u32 { return (st >= first && st < nsteps) ? (u32)data[p0 - 4 * (st - first)] : 0u; };
+    auto entry = [&](u32 si) -> u32x2 {
+        const u32 c0 = cum[si], c1 = cum[si + 1];
+        u32x2 e = {rcp_by_sym ? rcp_by_sym[si] : enc_rcp(rcptab, c1 - c0), c0 | ((c1 - c0) << 16)};
+        return e;
+    };
+    u32 b2 = ldbyte(2);
+    u32 si1 = idx[ldbyte(1)];
+    u32x2 e0 = entry(idx[ldbyte(0)]);
     for (u32 s = 0; wave_any(s < nsteps); s++) {
         const bool live = s >= first && s < nsteps;
-        const u32 si = idx[byte];
-        const u32 c0 = cum[si], c1 = cum[si + 1];
-        const u32x2 e = {rcp_by_sym ? rcp_by_sym[si] : enc_rcp(rcptab, c1 - c0), c0 | ((c1 - c0) << 16)};
-        const u32 nb = (live && p >= 4) ? data[p - 4] : 0u;          // next group's byte, a step ahead
-        const bool emit = live && enc_wants_emit(x, e.y, bits);
+        const u32 b3 = ldbyte(s + 3);
+        const u32 si2 = idx[b2];
+        const u32x2 e1 = entry(si1);
+        const bool emit = live && enc_wants_emit(x, e0.y, bits);
         const u32 em = quad_ballot(emit, lane);
         if (emit) {
             const u32 above = __popc(em >> (k + 1));
@@ -563,8 +572,9 @@ __device__ __forceinline__ u32 chain_encode_o0_lds(const u8 *img_lds, DP data, u
             x >>= 16;
         }
         written += __popc(em);
-        const u32 xn = enc_advance(x, e.x, e.y, bits);
-        if (live) { x = xn; byte = nb; p -= 4; }
+        const u32 xn = enc_advance(x, e0.x, e0.y, bits);
+        if (live) x = xn;
+        e0 = e1; si1 = si2; b2 = b3;
     }
     if (active) *(gu32 *)(scratch_end - 2 * written - 16 + 4 * k) = x;
     return active ? 2 * written + 16 : 0;
@@ -1054,6 +1064,13 @@ __device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, 
 // ---------------------------------------------------------------------------------------------
 // k_enc_front
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_f64(double v, int src)
+{
+    const long long b = __double_as_longlong(v);
+    const u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)b, src), hi = (u32)__builtin_amdgcn_readlane((int)(u32)(b >> 32), src);
+    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+
 __device__ __forceinline__ double approx_log(double a)            // fast_log :620-623
 {
     const long long bits = __double_as_longlong(a);
@@ -1324,8 +1341,8 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
             tiny10 += (u32)__popcll(__ballot(f != 0 && qd > 1024u));
             tiny12 += (u32)__popcll(__ballot(f != 0 && qd > 4096u));
         }
-        const double l10 = tiny10 < WAVE ? __shfl(ltab10, (int)tiny10) : ws.logtab[tiny10];
-        const double l12 = tiny12 < WAVE ? __shfl(ltab12, (int)tiny12) : ws.logtab[257 + tiny12];
+        const double l10 = tiny10 < WAVE ? readlane_f64(ltab10, (int)tiny10) : ws.logtab[tiny10];
+        const double l12 = tiny12 < WAVE ? readlane_f64(ltab12, (int)tiny12) : ws.logtab[257 + tiny12];
         // Terms in parallel, one symbol per lane; the sum must run in the reference's order (j ascending, one
         // accumulator over all rows), so it walks the lanes with scalar lane reads - the terms never touch LDS.
         for (u32 jb = 0; jb < ns; jb += WAVE) {
@@ -1342,8 +1359,8 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
             while (m) {
                 const int src = __ffsll((unsigned long long)m) - 1;
                 m &= m - 1;
-                e10 -= __shfl(t10, src);
-                e12 -= __shfl(t12, src);
+                e10 -= readlane_f64(t10, src);               // scalar lane index: v_readlane, not the LDS crossbar
+                e12 -= readlane_f64(t12, src);
                 e10 += 4;
                 e12 += 6;
             }
