@@ -648,26 +648,140 @@ __device__ u32 put_alphabet(u8 *cp, const u8 *present)
 // Order-0 stream front end (rANS_static4x16pr.c:405-435): histogram, two normalisations, table
 // bytes to `tab`, encoder row to `imgrow`.  All lanes call.  Sets S.tab_len / S.status.
 // enc_o0_tables expects the byte histogram of the data in S.F.
+// normalise_freq over 256 counters by the whole wave, four counters per lane.  Same integer arithmetic as
+// the one-lane form (sums are exact, the arg-max keeps the reference's "first largest" rule); the rarely
+// taken tail that spreads a deficit over the symbols stays with one lane.  Returns 0 / -1 in every lane.
+__device__ int wave_normalise_freq256(u32 *F, int size, u32 tot, u32 lane)
+{
+    int retried = 0;
+    if (!size) return 0;
+    for (;;) {
+        const u64 scale = ((u64)tot << 31) / (u64)(long)size + (u64)(long)((1 << 30) / size);
+        u32 best = 0, arg = 0;
+        int sum = 0;
+#pragma unroll
+        for (u32 c = 0; c < 4; c++) {
+            const u32 j = 4 * lane + c;
+            u32 f = F[j];
+            if (!f) continue;
+            if (best < f) { best = f; arg = j; }
+            f = (u32)(((u64)f * scale) >> 31);
+            if (f == 0) f = 1;
+            F[j] = f;
+            sum += (int)f;
+        }
+        sum = (int)wave_sum((u32)sum);
+        u32 wbest = best;
+#pragma unroll
+        for (int d = WAVE / 2; d; d >>= 1) { const u32 t = __shfl_xor(wbest, d); wbest = t > wbest ? t : wbest; }
+        u32 warg = (best == wbest && best) ? arg : 0xffffu;          // first index holding the largest count
+#pragma unroll
+        for (int d = WAVE / 2; d; d >>= 1) { const u32 t = __shfl_xor(warg, d); warg = t < warg ? t : warg; }
+        if (warg == 0xffffu) warg = 0;                               // all counters zero (the reference keeps arg = 0)
+        wsync();
+        int ret = 0, again = 0;
+        if (lane == 0) {
+            int adjust = (int)(tot - (u32)sum);
+            if (adjust > 0) {
+                F[warg] += (u32)adjust;
+            } else if (adjust < 0) {
+                const u32 need = (u32)(-adjust);
+                if (F[warg] > need && (retried || F[warg] / 2 >= need)) {
+                    F[warg] -= need;
+                } else if (!retried) {
+                    again = 1;
+                } else {
+                    adjust += (int)(F[warg] - 1);
+                    F[warg] = 1;
+                    for (u32 j = 0; adjust && j < 256; j++) {
+                        if (F[j] < 2) continue;
+                        const int take = (F[j] > (u32)(-adjust)) ? adjust : (int)(1 - F[j]);
+                        F[j] += (u32)take;
+                        adjust -= take;
+                    }
+                }
+            }
+            ret = F[warg] > 0 ? 0 : -1;
+        }
+        again = __shfl(again, 0);
+        ret = __shfl(ret, 0);
+        wsync();
+        if (again) { retried = 1; size = sum; continue; }
+        return ret;
+    }
+}
+
+// encode_alphabet (:182-206) from a 256-bit presence mask held as four scalars: walks the set bits, no
+// memory reads.  One lane.  Returns bytes written.
+__device__ u32 put_alphabet_mask(u8 *cp, const u64 pm[4])
+{
+    u8 *start = cp;
+    auto has = [&](u32 j) -> bool { return j < 256 && ((pm[j >> 6] >> (j & 63)) & 1ull); };
+    u32 j = 0;
+    for (;;) {
+        // next present symbol at or after j
+        u32 w = j >> 6;
+        u64 m = w < 4 ? pm[w] & (~0ull << (j & 63)) : 0ull;
+        while (!m && ++w < 4) m = pm[w];
+        if (!m) break;
+        j = 64 * w + (u32)__ffsll((unsigned long long)m) - 1;
+        *cp++ = (u8)j;
+        if (j && has(j - 1)) {
+            u32 kk = j + 1;
+            while (has(kk)) kk++;
+            *cp++ = (u8)(kk - (j + 1));
+            j = kk;                                                    // the implicit run is skipped
+        } else j++;
+    }
+    *cp++ = 0;
+    return (u32)(cp - start);
+}
+
 __device__ void enc_o0_tables(u32 n, u8 *tab, u8 *image, EncShared &S, u32 lane)
 {
     u16 *imgrow = (u16 *)(image + ENC_IMG_IDX);      // cum[0..256]
     for (u32 j = lane; j < 256; j += WAVE) image[j] = (u8)j;       // order-0: symbols index the row directly
-    if (lane == 0) {
-        u32 target = pow2_ceil(n);
-        if (target > (1u << O0_BITS)) target = 1u << O0_BITS;
-        S.status = ST_OK;
-        if (normalise_freq(S.F, 256, (int)n, target) < 0) S.status = ST_TABLE;
-        for (u32 j = 0; j < 256; j++) S.present[j] = S.F[j] != 0;
-        u8 *cp = tab;
-        cp += put_alphabet(cp, S.present);
-        for (u32 j = 0; j < 256; j++)
-            if (S.F[j]) cp += var_put(cp, S.F[j]);
-        S.tab_len = (u32)(cp - tab);
-        if (normalise_freq(S.F, 256, (int)target, 1u << O0_BITS) < 0) S.status = ST_TABLE;   // :426
+    u32 target = pow2_ceil(n);
+    if (target > (1u << O0_BITS)) target = 1u << O0_BITS;
+    if (lane == 0) S.status = ST_OK;
+    wsync();
+    if (wave_normalise_freq256(S.F, (int)n, target, lane) < 0) { if (lane == 0) S.status = ST_TABLE; }
+    // table bytes: alphabet from the presence mask, then the frequencies as varints at prefix offsets
+    u32 f[4], vl[4], mine = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) { f[c] = S.F[lane * 4 + c]; vl[c] = f[c] ? var_len(f[c]) : 0u; mine += vl[c]; }
+    u64 pm[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        // symbols 64w .. 64w+63 live in lanes 16w .. 16w+15, four per lane
+        u64 bits4 = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            u64 x = (__ballot(f[c] != 0) >> (16 * w)) & 0xffffull;     // lanes 16w .. 16w+15
+            x = (x | (x << 24)) & 0x000000ff000000ffull;               // spread 16 bits to every fourth position
+            x = (x | (x << 12)) & 0x000f000f000f000full;
+            x = (x | (x << 6)) & 0x0303030303030303ull;
+            x = (x | (x << 3)) & 0x1111111111111111ull;
+            bits4 |= x << c;
+        }
+        pm[w] = bits4;
+    }
+    for (u32 j = lane; j < 256; j += WAVE) S.present[j] = (pm[j >> 6] >> (j & 63)) & 1ull;
+    u32 alen = 0;
+    if (lane == 0) alen = put_alphabet_mask(tab, pm);
+    alen = __shfl(alen, 0);
+    {
+        u32 off = alen + wave_incl_scan(mine, lane) - mine;
+#pragma unroll
+        for (int c = 0; c < 4; c++) if (f[c]) { var_put(tab + off, f[c]); off += vl[c]; }
+        const u32 total = __shfl(wave_incl_scan(mine, lane), WAVE - 1);
+        if (lane == 0) S.tab_len = alen + total;
     }
     wsync();
+    if (wave_normalise_freq256(S.F, (int)target, 1u << O0_BITS, lane) < 0) { if (lane == 0) S.status = ST_TABLE; }   // :426
+    wsync();
     // cumulative starts by a wave scan, 4 symbols per lane
-    u32 f[4], sum = 0;
+    u32 sum = 0;
 #pragma unroll
     for (int c = 0; c < 4; c++) { f[c] = S.F[lane * 4 + c]; sum += f[c]; }
     u32 start = wave_incl_scan(sum, lane) - sum;
