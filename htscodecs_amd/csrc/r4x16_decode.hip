@@ -404,6 +404,9 @@ struct FrontShared {
     u8  present[256];  // alphabet of the stream (order-1: F0)
     u8  idx_of[256];   // byte -> compact index        (order-1)
     u8  alpha[256];    // compact index -> byte        (order-1)
+    u16 rankof[256];   // compact index -> its rank among the alphabet members that have a row entry, or 0xffff
+    u32 Fk[256];       // order-1: frequencies of the row being parsed, by that rank
+    u32 np;            // number of ranked members
     // scalars handed from lane 0 to the wave
     i32 status;
     u32 empty, pos, nsym, bits, look, go;
@@ -807,8 +810,28 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
     const u32 stride = img_row_bytes(nsym);
     u8 *rows0 = img + img_alpha_bytes(nsym);
 
+    // Every row lists a frequency for each member of F0 (decode_freq_d :327-358): rank them once.
+    if (lane == 0) {
+        u32 k = 0;
+        for (u32 c = 0; c < nsym; c++) S.rankof[c] = S.present[S.alpha[c]] ? (u16)k++ : (u16)0xffff;
+        S.np = k;
+    }
+    __syncthreads();
+    const u32 np = S.np;
+    // The parsing lane reads the table through a 1 KB register window (un-nested tables sit in tbuf, whose
+    // slot may be read past the table's end); a raw table inside the input keeps the plain reader.
+    WinSrc win(&tsrc);
+    const u32 wlimit = compressed ? TBUF_BYTES : 0u;
+
     // rows, in byte order of the compact alphabet (:967-998)
     for (u32 ci = 0; ci < nsym; ci++) {
+        {   // all lanes: clear the row's frequencies, keep the window ahead of the parse position
+            for (u32 c = lane; c < np; c += WAVE) S.Fk[c] = 0;
+            const u32 pos_now = S.pos;
+            if (wlimit && (win.wlen == 0 || pos_now < win.wbase || pos_now + 800u > win.wbase + win.wlen)) win.fill(pos_now, wlimit, lane);
+        }
+        __syncthreads();
+        u32 total = 0;
         if (lane == 0) {
             const u32 ctx = S.alpha[ci];
             S.empty = 0;
@@ -816,37 +839,67 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
             if (!S.present[ctx]) {
                 S.empty = 1;                                           // byte 0 outside F0
             } else {
-                // decode_freq_d :327-358; "for j in 0..255 if F0[j]" is a walk over the compact
-                // alphabet (its members other than a forced-in 0 are exactly F0, in byte order)
-                u32 p = S.pos, total = 0, zeros = 0;
+                // decode_freq_d :327-358: one value per ranked member, zero runs as (0, count - 1)
+                u32 p = S.pos, zeros = 0;
                 bool ok = p != tend;
-                for (u32 cj = 0; cj < nsym; cj++) S.F[S.alpha[cj]] = 0;
-                for (u32 cj = 0; ok && cj < nsym && p < tend; cj++) {
-                    const u32 j = S.alpha[cj];
-                    if (!S.present[j]) continue;
+                for (u32 k = 0; ok && k < np && p < tend; k++) {
                     u32 f;
                     if (zeros) { f = 0; zeros--; }
                     else {
-                        p += var_get(tsrc, p, tend, &f);
+                        p += var_get(win, p, tend, &f);
                         if (f == 0) {
                             if (p >= tend) { ok = false; break; }
-                            zeros = tsrc.at(p++);
+                            zeros = win.at(p++);
                         }
                     }
-                    S.F[j] = f;
+                    S.Fk[k] = f;
                     total += f;
                 }
                 if (!ok || p == S.pos) { H.status = ST_TABLE; S.go = 0; }
                 else {
                     S.pos = p;
                     if (total == 0) S.empty = 1;                       // :977-980
-                    else if (!make_cum(S, nsym, total, bits)) { H.status = ST_TABLE; S.go = 0; }
                 }
             }
             ((u16 *)img)[ci] = (u16)(ctx | (S.empty ? ROW_EMPTY : 0u));
         }
         __syncthreads();
         if (!S.go) break;
+        if (!S.empty) {
+            // cumulative starts by the whole wave (normalise_freq_shift :168-179 and the checks at :985-997):
+            // four compact symbols per lane, scaled, prefix-summed
+            total = __shfl(total, 0);
+            u32 sh = 0;
+            if (total != (1u << bits)) { u32 size = total; while (size < (1u << bits)) { size *= 2; sh++; } }
+            u32 f[4], sum = 0;
+            bool bad = false;
+#pragma unroll
+            for (u32 c = 0; c < 4; c++) {
+                const u32 cc = 4 * lane + c;
+                const u32 rk = cc < nsym ? S.rankof[cc] : 0xffffu;
+                f[c] = rk != 0xffffu ? S.Fk[rk] << sh : 0u;
+                bad |= f[c] > (1u << bits);
+                sum += f[c];
+            }
+            const bool anybad = wave_any(bad);
+            if (anybad) sum = 0;                                       // keeps the scan below from wrapping
+            const u32 incl = wave_incl_scan(sum, lane);
+            u32 x = incl - sum;
+#pragma unroll
+            for (u32 c = 0; c < 4; c++) {
+                const u32 cc = 4 * lane + c;
+                if (cc < nsym) S.cum[cc] = (u16)x;
+                x += f[c];
+            }
+            const u32 tot = __shfl(incl, WAVE - 1);
+            if (lane == 0) {
+                if (anybad || tot != (1u << bits)) { H.status = ST_TABLE; S.go = 0; }
+                S.cum[nsym] = (u16)tot;
+                S.cum[nsym + 1] = S.cum[nsym + 2] = S.cum[nsym + 3] = 0x7fffu;
+            }
+            __syncthreads();
+            if (!S.go) break;
+        }
         write_row(rows0 + (u64)ci * stride, S, nsym, S.empty != 0, lane);
         __syncthreads();
     }

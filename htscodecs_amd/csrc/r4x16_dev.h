@@ -76,8 +76,43 @@ struct ByteSrc {
     }
 };
 
-// varint.h:131-160 on a ByteSrc: bytes [pos, end).  Returns bytes consumed (0 if pos >= end).
-__device__ __forceinline__ u32 var_get(ByteSrc &s, u32 pos, u32 end, u32 *v)
+// A window of 1 KB of a byte stream held in registers, 16 bytes per lane: the lane that parses reads any
+// byte of it with a scalar lane read, so a run of dependent byte reads never waits for memory.  The window
+// is (re)loaded by the whole wave with fill(); bytes outside it fall back to the ByteSrc.
+struct WinSrc {
+    ByteSrc *far;
+    u32x4 held;
+    u32 wbase;           // stream position of lane 0's first byte
+    u32 wlen;            // bytes of the window that are loaded (0 = no window)
+    __device__ WinSrc(ByteSrc *f) : far(f), held{0, 0, 0, 0}, wbase(0), wlen(0) {}
+    // all lanes: load [pos & ~15, +1024) as far as it lies below `limit` (bytes of the stream that may be read)
+    __device__ __forceinline__ void fill(u32 pos, u32 limit, u32 lane) {
+        wbase = pos & ~15u;
+        const u32 mine = wbase + 16u * lane;
+        held = u32x4{0, 0, 0, 0};
+        if (mine + 16u <= limit) held = *(const u32x4_unaligned *)(far->base + mine);
+        const u32 room = limit > wbase ? (limit - wbase) & ~15u : 0u;
+        wlen = room < 1024u ? room : 1024u;
+    }
+    __device__ __forceinline__ u8 at(u32 pos) {
+        const u32 o = pos - wbase;
+        if (o < wlen) {
+            const u32 so = (u32)__builtin_amdgcn_readfirstlane((int)o);
+            const int ln = (int)(so >> 4);
+            const u32 sel = so & 12u;
+            const u32 d = sel == 0 ? (u32)__builtin_amdgcn_readlane((int)held.x, ln)
+                        : sel == 4 ? (u32)__builtin_amdgcn_readlane((int)held.y, ln)
+                        : sel == 8 ? (u32)__builtin_amdgcn_readlane((int)held.z, ln)
+                                   : (u32)__builtin_amdgcn_readlane((int)held.w, ln);
+            return (u8)(d >> (8u * (so & 3u)));
+        }
+        return far->at(pos);
+    }
+};
+
+// varint.h:131-160 on a byte source: bytes [pos, end).  Returns bytes consumed (0 if pos >= end).
+template <class SRC>
+__device__ __forceinline__ u32 var_get(SRC &s, u32 pos, u32 end, u32 *v)
 {
     u32 acc = 0, p = pos;
     u8 c;
