@@ -842,6 +842,21 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
                 // decode_freq_d :327-358: one value per ranked member, zero runs as (0, count - 1)
                 u32 p = S.pos, zeros = 0;
                 bool ok = p != tend;
+                // a row is at most 6 bytes per member; when that much lies inside the window and before the
+                // end of the table, no byte of the row needs a bounds check
+                if (ok && p >= win.wbase && p + 6u * np + 6u <= win.wbase + win.wlen && p + 6u * np + 6u <= tend) {
+                    for (u32 k = 0; k < np; k++) {
+                        u32 f = 0;
+                        if (zeros) zeros--;
+                        else {
+                            u32 c;
+                            do { c = win.at_inside(p++); f = (f << 7) | (c & 0x7fu); } while (c & 0x80u);   // varint.h:131-160
+                            if (f == 0) zeros = win.at_inside(p++);
+                        }
+                        S.Fk[k] = f;
+                        total += f;
+                    }
+                } else
                 for (u32 k = 0; ok && k < np && p < tend; k++) {
                     u32 f;
                     if (zeros) { f = 0; zeros--; }

@@ -99,14 +99,24 @@ struct WinSrc {
         if (o < wlen) {
             const u32 so = (u32)__builtin_amdgcn_readfirstlane((int)o);
             const int ln = (int)(so >> 4);
-            const u32 sel = so & 12u;
-            const u32 d = sel == 0 ? (u32)__builtin_amdgcn_readlane((int)held.x, ln)
-                        : sel == 4 ? (u32)__builtin_amdgcn_readlane((int)held.y, ln)
-                        : sel == 8 ? (u32)__builtin_amdgcn_readlane((int)held.z, ln)
-                                   : (u32)__builtin_amdgcn_readlane((int)held.w, ln);
+            // all four dwords of that lane, then scalar selects (a chain of conditional reads compiles to branches)
+            const u32 d0 = (u32)__builtin_amdgcn_readlane((int)held.x, ln), d1 = (u32)__builtin_amdgcn_readlane((int)held.y, ln),
+                      d2 = (u32)__builtin_amdgcn_readlane((int)held.z, ln), d3 = (u32)__builtin_amdgcn_readlane((int)held.w, ln);
+            const u32 lo = (so & 4u) ? d1 : d0, hi = (so & 4u) ? d3 : d2;
+            const u32 d = (so & 8u) ? hi : lo;
             return (u8)(d >> (8u * (so & 3u)));
         }
         return far->at(pos);
+    }
+    // the same without the range check, for callers that know the byte is inside the window
+    __device__ __forceinline__ u32 at_inside(u32 pos) {
+        const u32 so = (u32)__builtin_amdgcn_readfirstlane((int)(pos - wbase));
+        const int ln = (int)(so >> 4);
+        const u32 d0 = (u32)__builtin_amdgcn_readlane((int)held.x, ln), d1 = (u32)__builtin_amdgcn_readlane((int)held.y, ln),
+                  d2 = (u32)__builtin_amdgcn_readlane((int)held.z, ln), d3 = (u32)__builtin_amdgcn_readlane((int)held.w, ln);
+        const u32 lo = (so & 4u) ? d1 : d0, hi = (so & 4u) ? d3 : d2;
+        const u32 d = (so & 8u) ? hi : lo;
+        return (d >> (8u * (so & 3u))) & 0xffu;
     }
 };
 
