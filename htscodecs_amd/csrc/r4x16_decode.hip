@@ -115,7 +115,8 @@ __device__ __forceinline__ u32 lookup_step(const IMG &img, u32 row, u32 look, u3
     const u32 start = up ? c1 : c0;
     const u32 next = up ? c2 : c1;
     x = __umul24(next - start, x >> look) + (m - start);   // freq <= 2^15, x>>look < 2^22: exact mod 2^32
-    return e + (up ? 1u : 0u);
+    asm("" : "+v"(e));                        // (keeps e + carry an add-with-carry: the compiler would otherwise
+    return e + (up ? 1u : 0u);                  //  turn it into a select of 0/1 and an or, e being even)
 }
 
 // ---------------------------------------------------------------------------------------------
