@@ -854,6 +854,42 @@ __device__ __forceinline__ void wg_hist8(const u8 *data, u32 n, u32 *Fout, u32 *
     __syncthreads();
 }
 
+// present8 (utils.h:108-131): which byte values occur.  Order-1 needs only that of the byte histogram, and
+// plain byte stores do not serialise on the hot symbols the way counting atomics do.  F[b] becomes 0 / 1.
+__device__ __forceinline__ void wg_present8(const u8 *data, u32 n, u32 *F, u8 *flags, u32 tid)
+{
+    flags[tid] = 0;                                       // FRONT_THREADS == 256
+    __syncthreads();
+    const u32 full = n >> 4;
+    auto ld = [&](u32 pi) -> u32x4 {
+        u32x4 v = {0, 0, 0, 0};
+        if (pi < full) v = *(const u32x4_unaligned *)(data + 16ull * pi);
+        return v;
+    };
+    auto mark = [&](u32x4 w, u32 pi) {
+        if (pi >= full) return;
+        const u32 ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            flags[ww[c] & 0xff] = 1; flags[(ww[c] >> 8) & 0xff] = 1;
+            flags[(ww[c] >> 16) & 0xff] = 1; flags[ww[c] >> 24] = 1;
+        }
+    };
+    const u32 T = FRONT_THREADS;
+    u32x4 q0 = ld(tid), q1 = ld(tid + T), q2 = ld(tid + 2 * T), q3 = ld(tid + 3 * T);
+    for (u32 pi = tid; pi < full; pi += 4 * T) {
+        mark(q0, pi);         q0 = ld(pi + 4 * T);
+        mark(q1, pi + T);     q1 = ld(pi + 5 * T);
+        mark(q2, pi + 2 * T); q2 = ld(pi + 6 * T);
+        mark(q3, pi + 3 * T); q3 = ld(pi + 7 * T);
+    }
+    const u32 done = full * 16;
+    if (done + tid < n) flags[data[done + tid]] = 1;
+    __syncthreads();
+    F[tid] = flags[tid];
+    __syncthreads();
+}
+
 // Fp0 points at `copies` x ns*ns zeroed counters (LDS, or global with copies == 1); threads spread
 // over the copies by tid, and the copies are summed into the first one at the end.
 // counters of one copy: ns*ns, padded so that the copies start eight LDS banks apart
@@ -1338,8 +1374,10 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
     data = (const u8 *)H.data;
     n = H.dlen;
 
-    // pass 1 over the block: byte histogram (hist8 / present8, utils.h:80-131), all waves
-    wg_hist8(data, n, S.F, (u32 *)dyn, tid);
+    // pass 1 over the block, all waves: byte histogram (hist8, utils.h:80-102) for order 0, presence only
+    // (present8, :108-131) for order 1
+    if (H.order == 0) wg_hist8(data, n, S.F, (u32 *)dyn, tid);
+    else              wg_present8(data, n, S.F, S.pmask, tid);
 
     EncStat *ST = &ws.stat[b];
     ST->F0[tid] = S.F[tid];                                               // FRONT_THREADS == 256
