@@ -12,6 +12,9 @@
 #include <string>
 #include <vector>
 #include <mutex>
+#include <atomic>
+#include <thread>
+#include <chrono>
 
 #include "../../include/rans4x16_hip.h"
 #include "r4x16_dev.h"
@@ -29,6 +32,8 @@ void r4x16_launch_stripe(const u8 *, u8 *, u32, u32, int, hipStream_t);
 }
 
 struct TimedLaunch { hipEvent_t a, b; };
+struct HostPipe;
+static void pipe_destroy(HostPipe *);
 
 struct rans4x16_hip_ctx {
     int device = 0;
@@ -45,6 +50,9 @@ struct rans4x16_hip_ctx {
     int timing = 0;
     std::vector<TimedLaunch> timed[2];
     size_t max_ws = (size_t)48 << 30;       // cap for one chunk of blocks
+    // host-buffer batches: this context's own stream, and the lane contexts large batches are pipelined over
+    hipStream_t stream = nullptr;
+    struct HostPipe *pipe = nullptr;
 };
 
 #define HIPCHK(ctx, call)                                                                   \
@@ -96,13 +104,20 @@ extern "C" rans4x16_hip_ctx *rans4x16_hip_create(int device)
         rans4x16_hip_destroy(c);
         return nullptr;
     }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        c->stream = nullptr;
+        rans4x16_hip_destroy(c);
+        return nullptr;
+    }
     return c;
 }
 
 extern "C" void rans4x16_hip_destroy(rans4x16_hip_ctx *c)
 {
     if (!c) return;
+    pipe_destroy(c->pipe);
     (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (int w = 0; w < 2; w++)
         for (auto &t : c->timed[w]) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     if (c->ws) (void)hipFree(c->ws);
@@ -381,11 +396,12 @@ static int run_host_batch(rans4x16_hip_ctx *c, int n, bool decode,
     return failed + f;
 }
 
-static int run_plain_batch(rans4x16_hip_ctx *c, int n, bool decode,
-                           const unsigned char *const *in, const unsigned int *in_size,
-                           unsigned char *const *out, unsigned int *out_size, const int *order, int *status)
+// One slab of blocks: copy in, run the device path, copy out, all on the context's own stream.
+static int run_slab(rans4x16_hip_ctx *c, int n, bool decode,
+                    const unsigned char *const *in, const unsigned int *in_size,
+                    unsigned char *const *out, unsigned int *out_size, const int *order, int *status)
 {
-
+    hipStream_t s = c->stream;
     // arena: [in blocks][out slots][offset/size/status arrays]
     std::vector<u64> in_off(n), out_off(n);
     std::vector<u32> cap(n);
@@ -410,35 +426,404 @@ static int run_plain_batch(rans4x16_hip_ctx *c, int n, bool decode,
     i32 *d_order = (i32 *)(meta + 5 * arr + arr / 2);
 
     for (int i = 0; i < n; i++)
-        if (in_size[i]) HIPCHK(c, hipMemcpyAsync(d_in + in_off[i], in[i], in_size[i], hipMemcpyHostToDevice, 0));
-    HIPCHK(c, hipMemcpyAsync(d_in_off, in_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, 0));
-    HIPCHK(c, hipMemcpyAsync(d_out_off, out_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, 0));
-    HIPCHK(c, hipMemcpyAsync(d_in_size, in_size, (size_t)n * 4, hipMemcpyHostToDevice, 0));
-    HIPCHK(c, hipMemcpyAsync(d_cap, cap.data(), (size_t)n * 4, hipMemcpyHostToDevice, 0));
-    HIPCHK(c, hipMemcpyAsync(d_order, ord.data(), (size_t)n * 4, hipMemcpyHostToDevice, 0));
+        if (in_size[i]) HIPCHK(c, hipMemcpyAsync(d_in + in_off[i], in[i], in_size[i], hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_in_off, in_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_out_off, out_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_in_size, in_size, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_cap, cap.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_order, ord.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
 
     int rc;
     if (decode)
         rc = rans4x16_hip_uncompress_dev(c, n, d_in, d_in_off, d_in_size, d_out, d_out_off, d_cap, d_osz,
-                                         d_status, max_in, max_cap, nullptr);
+                                         d_status, max_in, max_cap, s);
     else
         rc = rans4x16_hip_compress_dev(c, n, d_in, d_in_off, d_in_size, d_out, d_out_off, d_cap, d_osz,
-                                       d_status, 0, d_order, max_in, nullptr);
+                                       d_status, 0, d_order, max_in, s);
     if (rc != 0) return -1;
 
     std::vector<u32> osz(n);
     std::vector<i32> st(n);
-    HIPCHK(c, hipMemcpy(osz.data(), d_osz, (size_t)n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(st.data(), d_status, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpyAsync(osz.data(), d_osz, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(st.data(), d_status, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
     int failed = 0;
     for (int i = 0; i < n; i++) {
         if (status) status[i] = st[i];
         if (st[i] != 0) { out_size[i] = 0; failed++; continue; }
         out_size[i] = osz[i];
-        if (osz[i]) HIPCHK(c, hipMemcpyAsync(out[i], d_out + out_off[i], osz[i], hipMemcpyDeviceToHost, 0));
+        if (osz[i]) HIPCHK(c, hipMemcpyAsync(out[i], d_out + out_off[i], osz[i], hipMemcpyDeviceToHost, s));
     }
-    HIPCHK(c, hipStreamSynchronize(0));
+    HIPCHK(c, hipStreamSynchronize(s));
     return failed;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Large host batches: a staged pipeline instead of one copy-in / compute / copy-out pass.
+//   * Copier threads move the callers' (pageable) buffers through their own pinned bounce buffers: a CPU
+//     memcpy per core feeding true asynchronous DMA, both PCIe directions at once.  (Copies from pageable
+//     memory issued straight to the runtime are staged by one runtime thread: ~20 GB/s both ways together.)
+//   * The batch is cut into a few slabs; the thread that queues a slab's last copy-in launches the slab's
+//     kernels on one of the lane contexts (own stream + workspace), after events on the copier streams.
+//   * A slab's results are copied out as soon as its kernels finish, beside later slabs' kernels.
+// A chain kernel needs its 25-55 ms per MiB of block size however few blocks it is given, so slabs are
+// large (up to 2 GiB of input + output capacity) and all lanes run at once.
+// Knobs: R4X16_HOST_PIPE_MB (smallest batch that takes this route, default 64; 0 = never),
+//        R4X16_HOST_THREADS (default 8), R4X16_HOST_LANES (default 4), R4X16_HOST_SLAB_MIN_MB (default 32).
+// ---------------------------------------------------------------------------------------------
+static long env_long(const char *name, long dflt)
+{
+    const char *e = getenv(name);
+    return e && *e ? atol(e) : dflt;
+}
+
+#define PIPE_CHUNK ((size_t)8 << 20)          // bytes per pinned bounce buffer
+
+struct PipeSlot {
+    u8 *pin = nullptr;
+    hipEvent_t ev = nullptr;
+    bool busy = false;                        // a DMA batch is in flight, `ev` marks its end
+    size_t fill = 0;
+    struct Out { u8 *dst; size_t off, len; };
+    std::vector<Out> outs;                    // copy-out: pinned -> caller once the DMA has landed
+};
+struct PipeCopier {
+    hipStream_t s = nullptr;
+    PipeSlot slot[2];
+    int k = 0;
+};
+struct HostPipe {
+    std::vector<PipeCopier> cp;
+    std::vector<rans4x16_hip_ctx *> lanes;
+    std::mutex *lane_mu = nullptr;
+    std::vector<hipEvent_t> events;           // grows; reused by every call
+    u32 *h_osz = nullptr;                     // pinned: per-block output sizes and statuses
+    i32 *h_st = nullptr;
+    size_t h_n = 0;
+};
+
+static void pipe_destroy(HostPipe *hp)
+{
+    if (!hp) return;
+    for (auto &c : hp->cp) {
+        if (c.s) { (void)hipStreamSynchronize(c.s); (void)hipStreamDestroy(c.s); }
+        for (auto &sl : c.slot) { if (sl.pin) (void)hipHostFree(sl.pin); if (sl.ev) (void)hipEventDestroy(sl.ev); }
+    }
+    for (auto *l : hp->lanes) rans4x16_hip_destroy(l);
+    delete[] hp->lane_mu;
+    for (auto e : hp->events) (void)hipEventDestroy(e);
+    if (hp->h_osz) (void)hipHostFree(hp->h_osz);
+    if (hp->h_st) (void)hipHostFree(hp->h_st);
+    delete hp;
+}
+
+static int pipe_prepare(rans4x16_hip_ctx *c, int threads, int nlanes, size_t nevents, size_t n)
+{
+    if (!c->pipe) c->pipe = new HostPipe();
+    HostPipe *hp = c->pipe;
+    while ((int)hp->cp.size() < threads) {
+        PipeCopier pc;
+        HIPCHK(c, hipStreamCreateWithFlags(&pc.s, hipStreamNonBlocking));
+        for (auto &sl : pc.slot) {
+            HIPCHK(c, hipHostMalloc((void **)&sl.pin, PIPE_CHUNK, hipHostMallocDefault));
+            HIPCHK(c, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
+        }
+        hp->cp.push_back(std::move(pc));
+    }
+    if ((int)hp->lanes.size() < nlanes) {
+        if (!hp->lane_mu) hp->lane_mu = new std::mutex[16];
+        while ((int)hp->lanes.size() < nlanes) {
+            rans4x16_hip_ctx *l = rans4x16_hip_create(c->device);
+            if (!l) { c->err = "host batch: cannot create a lane context"; return -1; }
+            hp->lanes.push_back(l);
+        }
+    }
+    while (hp->events.size() < nevents) {
+        hipEvent_t e;
+        HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        hp->events.push_back(e);
+    }
+    if (hp->h_n < n) {
+        if (hp->h_osz) { (void)hipHostFree(hp->h_osz); hp->h_osz = nullptr; }
+        if (hp->h_st) { (void)hipHostFree(hp->h_st); hp->h_st = nullptr; }
+        hp->h_n = 0;
+        const size_t want = n + n / 2 + 1024;
+        HIPCHK(c, hipHostMalloc((void **)&hp->h_osz, want * 4, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void **)&hp->h_st, want * 4, hipHostMallocDefault));
+        hp->h_n = want;
+    }
+    return 0;
+}
+
+struct PipeSlab {
+    int lo = 0, hi = 0;                       // blocks [lo, hi)
+    int gin = 1, gout = 1;                    // blocks per copy-in / copy-out unit
+    int nin = 0, nout = 0;                    // units
+    u32 max_in = 0, max_cap = 0;
+    std::atomic<int> in_next{0}, in_queued{0}, out_next{0};
+    std::atomic<int> launched{0}, finished{0};
+};
+
+static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
+                         const unsigned char *const *in, const unsigned int *in_size,
+                         unsigned char *const *out, unsigned int *out_size, const int *order, int *status,
+                         int threads, int nlanes)
+{
+    // ---- layout: the same arena as run_slab -----------------------------------------------------
+    std::vector<u64> in_off(n), out_off(n);
+    std::vector<u32> cap(n);
+    std::vector<i32> ord(n);
+    size_t in_tot = 0, out_tot = 0;
+    for (int i = 0; i < n; i++) {
+        in_off[i] = in_tot; in_tot += align_up((size_t)in_size[i] + 16, 256);
+        cap[i] = out_size[i];
+        out_off[i] = out_tot; out_tot += align_up((size_t)cap[i] + 16, 256);
+        ord[i] = order ? order[i] : 0;
+    }
+    const size_t arr = align_up((size_t)n * 8, 256);
+    if (ensure_stage(c, in_tot + out_tot + 6 * arr) != 0) return -1;
+    u8 *d_in = c->stage, *d_out = d_in + in_tot, *meta = d_out + out_tot;
+    u64 *d_in_off = (u64 *)meta, *d_out_off = (u64 *)(meta + arr);
+    u32 *d_in_size = (u32 *)(meta + 2 * arr), *d_cap = (u32 *)(meta + 3 * arr), *d_osz = (u32 *)(meta + 4 * arr);
+    i32 *d_status = (i32 *)(meta + 5 * arr);
+    i32 *d_order = (i32 *)(meta + 5 * arr + arr / 2);
+
+    // ---- slabs: a multiple of the lane count, each at most 2 GiB of input + capacity -------------
+    const size_t tot = in_tot + out_tot;
+    const size_t rounds = (tot + (size_t)nlanes * ((size_t)2 << 30) - 1) / ((size_t)nlanes * ((size_t)2 << 30));
+    size_t nslab = (rounds ? rounds : 1) * (size_t)nlanes;
+    const long slab_min_mb = env_long("R4X16_HOST_SLAB_MIN_MB", 32);
+    while (nslab > 1 && tot / nslab < ((size_t)(slab_min_mb > 0 ? slab_min_mb : 1) << 20)) nslab--;
+    if (nslab > (size_t)n) nslab = (size_t)n;
+    std::vector<PipeSlab> slabs(nslab);
+    {
+        const size_t per = (tot + nslab - 1) / nslab;
+        size_t acc = 0, j = 0;
+        slabs[0].lo = 0;
+        for (int i = 0; i < n; i++) {
+            acc += align_up((size_t)in_size[i] + 16, 256) + align_up((size_t)cap[i] + 16, 256);
+            const int left = n - (i + 1);
+            if (j + 1 < nslab && (acc >= per * (j + 1) || left == (int)(nslab - j - 1))) {
+                slabs[j].hi = i + 1;
+                slabs[++j].lo = i + 1;
+            }
+        }
+        slabs[j].hi = n;
+        nslab = j + 1;
+    }
+    for (size_t j = 0; j < nslab; j++) {
+        PipeSlab &S = slabs[j];
+        for (int i = S.lo; i < S.hi; i++) {
+            if (in_size[i] > S.max_in) S.max_in = in_size[i];
+            if (cap[i] > S.max_cap) S.max_cap = cap[i];
+        }
+        const size_t gi = PIPE_CHUNK / (align_up((size_t)S.max_in + 16, 256));
+        const size_t go = PIPE_CHUNK / ((size_t)S.max_cap + 64);
+        S.gin = (int)(gi < 1 ? 1 : gi > 512 ? 512 : gi);
+        S.gout = (int)(go < 1 ? 1 : go > 512 ? 512 : go);
+        S.nin = (S.hi - S.lo + S.gin - 1) / S.gin;
+        S.nout = (S.hi - S.lo + S.gout - 1) / S.gout;
+    }
+    if (pipe_prepare(c, threads, nlanes, nslab * ((size_t)threads + 1), (size_t)n) != 0) return -1;
+    HostPipe *hp = c->pipe;
+
+    hipStream_t s0 = c->stream;
+    HIPCHK(c, hipMemcpyAsync(d_in_off, in_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, s0));
+    HIPCHK(c, hipMemcpyAsync(d_out_off, out_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, s0));
+    HIPCHK(c, hipMemcpyAsync(d_in_size, in_size, (size_t)n * 4, hipMemcpyHostToDevice, s0));
+    HIPCHK(c, hipMemcpyAsync(d_cap, cap.data(), (size_t)n * 4, hipMemcpyHostToDevice, s0));
+    HIPCHK(c, hipMemcpyAsync(d_order, ord.data(), (size_t)n * 4, hipMemcpyHostToDevice, s0));
+    HIPCHK(c, hipStreamSynchronize(s0));
+
+    std::atomic<int> broken{0};
+    std::mutex err_mu;
+    const bool trace = env_long("R4X16_HOST_TRACE", 0) != 0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto now_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    if (trace) fprintf(stderr, "[pipe] %s n=%d slabs=%zu threads=%d lanes=%d in=%.1f MB cap=%.1f MB\n", decode ? "dec" : "enc", n, nslab, threads, nlanes, in_tot / 1e6, out_tot / 1e6);
+    auto fail = [&](const char *what, hipError_t e) {
+        std::lock_guard<std::mutex> g(err_mu);
+        if (!broken.exchange(1)) c->err = std::string("host batch pipeline: ") + what + ": " + hipGetErrorString(e);
+    };
+#define PIPECHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(#call, e_); return false; } } while (0)
+
+    // wait for the slot's DMA batch, then hand copy-out bytes to the caller's buffers
+    auto drain = [&](PipeSlot &sl) -> bool {
+        if (sl.busy) {
+            PIPECHK(hipEventSynchronize(sl.ev));
+            for (auto &o : sl.outs) memcpy(o.dst, sl.pin + o.off, o.len);
+            sl.busy = false;
+        }
+        sl.outs.clear();
+        sl.fill = 0;
+        return true;
+    };
+    // close the current slot (its DMAs are queued), move to the other one and make it free
+    auto flip = [&](PipeCopier &pc) -> bool {
+        PipeSlot &sl = pc.slot[pc.k];
+        if (sl.fill) { PIPECHK(hipEventRecord(sl.ev, pc.s)); sl.busy = true; }
+        pc.k ^= 1;
+        return drain(pc.slot[pc.k]);
+    };
+
+    auto launch_slab = [&](size_t j) -> bool {
+        PipeSlab &S = slabs[j];
+        const size_t li = j % (size_t)nlanes;
+        rans4x16_hip_ctx *l = hp->lanes[li];
+        std::lock_guard<std::mutex> g(hp->lane_mu[li]);
+        for (int t = 0; t < threads; t++) {
+            hipEvent_t e = hp->events[j * ((size_t)threads + 1) + (size_t)t];
+            PIPECHK(hipEventRecord(e, hp->cp[t].s));
+            PIPECHK(hipStreamWaitEvent(l->stream, e, 0));
+        }
+        const int lo = S.lo, m = S.hi - S.lo;
+        int rc;
+        if (decode)
+            rc = rans4x16_hip_uncompress_dev(l, m, d_in, d_in_off + lo, d_in_size + lo, d_out, d_out_off + lo, d_cap + lo,
+                                             d_osz + lo, d_status + lo, S.max_in, S.max_cap, l->stream);
+        else
+            rc = rans4x16_hip_compress_dev(l, m, d_in, d_in_off + lo, d_in_size + lo, d_out, d_out_off + lo, d_cap + lo,
+                                           d_osz + lo, d_status + lo, 0, d_order + lo, S.max_in, l->stream);
+        if (rc != 0) {
+            std::lock_guard<std::mutex> g2(err_mu);
+            if (!broken.exchange(1)) c->err = l->err;
+            return false;
+        }
+        PIPECHK(hipMemcpyAsync(hp->h_osz + lo, d_osz + lo, (size_t)m * 4, hipMemcpyDeviceToHost, l->stream));
+        PIPECHK(hipMemcpyAsync(hp->h_st + lo, d_status + lo, (size_t)m * 4, hipMemcpyDeviceToHost, l->stream));
+        PIPECHK(hipEventRecord(hp->events[j * ((size_t)threads + 1) + (size_t)threads], l->stream));
+        S.launched.store(1, std::memory_order_release);
+        if (trace) fprintf(stderr, "[pipe] slab %zu (%d blocks) launched on lane %zu at %.1f ms\n", j, m, li, now_ms());
+        return true;
+    };
+
+    // one copy-in unit: blocks [b0, b1) of slab j
+    auto copy_in_unit = [&](PipeCopier &pc, int b0, int b1) -> bool {
+        const u64 base = in_off[b0];
+        const u64 extent = in_off[b1 - 1] + in_size[b1 - 1] - base;
+        if (extent <= PIPE_CHUNK) {
+            PipeSlot &sl = pc.slot[pc.k];                      // free: flip() drained it
+            for (int i = b0; i < b1; i++)
+                if (in_size[i]) memcpy(sl.pin + (in_off[i] - base), in[i], in_size[i]);
+            if (extent) {
+                PIPECHK(hipMemcpyAsync(d_in + base, sl.pin, extent, hipMemcpyHostToDevice, pc.s));
+                sl.fill = extent;
+            }
+            return flip(pc);
+        }
+        // a single block larger than a bounce buffer: piece by piece
+        for (u64 p = 0; p < extent; p += PIPE_CHUNK) {
+            const size_t len = (size_t)(extent - p < PIPE_CHUNK ? extent - p : PIPE_CHUNK);
+            PipeSlot &sl = pc.slot[pc.k];
+            memcpy(sl.pin, in[b0] + p, len);
+            PIPECHK(hipMemcpyAsync(d_in + base + p, sl.pin, len, hipMemcpyHostToDevice, pc.s));
+            sl.fill = len;
+            if (!flip(pc)) return false;
+        }
+        return true;
+    };
+    // one copy-out unit (the slab's kernels have finished, sizes and statuses are in pinned memory)
+    auto copy_out_unit = [&](PipeCopier &pc, int b0, int b1) -> bool {
+        for (int i = b0; i < b1; i++) {
+            if (hp->h_st[i] != 0) continue;
+            const size_t sz = hp->h_osz[i];
+            for (size_t p = 0; p < sz;) {
+                PipeSlot *sl = &pc.slot[pc.k];
+                size_t at = (sl->fill + 63) & ~(size_t)63;
+                if (at >= PIPE_CHUNK || (PIPE_CHUNK - at < sz - p && at != 0)) {
+                    if (!flip(pc)) return false;
+                    sl = &pc.slot[pc.k];
+                    at = 0;
+                }
+                const size_t len = sz - p < PIPE_CHUNK - at ? sz - p : PIPE_CHUNK - at;
+                PIPECHK(hipMemcpyAsync(sl->pin + at, d_out + out_off[i] + p, len, hipMemcpyDeviceToHost, pc.s));
+                sl->outs.push_back({out[i] + p, at, len});
+                sl->fill = at + len;
+                p += len;
+            }
+        }
+        return flip(pc);
+    };
+
+    auto worker = [&](int t) {
+        if (hipSetDevice(c->device) != hipSuccess) { fail("hipSetDevice", hipErrorInvalidDevice); return; }
+        PipeCopier &pc = hp->cp[t];
+        pc.k = 0;
+        for (auto &sl : pc.slot) { sl.busy = false; sl.fill = 0; sl.outs.clear(); }
+        size_t in_low = 0, out_low = 0;
+        while (!broken.load(std::memory_order_relaxed)) {
+            bool did = false;
+            // copy-out first: it frees the tail of the pipeline
+            while (out_low < nslab && slabs[out_low].out_next.load(std::memory_order_relaxed) >= slabs[out_low].nout) out_low++;
+            for (size_t j = out_low; j < nslab && !did; j++) {
+                PipeSlab &S = slabs[j];
+                if (!S.launched.load(std::memory_order_acquire)) break;
+                if (S.out_next.load(std::memory_order_relaxed) >= S.nout) continue;
+                if (!S.finished.load(std::memory_order_acquire)) {
+                    const hipError_t q = hipEventQuery(hp->events[j * ((size_t)threads + 1) + (size_t)threads]);
+                    if (q == hipErrorNotReady) continue;
+                    if (q != hipSuccess) { fail("hipEventQuery", q); return; }
+                    if (!S.finished.exchange(1) && trace) fprintf(stderr, "[pipe] slab %zu kernels seen finished at %.1f ms\n", j, now_ms());
+                }
+                const int u = S.out_next.fetch_add(1);
+                if (u >= S.nout) continue;
+                const int b0 = S.lo + u * S.gout, b1 = b0 + S.gout < S.hi ? b0 + S.gout : S.hi;
+                if (!copy_out_unit(pc, b0, b1)) return;
+                did = true;
+            }
+            if (did) continue;
+            while (in_low < nslab && slabs[in_low].in_next.load(std::memory_order_relaxed) >= slabs[in_low].nin) in_low++;
+            if (in_low < nslab) {
+                PipeSlab &S = slabs[in_low];
+                const int u = S.in_next.fetch_add(1);
+                if (u < S.nin) {
+                    const int b0 = S.lo + u * S.gin, b1 = b0 + S.gin < S.hi ? b0 + S.gin : S.hi;
+                    if (!copy_in_unit(pc, b0, b1)) return;
+                    if (S.in_queued.fetch_add(1, std::memory_order_acq_rel) + 1 == S.nin)
+                        if (!launch_slab(in_low)) return;
+                }
+                continue;
+            }
+            if (out_low >= nslab) break;                       // every unit has been taken
+            // nothing to take yet: finish what this thread has in flight, then wait for a kernel
+            if (!flip(pc) || !flip(pc)) return;
+            std::this_thread::sleep_for(std::chrono::microseconds(100));
+        }
+        if (!broken.load()) { if (flip(pc)) (void)flip(pc); }
+    };
+
+    std::vector<std::thread> th;
+    for (int t = 1; t < threads; t++) th.emplace_back(worker, t);
+    worker(0);
+    for (auto &t : th) t.join();
+    if (trace) fprintf(stderr, "[pipe] done at %.1f ms\n", now_ms());
+#undef PIPECHK
+    if (broken.load()) {
+        (void)hipDeviceSynchronize();
+        return -1;
+    }
+    int failed = 0;
+    for (int i = 0; i < n; i++) {
+        if (status) status[i] = hp->h_st[i];
+        if (hp->h_st[i] != 0) { out_size[i] = 0; failed++; }
+        else out_size[i] = hp->h_osz[i];
+    }
+    return failed;
+}
+
+static int run_plain_batch(rans4x16_hip_ctx *c, int n, bool decode,
+                           const unsigned char *const *in, const unsigned int *in_size,
+                           unsigned char *const *out, unsigned int *out_size, const int *order, int *status)
+{
+    const long pipe_mb = env_long("R4X16_HOST_PIPE_MB", 64);
+    long threads = env_long("R4X16_HOST_THREADS", 8), nlanes = env_long("R4X16_HOST_LANES", 4);
+    threads = threads < 1 ? 1 : threads > 32 ? 32 : threads;
+    nlanes = nlanes < 1 ? 1 : nlanes > 16 ? 16 : nlanes;
+    size_t tot = 0;
+    for (int i = 0; i < n; i++) tot += (size_t)in_size[i] + out_size[i];
+    if (pipe_mb <= 0 || tot < ((size_t)pipe_mb << 20))
+        return run_slab(c, n, decode, in, in_size, out, out_size, order, status);
+    return run_pipelined(c, n, decode, in, in_size, out, out_size, order, status, (int)threads, (int)nlanes);
 }
 
 // ---------------------------------------------------------------------------------------------

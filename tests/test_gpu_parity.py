@@ -359,3 +359,37 @@ def test_alphabet_sizes_at_the_tree_depth_boundaries(H, oracle):
     assert all(s == 0 for s in st), st
     bad = [(len(set(d)), o) for d, o, x in zip(datas, orders, dec) if x != d]
     assert not bad, bad
+
+
+def test_host_batch_pipeline_matches_single_pass(H, oracle, monkeypatch):
+    """Large host batches go through the staged pipeline (pinned bounce buffers, copier threads, slabs on
+    several lanes: r4x16_api.hip run_pipelined).  Force that route on a small batch with everything awkward
+    in it: empty and tiny blocks, a block larger than a bounce buffer, per-block orders, blocks that must
+    fail on decode - and require reference bytes and the same statuses as the single-pass route."""
+    monkeypatch.setenv("R4X16_HOST_PIPE_MB", "1")
+    monkeypatch.setenv("R4X16_HOST_SLAB_MIN_MB", "1")
+    monkeypatch.setenv("R4X16_HOST_THREADS", "5")
+    monkeypatch.setenv("R4X16_HOST_LANES", "3")
+    rs = np.random.RandomState(4242)
+    datas = _random_inputs(rs, 120, max_n=300000)
+    datas += [b"", b"x", datagen.tile("q40+dir", 9 * (1 << 20) + 13, 3).tobytes(), b"", datagen.tile("q4", 1 << 20, 1).tobytes()]
+    datas += _random_inputs(rs, 60, max_n=100000)
+    orders = [int(rs.choice(sorted(DEVICE_ORDERS))) for _ in datas]
+    enc, st = H.compress_batch(datas, orders)
+    want = [oracle.compress(d, o) for d, o in zip(datas, orders)]
+    bad = [(i, len(d), o) for i, (d, o, e, w) in enumerate(zip(datas, orders, enc, want)) if e != w]
+    assert not bad, bad[:10]
+    # decode, with some streams damaged so that statuses differ per block
+    comps = list(want)
+    damaged = set(int(i) for i in rs.choice(len(comps), 25, replace=False) if len(comps[i]) > 40)
+    for i in damaged:
+        b = bytearray(comps[i]); b[1] ^= 0x55; b = b[:len(b) // 2]; comps[i] = bytes(b)
+    caps = [len(d) for d in datas]
+    dec, st = H.uncompress_batch(comps, caps)
+    monkeypatch.setenv("R4X16_HOST_PIPE_MB", "0")
+    dec1, st1 = H.uncompress_batch(comps, caps)
+    assert list(st) == list(st1)
+    assert dec == dec1
+    for i, (d, x) in enumerate(zip(datas, dec)):
+        if i not in damaged:
+            assert x == d, i
