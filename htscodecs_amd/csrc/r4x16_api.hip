@@ -463,13 +463,16 @@ static int run_slab(rans4x16_hip_ctx *c, int n, bool decode,
 //   * Copier threads move the callers' (pageable) buffers through their own pinned bounce buffers: a CPU
 //     memcpy per core feeding true asynchronous DMA, both PCIe directions at once.  (Copies from pageable
 //     memory issued straight to the runtime are staged by one runtime thread: ~20 GB/s both ways together.)
+//     All copy-in DMA shares one stream and all copy-out DMA another: the runtime multiplexes streams onto
+//     four hardware queues, and a copy that lands in the queue of a running 50 ms chain kernel waits for it
+//     (measured: with a stream per copier thread, slabs were launched only as their predecessors finished).
 //   * The batch is cut into a few slabs; the thread that queues a slab's last copy-in launches the slab's
 //     kernels on one of the lane contexts (own stream + workspace), after events on the copier streams.
 //   * A slab's results are copied out as soon as its kernels finish, beside later slabs' kernels.
 // A chain kernel needs its 25-55 ms per MiB of block size however few blocks it is given, so slabs are
 // large (up to 2 GiB of input + output capacity) and all lanes run at once.
 // Knobs: R4X16_HOST_PIPE_MB (smallest batch that takes this route, default 64; 0 = never),
-//        R4X16_HOST_THREADS (default 8), R4X16_HOST_LANES (default 4), R4X16_HOST_SLAB_MIN_MB (default 32).
+//        R4X16_HOST_THREADS (default 8), R4X16_HOST_LANES (default 2), R4X16_HOST_SLAB_MIN_MB (default 32).
 // ---------------------------------------------------------------------------------------------
 static long env_long(const char *name, long dflt)
 {
@@ -488,12 +491,12 @@ struct PipeSlot {
     std::vector<Out> outs;                    // copy-out: pinned -> caller once the DMA has landed
 };
 struct PipeCopier {
-    hipStream_t s = nullptr;
     PipeSlot slot[2];
     int k = 0;
 };
 struct HostPipe {
     std::vector<PipeCopier> cp;
+    hipStream_t s_out = nullptr;              // copy-out DMA (copy-in uses the context's own stream)
     std::vector<rans4x16_hip_ctx *> lanes;
     std::mutex *lane_mu = nullptr;
     std::vector<hipEvent_t> events;           // grows; reused by every call
@@ -505,8 +508,8 @@ struct HostPipe {
 static void pipe_destroy(HostPipe *hp)
 {
     if (!hp) return;
+    if (hp->s_out) { (void)hipStreamSynchronize(hp->s_out); (void)hipStreamDestroy(hp->s_out); }
     for (auto &c : hp->cp) {
-        if (c.s) { (void)hipStreamSynchronize(c.s); (void)hipStreamDestroy(c.s); }
         for (auto &sl : c.slot) { if (sl.pin) (void)hipHostFree(sl.pin); if (sl.ev) (void)hipEventDestroy(sl.ev); }
     }
     for (auto *l : hp->lanes) rans4x16_hip_destroy(l);
@@ -521,9 +524,9 @@ static int pipe_prepare(rans4x16_hip_ctx *c, int threads, int nlanes, size_t nev
 {
     if (!c->pipe) c->pipe = new HostPipe();
     HostPipe *hp = c->pipe;
+    if (!hp->s_out) HIPCHK(c, hipStreamCreateWithFlags(&hp->s_out, hipStreamNonBlocking));
     while ((int)hp->cp.size() < threads) {
         PipeCopier pc;
-        HIPCHK(c, hipStreamCreateWithFlags(&pc.s, hipStreamNonBlocking));
         for (auto &sl : pc.slot) {
             HIPCHK(c, hipHostMalloc((void **)&sl.pin, PIPE_CHUNK, hipHostMallocDefault));
             HIPCHK(c, hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming));
@@ -535,6 +538,18 @@ static int pipe_prepare(rans4x16_hip_ctx *c, int threads, int nlanes, size_t nev
         while ((int)hp->lanes.size() < nlanes) {
             rans4x16_hip_ctx *l = rans4x16_hip_create(c->device);
             if (!l) { c->err = "host batch: cannot create a lane context"; return -1; }
+            // The runtime keeps one pool of hardware queues per stream priority and multiplexes the streams of
+            // a priority onto it; two lane streams of equal priority were seen sharing a queue, which runs their
+            // kernels one after the other.  Lanes therefore take different priorities: different queues.
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least > greatest) {
+                const int levels = least - greatest + 1;
+                hipStream_t ps = nullptr;
+                if (hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, greatest + (int)(hp->lanes.size() % (size_t)levels)) == hipSuccess) {
+                    (void)hipStreamDestroy(l->stream);
+                    l->stream = ps;
+                }
+            }
             hp->lanes.push_back(l);
         }
     }
@@ -588,10 +603,17 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
     i32 *d_status = (i32 *)(meta + 5 * arr);
     i32 *d_order = (i32 *)(meta + 5 * arr + arr / 2);
 
-    // ---- slabs: a multiple of the lane count, each at most 2 GiB of input + capacity -------------
+    // ---- slabs: a multiple of the lane count.  A chain kernel takes the same time for one block as for a few
+    // thousand (it is bound by the length of a chain, not by their number), so a slab holds up to 4,096 blocks
+    // per lane round - or 8 GiB of input + capacity, which bounds the lane workspaces.
     const size_t tot = in_tot + out_tot;
-    const size_t rounds = (tot + (size_t)nlanes * ((size_t)2 << 30) - 1) / ((size_t)nlanes * ((size_t)2 << 30));
-    size_t nslab = (rounds ? rounds : 1) * (size_t)nlanes;
+    size_t rounds = ((size_t)n + (size_t)nlanes * 4096 - 1) / ((size_t)nlanes * 4096);
+    const size_t rounds_b = (tot + (size_t)nlanes * ((size_t)8 << 30) - 1) / ((size_t)nlanes * ((size_t)8 << 30));
+    if (rounds_b > rounds) rounds = rounds_b;
+    // (encode slabs are half that: its chain kernel is the shorter one, ~28 ms per MiB of block size against the
+    //  decoder's ~52, and sparse bound-sized output slots make its copy-out the slower DMA - a smaller last
+    //  slab shortens the tail of the pipeline)
+    size_t nslab = (rounds ? rounds : 1) * (size_t)nlanes * (decode ? 1u : 2u);
     const long slab_min_mb = env_long("R4X16_HOST_SLAB_MIN_MB", 32);
     while (nslab > 1 && tot / nslab < ((size_t)(slab_min_mb > 0 ? slab_min_mb : 1) << 20)) nslab--;
     if (nslab > (size_t)n) nslab = (size_t)n;
@@ -624,10 +646,11 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
         S.nin = (S.hi - S.lo + S.gin - 1) / S.gin;
         S.nout = (S.hi - S.lo + S.gout - 1) / S.gout;
     }
-    if (pipe_prepare(c, threads, nlanes, nslab * ((size_t)threads + 1), (size_t)n) != 0) return -1;
+    if (pipe_prepare(c, threads, nlanes, 2 * nslab, (size_t)n) != 0) return -1;
     HostPipe *hp = c->pipe;
 
     hipStream_t s0 = c->stream;
+    const hipStream_t s_in = c->stream, s_out = hp->s_out;
     HIPCHK(c, hipMemcpyAsync(d_in_off, in_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, s0));
     HIPCHK(c, hipMemcpyAsync(d_out_off, out_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, s0));
     HIPCHK(c, hipMemcpyAsync(d_in_size, in_size, (size_t)n * 4, hipMemcpyHostToDevice, s0));
@@ -659,9 +682,9 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
         return true;
     };
     // close the current slot (its DMAs are queued), move to the other one and make it free
-    auto flip = [&](PipeCopier &pc) -> bool {
+    auto flip = [&](PipeCopier &pc, hipStream_t st) -> bool {
         PipeSlot &sl = pc.slot[pc.k];
-        if (sl.fill) { PIPECHK(hipEventRecord(sl.ev, pc.s)); sl.busy = true; }
+        if (sl.fill) { PIPECHK(hipEventRecord(sl.ev, st)); sl.busy = true; }
         pc.k ^= 1;
         return drain(pc.slot[pc.k]);
     };
@@ -671,9 +694,9 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
         const size_t li = j % (size_t)nlanes;
         rans4x16_hip_ctx *l = hp->lanes[li];
         std::lock_guard<std::mutex> g(hp->lane_mu[li]);
-        for (int t = 0; t < threads; t++) {
-            hipEvent_t e = hp->events[j * ((size_t)threads + 1) + (size_t)t];
-            PIPECHK(hipEventRecord(e, hp->cp[t].s));
+        {
+            hipEvent_t e = hp->events[2 * j];              // every copy-in of this slab is queued on s_in
+            PIPECHK(hipEventRecord(e, s_in));
             PIPECHK(hipStreamWaitEvent(l->stream, e, 0));
         }
         const int lo = S.lo, m = S.hi - S.lo;
@@ -691,7 +714,7 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
         }
         PIPECHK(hipMemcpyAsync(hp->h_osz + lo, d_osz + lo, (size_t)m * 4, hipMemcpyDeviceToHost, l->stream));
         PIPECHK(hipMemcpyAsync(hp->h_st + lo, d_status + lo, (size_t)m * 4, hipMemcpyDeviceToHost, l->stream));
-        PIPECHK(hipEventRecord(hp->events[j * ((size_t)threads + 1) + (size_t)threads], l->stream));
+        PIPECHK(hipEventRecord(hp->events[2 * j + 1], l->stream));
         S.launched.store(1, std::memory_order_release);
         if (trace) fprintf(stderr, "[pipe] slab %zu (%d blocks) launched on lane %zu at %.1f ms\n", j, m, li, now_ms());
         return true;
@@ -706,24 +729,41 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
             for (int i = b0; i < b1; i++)
                 if (in_size[i]) memcpy(sl.pin + (in_off[i] - base), in[i], in_size[i]);
             if (extent) {
-                PIPECHK(hipMemcpyAsync(d_in + base, sl.pin, extent, hipMemcpyHostToDevice, pc.s));
+                PIPECHK(hipMemcpyAsync(d_in + base, sl.pin, extent, hipMemcpyHostToDevice, s_in));
                 sl.fill = extent;
             }
-            return flip(pc);
+            return flip(pc, s_in);
         }
         // a single block larger than a bounce buffer: piece by piece
         for (u64 p = 0; p < extent; p += PIPE_CHUNK) {
             const size_t len = (size_t)(extent - p < PIPE_CHUNK ? extent - p : PIPE_CHUNK);
             PipeSlot &sl = pc.slot[pc.k];
             memcpy(sl.pin, in[b0] + p, len);
-            PIPECHK(hipMemcpyAsync(d_in + base + p, sl.pin, len, hipMemcpyHostToDevice, pc.s));
+            PIPECHK(hipMemcpyAsync(d_in + base + p, sl.pin, len, hipMemcpyHostToDevice, s_in));
             sl.fill = len;
-            if (!flip(pc)) return false;
+            if (!flip(pc, s_in)) return false;
         }
         return true;
     };
     // one copy-out unit (the slab's kernels have finished, sizes and statuses are in pinned memory)
     auto copy_out_unit = [&](PipeCopier &pc, int b0, int b1) -> bool {
+        // results that nearly fill their slots (decode: the capacity is the size) travel as one DMA over the
+        // whole extent, like copy-in; sparse ones (encode: bound-sized slots) block by block
+        {
+            size_t sum = 0;
+            u64 end = out_off[b0];
+            for (int i = b0; i < b1; i++)
+                if (hp->h_st[i] == 0 && hp->h_osz[i]) { sum += hp->h_osz[i]; end = out_off[i] + hp->h_osz[i]; }
+            const u64 base = out_off[b0], extent = end - base;
+            if (sum && extent <= PIPE_CHUNK && sum * 4 >= extent * 3) {
+                PipeSlot &sl = pc.slot[pc.k];                  // free: the previous unit ended with flip()
+                PIPECHK(hipMemcpyAsync(sl.pin, d_out + base, extent, hipMemcpyDeviceToHost, s_out));
+                for (int i = b0; i < b1; i++)
+                    if (hp->h_st[i] == 0 && hp->h_osz[i]) sl.outs.push_back({out[i], (size_t)(out_off[i] - base), hp->h_osz[i]});
+                sl.fill = extent;
+                return flip(pc, s_out);
+            }
+        }
         for (int i = b0; i < b1; i++) {
             if (hp->h_st[i] != 0) continue;
             const size_t sz = hp->h_osz[i];
@@ -731,18 +771,18 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
                 PipeSlot *sl = &pc.slot[pc.k];
                 size_t at = (sl->fill + 63) & ~(size_t)63;
                 if (at >= PIPE_CHUNK || (PIPE_CHUNK - at < sz - p && at != 0)) {
-                    if (!flip(pc)) return false;
+                    if (!flip(pc, s_out)) return false;
                     sl = &pc.slot[pc.k];
                     at = 0;
                 }
                 const size_t len = sz - p < PIPE_CHUNK - at ? sz - p : PIPE_CHUNK - at;
-                PIPECHK(hipMemcpyAsync(sl->pin + at, d_out + out_off[i] + p, len, hipMemcpyDeviceToHost, pc.s));
+                PIPECHK(hipMemcpyAsync(sl->pin + at, d_out + out_off[i] + p, len, hipMemcpyDeviceToHost, s_out));
                 sl->outs.push_back({out[i] + p, at, len});
                 sl->fill = at + len;
                 p += len;
             }
         }
-        return flip(pc);
+        return flip(pc, s_out);
     };
 
     auto worker = [&](int t) {
@@ -751,45 +791,56 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
         pc.k = 0;
         for (auto &sl : pc.slot) { sl.busy = false; sl.fill = 0; sl.outs.clear(); }
         size_t in_low = 0, out_low = 0;
-        while (!broken.load(std::memory_order_relaxed)) {
-            bool did = false;
-            // copy-out first: it frees the tail of the pipeline
+        // Copy-in feeds the kernels and copy-out drains them; the even threads look for copy-in work first, the
+        // odd ones for copy-out, and each takes the other kind when its own has nothing ready.
+        const bool in_first = (t & 1) == 0;
+        auto take_out = [&](bool &err) -> bool {
             while (out_low < nslab && slabs[out_low].out_next.load(std::memory_order_relaxed) >= slabs[out_low].nout) out_low++;
-            for (size_t j = out_low; j < nslab && !did; j++) {
+            for (size_t j = out_low; j < nslab; j++) {
                 PipeSlab &S = slabs[j];
-                if (!S.launched.load(std::memory_order_acquire)) break;
                 if (S.out_next.load(std::memory_order_relaxed) >= S.nout) continue;
+                if (!S.launched.load(std::memory_order_acquire)) continue;
                 if (!S.finished.load(std::memory_order_acquire)) {
-                    const hipError_t q = hipEventQuery(hp->events[j * ((size_t)threads + 1) + (size_t)threads]);
+                    const hipError_t q = hipEventQuery(hp->events[2 * j + 1]);
                     if (q == hipErrorNotReady) continue;
-                    if (q != hipSuccess) { fail("hipEventQuery", q); return; }
+                    if (q != hipSuccess) { fail("hipEventQuery", q); err = true; return false; }
                     if (!S.finished.exchange(1) && trace) fprintf(stderr, "[pipe] slab %zu kernels seen finished at %.1f ms\n", j, now_ms());
                 }
                 const int u = S.out_next.fetch_add(1);
                 if (u >= S.nout) continue;
                 const int b0 = S.lo + u * S.gout, b1 = b0 + S.gout < S.hi ? b0 + S.gout : S.hi;
-                if (!copy_out_unit(pc, b0, b1)) return;
-                did = true;
+                if (!copy_out_unit(pc, b0, b1)) { err = true; return false; }
+                return true;
             }
-            if (did) continue;
-            while (in_low < nslab && slabs[in_low].in_next.load(std::memory_order_relaxed) >= slabs[in_low].nin) in_low++;
-            if (in_low < nslab) {
+            return false;
+        };
+        auto take_in = [&](bool &err) -> bool {
+            for (;;) {
+                while (in_low < nslab && slabs[in_low].in_next.load(std::memory_order_relaxed) >= slabs[in_low].nin) in_low++;
+                if (in_low >= nslab) return false;
                 PipeSlab &S = slabs[in_low];
                 const int u = S.in_next.fetch_add(1);
-                if (u < S.nin) {
-                    const int b0 = S.lo + u * S.gin, b1 = b0 + S.gin < S.hi ? b0 + S.gin : S.hi;
-                    if (!copy_in_unit(pc, b0, b1)) return;
-                    if (S.in_queued.fetch_add(1, std::memory_order_acq_rel) + 1 == S.nin)
-                        if (!launch_slab(in_low)) return;
-                }
-                continue;
+                if (u >= S.nin) continue;
+                const int b0 = S.lo + u * S.gin, b1 = b0 + S.gin < S.hi ? b0 + S.gin : S.hi;
+                if (!copy_in_unit(pc, b0, b1)) { err = true; return false; }
+                if (S.in_queued.fetch_add(1, std::memory_order_acq_rel) + 1 == S.nin)
+                    if (!launch_slab(in_low)) { err = true; return false; }
+                return true;
             }
+        };
+        while (!broken.load(std::memory_order_relaxed)) {
+            bool err = false;
+            bool did = in_first ? take_in(err) : take_out(err);
+            if (err) return;
+            if (!did) did = in_first ? take_out(err) : take_in(err);
+            if (err) return;
+            if (did) continue;
             if (out_low >= nslab) break;                       // every unit has been taken
             // nothing to take yet: finish what this thread has in flight, then wait for a kernel
-            if (!flip(pc) || !flip(pc)) return;
+            if (!flip(pc, s_in) || !flip(pc, s_in)) return;
             std::this_thread::sleep_for(std::chrono::microseconds(100));
         }
-        if (!broken.load()) { if (flip(pc)) (void)flip(pc); }
+        if (!broken.load()) { if (flip(pc, s_in)) (void)flip(pc, s_in); }
     };
 
     std::vector<std::thread> th;
@@ -816,7 +867,7 @@ static int run_plain_batch(rans4x16_hip_ctx *c, int n, bool decode,
                            unsigned char *const *out, unsigned int *out_size, const int *order, int *status)
 {
     const long pipe_mb = env_long("R4X16_HOST_PIPE_MB", 64);
-    long threads = env_long("R4X16_HOST_THREADS", 8), nlanes = env_long("R4X16_HOST_LANES", 4);
+    long threads = env_long("R4X16_HOST_THREADS", 8), nlanes = env_long("R4X16_HOST_LANES", 2);
     threads = threads < 1 ? 1 : threads > 32 ? 32 : threads;
     nlanes = nlanes < 1 ? 1 : nlanes > 16 ? 16 : nlanes;
     size_t tot = 0;
