@@ -93,6 +93,30 @@ def compress_batch(blocks, orders):
     return _host_batch(blocks, False, orders=orders)
 
 
+def compress_best_batch(blocks, methods):
+    """The reference's caller-side "try several methods, keep the smallest" loop (tokenise_name3.c:1246-1300)
+    as one call: list of bytes, list of order values -> (list of bytes|None, chosen order per block, statuses)."""
+    ctx = _Ctx()
+    L = ctx.L
+    n, k = len(blocks), len(methods)
+    srcs = [np.frombuffer(bytes(b), dtype=np.uint8) for b in blocks]
+    capv = [max(L.rans_compress_bound_4x16(len(s), m) for m in methods) for s in srcs]
+    outs = [np.empty(max(c, 1), dtype=np.uint8) for c in capv]
+    dummy = np.zeros(1, dtype=np.uint8)
+    in_p = (C.c_void_p * n)(*[(s.ctypes.data if len(s) else dummy.ctypes.data) for s in srcs])
+    out_p = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    in_sz = (C.c_uint * n)(*[len(s) for s in srcs])
+    out_sz = (C.c_uint * n)(*capv)
+    meth = (C.c_int * k)(*methods)
+    chosen = (C.c_int * n)()
+    status = (C.c_int * n)()
+    rc = L.rans4x16_hip_compress_best_batch(ctx.h, n, in_p, in_sz, out_p, out_sz, k, meth, chosen, status)
+    if rc < 0:
+        raise RuntimeError("batch call failed: " + ctx.error())
+    res = [outs[i][:out_sz[i]].tobytes() if status[i] == 0 else None for i in range(n)]
+    return res, list(chosen), list(status)
+
+
 def uncompress_batch(blocks, caps):
     """list of compressed bytes, list of output capacities -> (list of bytes|None, statuses)."""
     return _host_batch(blocks, True, caps=caps)

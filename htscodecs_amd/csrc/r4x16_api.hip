@@ -579,29 +579,40 @@ struct PipeSlab {
     std::atomic<int> launched{0}, finished{0};
 };
 
+// K > 1 (encode only) is the "try K methods, keep the smallest" mode of SURVEY §8f-3: the K candidates of a
+// block share its one copy of the input, only the winner is copied out (first candidate wins ties,
+// tokenise_name3.c:1283-1286), and win_k[i] receives its index in methods[].
 static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
                          const unsigned char *const *in, const unsigned int *in_size,
                          unsigned char *const *out, unsigned int *out_size, const int *order, int *status,
-                         int threads, int nlanes)
+                         int threads, int nlanes, int K = 1, const int *methods = nullptr, int *win_k = nullptr)
 {
-    // ---- layout: the same arena as run_slab -----------------------------------------------------
-    std::vector<u64> in_off(n), out_off(n);
-    std::vector<u32> cap(n);
-    std::vector<i32> ord(n);
+    // ---- layout: the same arena as run_slab; K output slots per block --------------------------------
+    const size_t ni = (size_t)n * (size_t)K;
+    if (ni > (size_t)INT_MAX) { c->err = "host batch: too many candidates"; return -1; }
+    std::vector<u64> in_off(n), in_off_it(ni), out_off(ni);
+    std::vector<u32> cap(ni), in_size_it(ni);
+    std::vector<i32> ord(ni);
     size_t in_tot = 0, out_tot = 0;
     for (int i = 0; i < n; i++) {
         in_off[i] = in_tot; in_tot += align_up((size_t)in_size[i] + 16, 256);
-        cap[i] = out_size[i];
-        out_off[i] = out_tot; out_tot += align_up((size_t)cap[i] + 16, 256);
-        ord[i] = order ? order[i] : 0;
+        for (int k = 0; k < K; k++) {
+            const size_t it = (size_t)i * K + k;
+            in_off_it[it] = in_off[i];
+            in_size_it[it] = in_size[i];
+            cap[it] = out_size[i];
+            out_off[it] = out_tot; out_tot += align_up((size_t)cap[it] + 16, 256);
+            ord[it] = methods ? methods[k] : (order ? order[i] : 0);
+        }
     }
-    const size_t arr = align_up((size_t)n * 8, 256);
+    const size_t arr = align_up(ni * 8, 256);
     if (ensure_stage(c, in_tot + out_tot + 6 * arr) != 0) return -1;
     u8 *d_in = c->stage, *d_out = d_in + in_tot, *meta = d_out + out_tot;
     u64 *d_in_off = (u64 *)meta, *d_out_off = (u64 *)(meta + arr);
     u32 *d_in_size = (u32 *)(meta + 2 * arr), *d_cap = (u32 *)(meta + 3 * arr), *d_osz = (u32 *)(meta + 4 * arr);
     i32 *d_status = (i32 *)(meta + 5 * arr);
     i32 *d_order = (i32 *)(meta + 5 * arr + arr / 2);
+    std::vector<int> win(n, -1);                              // winning candidate of each block (K > 1)
 
     // ---- slabs: a multiple of the lane count.  A chain kernel takes the same time for one block as for a few
     // thousand (it is bound by the length of a chain, not by their number), so a slab holds up to 4,096 blocks
@@ -623,7 +634,7 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
         size_t acc = 0, j = 0;
         slabs[0].lo = 0;
         for (int i = 0; i < n; i++) {
-            acc += align_up((size_t)in_size[i] + 16, 256) + align_up((size_t)cap[i] + 16, 256);
+            acc += align_up((size_t)in_size[i] + 16, 256) + (size_t)K * align_up((size_t)out_size[i] + 16, 256);
             const int left = n - (i + 1);
             if (j + 1 < nslab && (acc >= per * (j + 1) || left == (int)(nslab - j - 1))) {
                 slabs[j].hi = i + 1;
@@ -637,7 +648,7 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
         PipeSlab &S = slabs[j];
         for (int i = S.lo; i < S.hi; i++) {
             if (in_size[i] > S.max_in) S.max_in = in_size[i];
-            if (cap[i] > S.max_cap) S.max_cap = cap[i];
+            if (out_size[i] > S.max_cap) S.max_cap = out_size[i];
         }
         const size_t gi = PIPE_CHUNK / (align_up((size_t)S.max_in + 16, 256));
         const size_t go = PIPE_CHUNK / ((size_t)S.max_cap + 64);
@@ -646,16 +657,16 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
         S.nin = (S.hi - S.lo + S.gin - 1) / S.gin;
         S.nout = (S.hi - S.lo + S.gout - 1) / S.gout;
     }
-    if (pipe_prepare(c, threads, nlanes, 2 * nslab, (size_t)n) != 0) return -1;
+    if (pipe_prepare(c, threads, nlanes, 2 * nslab, ni) != 0) return -1;
     HostPipe *hp = c->pipe;
 
     hipStream_t s0 = c->stream;
     const hipStream_t s_in = c->stream, s_out = hp->s_out;
-    HIPCHK(c, hipMemcpyAsync(d_in_off, in_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, s0));
-    HIPCHK(c, hipMemcpyAsync(d_out_off, out_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, s0));
-    HIPCHK(c, hipMemcpyAsync(d_in_size, in_size, (size_t)n * 4, hipMemcpyHostToDevice, s0));
-    HIPCHK(c, hipMemcpyAsync(d_cap, cap.data(), (size_t)n * 4, hipMemcpyHostToDevice, s0));
-    HIPCHK(c, hipMemcpyAsync(d_order, ord.data(), (size_t)n * 4, hipMemcpyHostToDevice, s0));
+    HIPCHK(c, hipMemcpyAsync(d_in_off, in_off_it.data(), ni * 8, hipMemcpyHostToDevice, s0));
+    HIPCHK(c, hipMemcpyAsync(d_out_off, out_off.data(), ni * 8, hipMemcpyHostToDevice, s0));
+    HIPCHK(c, hipMemcpyAsync(d_in_size, in_size_it.data(), ni * 4, hipMemcpyHostToDevice, s0));
+    HIPCHK(c, hipMemcpyAsync(d_cap, cap.data(), ni * 4, hipMemcpyHostToDevice, s0));
+    HIPCHK(c, hipMemcpyAsync(d_order, ord.data(), ni * 4, hipMemcpyHostToDevice, s0));
     HIPCHK(c, hipStreamSynchronize(s0));
 
     std::atomic<int> broken{0};
@@ -699,7 +710,7 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
             PIPECHK(hipEventRecord(e, s_in));
             PIPECHK(hipStreamWaitEvent(l->stream, e, 0));
         }
-        const int lo = S.lo, m = S.hi - S.lo;
+        const int lo = S.lo * K, m = (S.hi - S.lo) * K;          // items
         int rc;
         if (decode)
             rc = rans4x16_hip_uncompress_dev(l, m, d_in, d_in_off + lo, d_in_size + lo, d_out, d_out_off + lo, d_cap + lo,
@@ -716,7 +727,7 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
         PIPECHK(hipMemcpyAsync(hp->h_st + lo, d_status + lo, (size_t)m * 4, hipMemcpyDeviceToHost, l->stream));
         PIPECHK(hipEventRecord(hp->events[2 * j + 1], l->stream));
         S.launched.store(1, std::memory_order_release);
-        if (trace) fprintf(stderr, "[pipe] slab %zu (%d blocks) launched on lane %zu at %.1f ms\n", j, m, li, now_ms());
+        if (trace) fprintf(stderr, "[pipe] slab %zu (%d blocks) launched on lane %zu at %.1f ms\n", j, S.hi - S.lo, li, now_ms());
         return true;
     };
 
@@ -749,7 +760,7 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
     auto copy_out_unit = [&](PipeCopier &pc, int b0, int b1) -> bool {
         // results that nearly fill their slots (decode: the capacity is the size) travel as one DMA over the
         // whole extent, like copy-in; sparse ones (encode: bound-sized slots) block by block
-        {
+        if (K == 1) {
             size_t sum = 0;
             u64 end = out_off[b0];
             for (int i = b0; i < b1; i++)
@@ -765,8 +776,19 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
             }
         }
         for (int i = b0; i < b1; i++) {
-            if (hp->h_st[i] != 0) continue;
-            const size_t sz = hp->h_osz[i];
+            size_t it = (size_t)i;
+            if (K > 1) {
+                int w = -1;
+                for (int k = 0; k < K; k++) {
+                    const size_t cand = (size_t)i * K + k;
+                    if (hp->h_st[cand] == 0 && (w < 0 || hp->h_osz[cand] < hp->h_osz[(size_t)i * K + w])) w = k;
+                }
+                win[i] = w;
+                if (w < 0) continue;
+                it = (size_t)i * K + w;
+            }
+            if (hp->h_st[it] != 0) continue;
+            const size_t sz = hp->h_osz[it];
             for (size_t p = 0; p < sz;) {
                 PipeSlot *sl = &pc.slot[pc.k];
                 size_t at = (sl->fill + 63) & ~(size_t)63;
@@ -776,7 +798,7 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
                     at = 0;
                 }
                 const size_t len = sz - p < PIPE_CHUNK - at ? sz - p : PIPE_CHUNK - at;
-                PIPECHK(hipMemcpyAsync(sl->pin + at, d_out + out_off[i] + p, len, hipMemcpyDeviceToHost, s_out));
+                PIPECHK(hipMemcpyAsync(sl->pin + at, d_out + out_off[it] + p, len, hipMemcpyDeviceToHost, s_out));
                 sl->outs.push_back({out[i] + p, at, len});
                 sl->fill = at + len;
                 p += len;
@@ -855,9 +877,14 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
     }
     int failed = 0;
     for (int i = 0; i < n; i++) {
-        if (status) status[i] = hp->h_st[i];
-        if (hp->h_st[i] != 0) { out_size[i] = 0; failed++; }
-        else out_size[i] = hp->h_osz[i];
+        size_t it = (size_t)i;
+        if (K > 1) {
+            if (win_k) win_k[i] = win[i];
+            it = (size_t)i * K + (win[i] < 0 ? 0 : win[i]);
+        }
+        if (status) status[i] = hp->h_st[it];
+        if (hp->h_st[it] != 0) { out_size[i] = 0; failed++; }
+        else out_size[i] = hp->h_osz[it];
     }
     return failed;
 }
@@ -1040,6 +1067,77 @@ extern "C" int rans4x16_hip_compress_batch(rans4x16_hip_ctx *c, int n,
                                            const int *order, int *status)
 {
     return run_host_batch(c, n, false, in, in_size, out, out_size, order, status);
+}
+
+// "Try K methods, keep the smallest" (tokenise_name3.c:1246-1300 compress()): every block is
+// encoded with each of methods[0..k), the smallest result is delivered, the first method wins ties
+// (:1283-1286), and X_STRIPE methods are skipped for blocks whose size is not a multiple of four (:1271-1272).
+// The plain candidates of a block share one copy of its input on the device and only the winner crosses PCIe
+// back; X_STRIPE candidates go block by block through the host-orchestrated stripe path.
+extern "C" int rans4x16_hip_compress_best_batch(rans4x16_hip_ctx *c, int n,
+                                                const unsigned char *const *in, const unsigned int *in_size,
+                                                unsigned char *const *out, unsigned int *out_size,
+                                                int k, const int *methods, int *chosen, int *status)
+{
+    if (!c) return -1;
+    if (n < 0 || k <= 0 || !methods || (n && (!in || !in_size || !out || !out_size))) {
+        c->err = "compress_best_batch: bad arguments";
+        return -1;
+    }
+    if (n == 0) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<int> plain_m, plain_idx, stripe_idx;
+    for (int j = 0; j < k; j++) {
+        if (methods[j] & X_STRIPE) stripe_idx.push_back(j);
+        else { plain_m.push_back(methods[j]); plain_idx.push_back(j); }
+    }
+    std::vector<int> best(n, -1), st(n, R4X16_E_UNSUPPORTED);
+    std::vector<unsigned int> capv(out_size, out_size + n);
+    if (!plain_m.empty()) {
+        long threads = env_long("R4X16_HOST_THREADS", 8), nlanes = env_long("R4X16_HOST_LANES", 2);
+        threads = threads < 1 ? 1 : threads > 32 ? 32 : threads;
+        nlanes = nlanes < 1 ? 1 : nlanes > 16 ? 16 : nlanes;
+        size_t tot = 0;
+        for (int i = 0; i < n; i++) tot += in_size[i];
+        const long by_size = (long)(tot >> 22) + 1;                  // a copier thread per 4 MiB of input is plenty
+        if (threads > by_size) threads = by_size;
+        std::vector<int> wk(n, 0);
+        const int K = (int)plain_m.size();
+        if (run_pipelined(c, n, false, in, in_size, out, out_size, nullptr, st.data(), (int)threads, (int)nlanes,
+                          K, plain_m.data(), wk.data()) < 0)
+            return -1;
+        for (int i = 0; i < n; i++)
+            if (st[i] == 0) best[i] = plain_idx[K > 1 ? wk[i] : 0];
+    }
+    if (!stripe_idx.empty()) {
+        std::vector<unsigned char> tmp;
+        for (int i = 0; i < n; i++) {
+            if (in_size[i] % 4 != 0) continue;                       // :1271-1272
+            for (int j : stripe_idx) {
+                tmp.resize((size_t)capv[i] + 1);
+                unsigned int tsz = capv[i];
+                const unsigned char *bi = in[i];
+                unsigned char *bo = tmp.data();
+                int o = methods[j], bs = 0;
+                const int f = run_host_batch(c, 1, false, &bi, &in_size[i], &bo, &tsz, &o, &bs);
+                if (f < 0) return -1;
+                if (f != 0 || bs != 0) continue;
+                if (best[i] < 0 || tsz < out_size[i] || (tsz == out_size[i] && j < best[i])) {
+                    memcpy(out[i], tmp.data(), tsz);
+                    out_size[i] = tsz;
+                    best[i] = j;
+                    st[i] = 0;
+                }
+            }
+        }
+    }
+    int failed = 0;
+    for (int i = 0; i < n; i++) {
+        if (best[i] < 0) { out_size[i] = 0; failed++; if (st[i] == 0) st[i] = R4X16_E_UNSUPPORTED; }
+        if (chosen) chosen[i] = best[i] < 0 ? -1 : methods[best[i]];
+        if (status) status[i] = st[i];
+    }
+    return failed;
 }
 
 extern "C" int rans4x16_hip_uncompress_batch(rans4x16_hip_ctx *c, int n,

@@ -24,6 +24,8 @@ SIGNATURES = {
                                              C.c_void_p, C.c_void_p, C.c_void_p]),
     "rans4x16_hip_uncompress_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_void_p]),
+    "rans4x16_hip_compress_best_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rans4x16_hip_compress_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]),

@@ -86,6 +86,20 @@ int rans4x16_hip_uncompress_batch(rans4x16_hip_ctx *ctx, int n,
                                   unsigned char *const *out, unsigned int *out_size,
                                   int *status);
 
+/* "Try k methods, keep the smallest": the caller-side pattern of htscodecs/tokenise_name3.c:1246-1300
+ * (compress(): up to nine `order` values per token column, smallest kept) and of CRAM block writers, as one
+ * call.  Block i is encoded with every methods[j]; out[i] receives the smallest result, chosen[i] the
+ * method that produced it (the first wins ties, tokenise_name3.c:1283-1286; -1 if every candidate
+ * failed).  Methods with X_STRIPE (0x08) are skipped for blocks whose size is not a multiple of 4
+ * (:1271-1272).  out_size[i] is the capacity on entry (at least the largest
+ * rans_compress_bound_4x16(in_size[i], methods[j])) and the winner's size on return.
+ * The candidates share one upload of the block; only the winner is copied back.
+ * Returns the number of blocks without any successful candidate, or -1. */
+int rans4x16_hip_compress_best_batch(rans4x16_hip_ctx *ctx, int n,
+                                     const unsigned char *const *in, const unsigned int *in_size,
+                                     unsigned char *const *out, unsigned int *out_size,
+                                     int k, const int *methods, int *chosen, int *status);
+
 /* Device-resident batches.  Every pointer below is a DEVICE pointer.
  *   d_in  + d_in_off[i]   : block i input,  d_in_size[i] bytes
  *   d_out + d_out_off[i]  : block i output slot, d_out_cap[i] bytes available

@@ -393,3 +393,25 @@ def test_host_batch_pipeline_matches_single_pass(H, oracle, monkeypatch):
     for i, (d, x) in enumerate(zip(datas, dec)):
         if i not in damaged:
             assert x == d, i
+
+
+def test_compress_best_keeps_what_the_reference_loop_keeps(H, oracle):
+    """tokenise_name3.c:1246-1300 compress(): methods tried in order, a later one must be strictly smaller
+    to replace the best so far, X_STRIPE methods skipped when the size is not a multiple of 4.  The one-call
+    form must deliver the same bytes and the same method, for the reference's own method tables."""
+    rs = np.random.RandomState(77)
+    datas = _random_inputs(rs, 90, max_n=40000) + [b"", b"abc", b"A" * 24, datagen.tile("q4", 200000, 2).tobytes()]
+    for methods in ([0, 128], [0, 192 + 8], [0, 1, 129, 65, 193, 193 + 8], [0, 1, 128, 129, 64, 65, 192, 193, 193 + 8], [1]):
+        got, chosen, st = H.compress_best_batch(datas, methods)
+        for i, d in enumerate(datas):
+            best, best_m = None, None
+            for m in methods:
+                if len(d) % 4 != 0 and (m & 8):
+                    continue
+                c = oracle.compress(d, m)
+                if best is None or len(c) < len(best):
+                    best, best_m = c, m
+            assert st[i] == 0, (i, len(d), methods)
+            assert chosen[i] == best_m, (i, len(d), methods, chosen[i], best_m)
+            assert got[i] == best, (i, len(d), methods)
+            assert H.rans_uncompress_4x16(got[i], len(d)) == d
