@@ -276,8 +276,8 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             // more than the extra read (measured: +12 % on the whole kernel per misaligned read and step).
             // (volatile: keeps the compiler from sinking these reads into a branch, which would put their
             //  latency back on the dependent path; explicit LDS pointer: a volatile generic access goes FLAT)
-            lvcu32 *rp = (lvcu32 *)(ring + ra);
-            const u32 d0 = rp[0], d1 = rp[1], d2 = rp[2];
+            const u32x2 d01 = *(LAS const volatile u32x2_a4 *)(ring + ra);     // one ds_read2_b32
+            const u32 d0 = d01.x, d1 = d01.y, d2 = *(lvcu32 *)(ring + ra + 8);
             const u32 sh = (cb & 3u) * 8u;
 
             u32 xn = x;
@@ -328,8 +328,9 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             const u32 pre = __popc(wm & below);
             const bool take = FAST ? want : (want && cursor + pre < nwords);
             const u32 wlo = __builtin_amdgcn_alignbit(d1, d0, sh), whi = __builtin_amdgcn_alignbit(d2, d1, sh);
-            const u32 w2 = (pre & 2u) ? whi : wlo;
-            const u32 w = __builtin_amdgcn_ubfe(w2, pre << 4, 16);       // offset is taken mod 32: 16 * (pre & 1)
+            // word `pre` of the four candidates: one byte permute over the 8 bytes {whi:wlo} with a per-lane
+            // selector (bytes 2 pre and 2 pre + 1, then two zero bytes)
+            const u32 w = __builtin_amdgcn_perm(whi, wlo, __umul24(pre, 0x0202u) + 0x0c0c0100u);
             u32 xr = (x << 16) | w;
             asm volatile("" : "+v"(xr));                  // keeps the refill arithmetic out of a branch
             x = take ? xr : x;
