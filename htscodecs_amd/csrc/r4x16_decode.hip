@@ -256,7 +256,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     u32x2 root = img0.ld64(row);
     u32 acc = 0;                                          // order-1: the last (up to) 4 decoded bytes
     u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;                   // order-1: completed dwords not yet stored (a3 newest)
-    u32 hdr = 0;                                          // order-1: alpha[] word of the symbol decoded last step
+    u32 hdr = 0, hdr_even = 0;                            // order-1: alpha[] word of the symbol decoded last step
     if (ORDER == 1 && count) bad = img.ld16(0);
 
     // Four steps per trip: one loop test, one store and one ring check per trip.  A trip in which
@@ -278,7 +278,6 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             //  latency back on the dependent path; explicit LDS pointer: a volatile generic access goes FLAT)
             const u32x2 d01 = *(LAS const volatile u32x2_a4 *)(ring + ra);     // one ds_read2_b32
             const u32 d0 = d01.x, d1 = d01.y, d2 = *(lvcu32 *)(ring + ra + 8);
-            const u32 sh = (cb & 3u) * 8u;
 
             u32 xn = x;
             RootSpec spec;
@@ -292,7 +291,10 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             } else {
                 // the byte of the symbol decoded one step ago and the flags of the row in use now
                 if (u > 0 || t > 0) {
-                    bad |= live ? hdr : 0u;               // ROW_EMPTY bit is tested after the loop
+                    // ROW_EMPTY bit is tested after the loop; the fast body folds two steps into one three-way or
+                    if (!FAST) bad |= live ? hdr : 0u;
+                    else if (u & 1) bad |= hdr | hdr_even;
+                    else hdr_even = hdr;
                     acc = (FAST || T <= count) ? __builtin_amdgcn_alignbit(hdr, acc, 8) : acc;
                 }
                 // symbols t-4 .. t-1 are now in acc, oldest in the low byte: queue the dword, and every
@@ -327,7 +329,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             const u32 wm = quad_ballot(want, lane);
             const u32 pre = __popc(wm & below);
             const bool take = FAST ? want : (want && cursor + pre < nwords);
-            const u32 wlo = __builtin_amdgcn_alignbit(d1, d0, sh), whi = __builtin_amdgcn_alignbit(d2, d1, sh);
+            const u32 wlo = __builtin_amdgcn_alignbyte(d1, d0, cb), whi = __builtin_amdgcn_alignbyte(d2, d1, cb);   // byte shift = cb & 3
             // word `pre` of the four candidates: one byte permute over the 8 bytes {whi:wlo} with a per-lane
             // selector (bytes 2 pre and 2 pre + 1, then two zero bytes)
             const u32 w = __builtin_amdgcn_perm(whi, wlo, __umul24(pre, 0x0202u) + 0x0c0c0100u);
