@@ -657,7 +657,7 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
         S.nin = (S.hi - S.lo + S.gin - 1) / S.gin;
         S.nout = (S.hi - S.lo + S.gout - 1) / S.gout;
     }
-    if (pipe_prepare(c, threads, nlanes, 2 * nslab, ni) != 0) return -1;
+    if (pipe_prepare(c, threads, nlanes, 2 * nslab, ni) != 0) return -2;      // nothing started: the caller may take the single-pass route
     HostPipe *hp = c->pipe;
 
     hipStream_t s0 = c->stream;
@@ -901,7 +901,9 @@ static int run_plain_batch(rans4x16_hip_ctx *c, int n, bool decode,
     for (int i = 0; i < n; i++) tot += (size_t)in_size[i] + out_size[i];
     if (pipe_mb <= 0 || tot < ((size_t)pipe_mb << 20))
         return run_slab(c, n, decode, in, in_size, out, out_size, order, status);
-    return run_pipelined(c, n, decode, in, in_size, out, out_size, order, status, (int)threads, (int)nlanes);
+    const int rc = run_pipelined(c, n, decode, in, in_size, out, out_size, order, status, (int)threads, (int)nlanes);
+    // -2: the pipeline's resources (pinned buffers, lane contexts) could not be set up, e.g. a locked-memory limit
+    return rc == -2 ? run_slab(c, n, decode, in, in_size, out, out_size, order, status) : rc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1105,7 +1107,7 @@ extern "C" int rans4x16_hip_compress_best_batch(rans4x16_hip_ctx *c, int n,
         const int K = (int)plain_m.size();
         if (run_pipelined(c, n, false, in, in_size, out, out_size, nullptr, st.data(), (int)threads, (int)nlanes,
                           K, plain_m.data(), wk.data()) < 0)
-            return -1;
+            return -1;                                               // (-2 included: this mode has no single-pass route)
         for (int i = 0; i < n; i++)
             if (st[i] == 0) best[i] = plain_idx[K > 1 ? wk[i] : 0];
     }

@@ -636,6 +636,9 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
                     if (n > 16) { per = 1; used = 1; }
                     else if (left <= 1) st = ST_TRUNCATED;
                     else {
+                        // the reference's map is `uint8_t map[16] = {0}` (rANS_static4x16pr.c:1524): codes past the
+                        // listed symbols - only a damaged stream holds any - decode to byte 0
+                        for (u32 q = 0; q < 16; q++) D->pack_map[q] = 0;
                         u32 j = 1, c = 0;
                         do { D->pack_map[c++] = src.at(pos + j); j++; } while (c < n && j < left);
                         if (c < n) st = ST_TRUNCATED; else used = j;

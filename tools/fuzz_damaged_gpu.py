@@ -82,7 +82,8 @@ def main():
             if x == r: agree += 1
             else:
                 wrong += 1
-                if wrong < 10: print("DIFFERENT BYTES: flags %#x len %d" % (b[0], len(b)))
+                if wrong < 10:
+                    print("DIFFERENT BYTES: flags %#x len %d\n  in  %s\n  dev %s\n  ref %s" % (b[0], len(b), b[:80].hex(), x[:60].hex(), r[:60].hex()), "lens", len(x), len(r))
         else:
             by_status[int(s)] = by_status.get(int(s), 0) + 1
             if s in (6, 7, 8): stricter += 1
