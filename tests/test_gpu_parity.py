@@ -415,3 +415,16 @@ def test_compress_best_keeps_what_the_reference_loop_keeps(H, oracle):
             assert chosen[i] == best_m, (i, len(d), methods, chosen[i], best_m)
             assert got[i] == best, (i, len(d), methods)
             assert H.rans_uncompress_4x16(got[i], len(d)) == d
+
+
+def test_pack_codes_outside_the_listed_symbols_decode_to_zero(H, oracle):
+    """rANS_static4x16pr.c:1524: `uint8_t map[16] = {0}` - a damaged X_PACK stream whose nibbles exceed the
+    symbol count decodes those positions to byte 0 (found by tools/fuzz_damaged_gpu.py, seed 909)."""
+    bad = bytes.fromhex("a0150800010203040506070b7150338022737671141307")
+    want = oracle.uncompress(bad, capacity=64, out_size_hint=64)
+    assert want == bytes.fromhex("010700050303000002020307060701070401030107")
+    # run a valid PACK block with a different, larger map through the same context first: stale entries must not leak
+    first = oracle.compress(bytes(range(65, 81)) * 40, 128)
+    dec, st = H.uncompress_batch([first, bad, bad], [640, 64, 64])
+    assert st == [0, 0, 0] and dec[0] == bytes(range(65, 81)) * 40
+    assert dec[1] == want and dec[2] == want
