@@ -15,6 +15,7 @@
 #include <atomic>
 #include <thread>
 #include <chrono>
+#include <algorithm>
 
 #include "../../include/rans4x16_hip.h"
 #include "r4x16_dev.h"
@@ -482,6 +483,7 @@ static long env_long(const char *name, long dflt)
 
 #define PIPE_CHUNK ((size_t)8 << 20)          // bytes per pinned bounce buffer
 
+struct PackDesc { u64 src, dst; u32 len, pad; };      // one result to gather: slot offset, packed offset, bytes
 struct PipeSlot {
     u8 *pin = nullptr;
     hipEvent_t ev = nullptr;
@@ -503,6 +505,8 @@ struct HostPipe {
     u32 *h_osz = nullptr;                     // pinned: per-block output sizes and statuses
     i32 *h_st = nullptr;
     size_t h_n = 0;
+    PackDesc *h_pk = nullptr;                 // pinned: one descriptor per block
+    size_t h_pk_n = 0;
 };
 
 static void pipe_destroy(HostPipe *hp)
@@ -517,10 +521,11 @@ static void pipe_destroy(HostPipe *hp)
     for (auto e : hp->events) (void)hipEventDestroy(e);
     if (hp->h_osz) (void)hipHostFree(hp->h_osz);
     if (hp->h_st) (void)hipHostFree(hp->h_st);
+    if (hp->h_pk) (void)hipHostFree(hp->h_pk);
     delete hp;
 }
 
-static int pipe_prepare(rans4x16_hip_ctx *c, int threads, int nlanes, size_t nevents, size_t n)
+static int pipe_prepare(rans4x16_hip_ctx *c, int threads, int nlanes, size_t nevents, size_t n, size_t nblocks)
 {
     if (!c->pipe) c->pipe = new HostPipe();
     HostPipe *hp = c->pipe;
@@ -567,6 +572,13 @@ static int pipe_prepare(rans4x16_hip_ctx *c, int threads, int nlanes, size_t nev
         HIPCHK(c, hipHostMalloc((void **)&hp->h_st, want * 4, hipHostMallocDefault));
         hp->h_n = want;
     }
+    if (hp->h_pk_n < nblocks) {
+        if (hp->h_pk) { (void)hipHostFree(hp->h_pk); hp->h_pk = nullptr; }
+        hp->h_pk_n = 0;
+        const size_t want = nblocks + nblocks / 2 + 1024;
+        HIPCHK(c, hipHostMalloc((void **)&hp->h_pk, want * sizeof(PackDesc), hipHostMallocDefault));
+        hp->h_pk_n = want;
+    }
     return 0;
 }
 
@@ -577,7 +589,25 @@ struct PipeSlab {
     u32 max_in = 0, max_cap = 0;
     std::atomic<int> in_next{0}, in_queued{0}, out_next{0};
     std::atomic<int> launched{0}, finished{0};
+    // copy-out plan, made once by the first thread that sees the slab's kernels finished:
+    // 0 none yet, 1 being made, 4 pack kernel in flight, 2 ready (results packed), 3 ready (copied from their slots)
+    std::atomic<int> plan{0};
+    u64 pk_total = 0;                         // bytes of the packed results
+    std::vector<u64> poff;                    // start of each block's result in the packed region
 };
+
+// Sparse results (encode: every block owns a bound-sized slot and fills a fraction of it) are gathered by the device
+// into the slab's input region, which is dead once the slab's kernels have run, and cross PCIe as a few dense DMAs
+// instead of one small DMA per block (15,000 small blocks: 140 ms of DMA calls before).
+__global__ __launch_bounds__(256) void k_pack_results(const u8 *out, u8 *in, const PackDesc *d)
+{
+    const PackDesc p = d[blockIdx.x];
+    const u8 *s = out + p.src;                // slots are 256-byte aligned, packed results 64-byte aligned
+    u8 *t = in + p.dst;
+    const u32 n16 = p.len >> 4;
+    for (u32 i = threadIdx.x; i < n16; i += 256) ((u32x4 *)t)[i] = ((const u32x4 *)s)[i];
+    for (u32 i = (n16 << 4) + threadIdx.x; i < p.len; i += 256) t[i] = s[i];
+}
 
 // K > 1 (encode only) is the "try K methods, keep the smallest" mode of SURVEY §8f-3: the K candidates of a
 // block share its one copy of the input, only the winner is copied out (first candidate wins ties,
@@ -606,21 +636,22 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
         }
     }
     const size_t arr = align_up(ni * 8, 256);
-    if (ensure_stage(c, in_tot + out_tot + 6 * arr) != 0) return -1;
+    const size_t pk_bytes = align_up((size_t)n * sizeof(PackDesc), 256);
+    if (ensure_stage(c, in_tot + out_tot + 6 * arr + pk_bytes) != 0) return -1;
     u8 *d_in = c->stage, *d_out = d_in + in_tot, *meta = d_out + out_tot;
     u64 *d_in_off = (u64 *)meta, *d_out_off = (u64 *)(meta + arr);
     u32 *d_in_size = (u32 *)(meta + 2 * arr), *d_cap = (u32 *)(meta + 3 * arr), *d_osz = (u32 *)(meta + 4 * arr);
     i32 *d_status = (i32 *)(meta + 5 * arr);
     i32 *d_order = (i32 *)(meta + 5 * arr + arr / 2);
+    PackDesc *d_pk = (PackDesc *)(meta + 6 * arr);
     std::vector<int> win(n, -1);                              // winning candidate of each block (K > 1)
 
-    // ---- slabs: a multiple of the lane count.  A chain kernel takes the same time for one block as for a few
-    // thousand (it is bound by the length of a chain, not by their number), so a slab holds up to 4,096 blocks
-    // per lane round - or 8 GiB of input + capacity, which bounds the lane workspaces.
+    // ---- slabs: a multiple of the lane count, as few as the lane workspaces allow (8 GiB of input + capacity per
+    // slab).  Every kernel of a slab has a latency floor that does not shrink with the slab - a chain kernel needs
+    // the same time for one block as for a few thousand, the table kernels one wave-lifetime per block - so many
+    // small slabs cost many floors (60,000 blocks of <= 64 KiB in slabs of 1,900: 717 ms; in four slabs: see §6).
     const size_t tot = in_tot + out_tot;
-    size_t rounds = ((size_t)n + (size_t)nlanes * 4096 - 1) / ((size_t)nlanes * 4096);
-    const size_t rounds_b = (tot + (size_t)nlanes * ((size_t)8 << 30) - 1) / ((size_t)nlanes * ((size_t)8 << 30));
-    if (rounds_b > rounds) rounds = rounds_b;
+    const size_t rounds = (tot + (size_t)nlanes * ((size_t)8 << 30) - 1) / ((size_t)nlanes * ((size_t)8 << 30));
     // (encode slabs are half that: its chain kernel is the shorter one, ~28 ms per MiB of block size against the
     //  decoder's ~52, and sparse bound-sized output slots make its copy-out the slower DMA - a smaller last
     //  slab shortens the tail of the pipeline)
@@ -657,7 +688,7 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
         S.nin = (S.hi - S.lo + S.gin - 1) / S.gin;
         S.nout = (S.hi - S.lo + S.gout - 1) / S.gout;
     }
-    if (pipe_prepare(c, threads, nlanes, 2 * nslab, ni) != 0) return -2;      // nothing started: the caller may take the single-pass route
+    if (pipe_prepare(c, threads, nlanes, 3 * nslab, ni, (size_t)n) != 0) return -2;      // nothing started: the caller may take the single-pass route
     HostPipe *hp = c->pipe;
 
     hipStream_t s0 = c->stream;
@@ -706,7 +737,7 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
         rans4x16_hip_ctx *l = hp->lanes[li];
         std::lock_guard<std::mutex> g(hp->lane_mu[li]);
         {
-            hipEvent_t e = hp->events[2 * j];              // every copy-in of this slab is queued on s_in
+            hipEvent_t e = hp->events[3 * j];              // every copy-in of this slab is queued on s_in
             PIPECHK(hipEventRecord(e, s_in));
             PIPECHK(hipStreamWaitEvent(l->stream, e, 0));
         }
@@ -725,7 +756,7 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
         }
         PIPECHK(hipMemcpyAsync(hp->h_osz + lo, d_osz + lo, (size_t)m * 4, hipMemcpyDeviceToHost, l->stream));
         PIPECHK(hipMemcpyAsync(hp->h_st + lo, d_status + lo, (size_t)m * 4, hipMemcpyDeviceToHost, l->stream));
-        PIPECHK(hipEventRecord(hp->events[2 * j + 1], l->stream));
+        PIPECHK(hipEventRecord(hp->events[3 * j + 1], l->stream));
         S.launched.store(1, std::memory_order_release);
         if (trace) fprintf(stderr, "[pipe] slab %zu (%d blocks) launched on lane %zu at %.1f ms\n", j, S.hi - S.lo, li, now_ms());
         return true;
@@ -778,14 +809,8 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
         for (int i = b0; i < b1; i++) {
             size_t it = (size_t)i;
             if (K > 1) {
-                int w = -1;
-                for (int k = 0; k < K; k++) {
-                    const size_t cand = (size_t)i * K + k;
-                    if (hp->h_st[cand] == 0 && (w < 0 || hp->h_osz[cand] < hp->h_osz[(size_t)i * K + w])) w = k;
-                }
-                win[i] = w;
-                if (w < 0) continue;
-                it = (size_t)i * K + w;
+                if (win[i] < 0) continue;                           // chosen by plan_slab
+                it = (size_t)i * K + win[i];
             }
             if (hp->h_st[it] != 0) continue;
             const size_t sz = hp->h_osz[it];
@@ -807,6 +832,72 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
         return flip(pc, s_out);
     };
 
+    // The copy-out plan of a slab whose kernels have finished (one thread makes it; sizes and statuses are in pinned
+    // memory by now): pick the winners, then either pack the results on the device or leave them in their slots.
+    auto plan_slab = [&](size_t j) -> bool {
+        PipeSlab &S = slabs[j];
+        const int m = S.hi - S.lo;
+        S.poff.resize((size_t)m + 1);
+        u64 T = 0, sum = 0;
+        for (int i = S.lo; i < S.hi; i++) {
+            size_t it = (size_t)i;
+            if (K > 1) {
+                int w = -1;
+                for (int k = 0; k < K; k++) {
+                    const size_t cand = (size_t)i * K + k;
+                    if (hp->h_st[cand] == 0 && (w < 0 || hp->h_osz[cand] < hp->h_osz[(size_t)i * K + w])) w = k;
+                }
+                win[i] = w;
+                it = (size_t)i * K + (w < 0 ? 0 : w);
+            }
+            const u32 sz = hp->h_st[it] == 0 ? hp->h_osz[it] : 0u;
+            hp->h_pk[i].src = out_off[it];
+            hp->h_pk[i].dst = in_off[S.lo] + T;
+            hp->h_pk[i].len = sz;
+            hp->h_pk[i].pad = 0;
+            S.poff[(size_t)(i - S.lo)] = T;
+            T += ((u64)sz + 63u) & ~(u64)63u;
+            sum += sz;
+        }
+        S.poff[(size_t)m] = T;
+        S.pk_total = T;
+        const u64 in_region = in_off[S.hi - 1] + align_up((size_t)in_size[S.hi - 1] + 16, 256) - in_off[S.lo];
+        const u64 out_extent = out_off[(size_t)(S.hi - 1) * K + (K - 1)] + cap[(size_t)(S.hi - 1) * K + (K - 1)] - out_off[(size_t)S.lo * K];
+        const bool dense = K == 1 && sum * 4 >= out_extent * 3;       // decode: capacity = size, slots are adjacent
+        if (dense || T > in_region || env_long("R4X16_HOST_PACK", 1) == 0) {
+            S.plan.store(3, std::memory_order_release);
+            return true;
+        }
+        S.nout = (int)((T + PIPE_CHUNK - 1) / PIPE_CHUNK);
+        if (T == 0) { S.plan.store(2, std::memory_order_release); return true; }
+        const size_t li = j % (size_t)nlanes;
+        rans4x16_hip_ctx *l = hp->lanes[li];
+        std::lock_guard<std::mutex> g(hp->lane_mu[li]);
+        PIPECHK(hipMemcpyAsync(d_pk + S.lo, hp->h_pk + S.lo, (size_t)m * sizeof(PackDesc), hipMemcpyHostToDevice, l->stream));
+        hipLaunchKernelGGL(k_pack_results, dim3((unsigned)m), dim3(256), 0, l->stream, (const u8 *)d_out, d_in, (const PackDesc *)(d_pk + S.lo));
+        PIPECHK(hipGetLastError());
+        PIPECHK(hipEventRecord(hp->events[3 * j + 2], l->stream));
+        S.plan.store(4, std::memory_order_release);
+        return true;
+    };
+    // one copy-out unit of a packed slab: PIPE_CHUNK bytes of the packed region, handed out to the blocks they belong to
+    auto copy_out_packed = [&](PipeCopier &pc, PipeSlab &S, int u) -> bool {
+        const u64 a = (u64)u * PIPE_CHUNK, b = a + PIPE_CHUNK < S.pk_total ? a + PIPE_CHUNK : S.pk_total;
+        PipeSlot &sl = pc.slot[pc.k];                              // free: the previous unit ended with flip()
+        PIPECHK(hipMemcpyAsync(sl.pin, d_in + in_off[S.lo] + a, (size_t)(b - a), hipMemcpyDeviceToHost, s_out));
+        // first block whose result ends after a
+        size_t i = (size_t)(std::upper_bound(S.poff.begin(), S.poff.end(), a) - S.poff.begin());
+        i = i ? i - 1 : 0;
+        const size_t m = (size_t)(S.hi - S.lo);
+        for (; i < m && S.poff[i] < b; i++) {
+            const u64 r0 = S.poff[i], r1 = r0 + hp->h_pk[(size_t)S.lo + i].len;
+            const u64 x0 = r0 > a ? r0 : a, x1 = r1 < b ? r1 : b;
+            if (x1 > x0) sl.outs.push_back({out[(size_t)S.lo + i] + (x0 - r0), (size_t)(x0 - a), (size_t)(x1 - x0)});
+        }
+        sl.fill = (size_t)(b - a);
+        return flip(pc, s_out);
+    };
+
     auto worker = [&](int t) {
         if (hipSetDevice(c->device) != hipSuccess) { fail("hipSetDevice", hipErrorInvalidDevice); return; }
         PipeCopier &pc = hp->cp[t];
@@ -817,21 +908,43 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
         // odd ones for copy-out, and each takes the other kind when its own has nothing ready.
         const bool in_first = (t & 1) == 0;
         auto take_out = [&](bool &err) -> bool {
-            while (out_low < nslab && slabs[out_low].out_next.load(std::memory_order_relaxed) >= slabs[out_low].nout) out_low++;
+            auto drained = [&](PipeSlab &S) { return S.plan.load(std::memory_order_acquire) >= 2 && S.plan.load() != 4 && S.out_next.load(std::memory_order_relaxed) >= S.nout; };
+            while (out_low < nslab && drained(slabs[out_low])) out_low++;
             for (size_t j = out_low; j < nslab; j++) {
                 PipeSlab &S = slabs[j];
-                if (S.out_next.load(std::memory_order_relaxed) >= S.nout) continue;
-                if (!S.launched.load(std::memory_order_acquire)) continue;
-                if (!S.finished.load(std::memory_order_acquire)) {
-                    const hipError_t q = hipEventQuery(hp->events[2 * j + 1]);
+                int pl = S.plan.load(std::memory_order_acquire);
+                if (pl == 0) {
+                    if (!S.launched.load(std::memory_order_acquire)) continue;
+                    if (!S.finished.load(std::memory_order_acquire)) {
+                        const hipError_t q = hipEventQuery(hp->events[3 * j + 1]);
+                        if (q == hipErrorNotReady) continue;
+                        if (q != hipSuccess) { fail("hipEventQuery", q); err = true; return false; }
+                        if (!S.finished.exchange(1) && trace) fprintf(stderr, "[pipe] slab %zu kernels seen finished at %.1f ms\n", j, now_ms());
+                    }
+                    int expect = 0;
+                    if (!S.plan.compare_exchange_strong(expect, 1)) continue;
+                    if (!plan_slab(j)) { err = true; return false; }
+                    pl = S.plan.load(std::memory_order_acquire);
+                }
+                if (pl == 1) continue;
+                if (pl == 4) {
+                    const hipError_t q = hipEventQuery(hp->events[3 * j + 2]);
                     if (q == hipErrorNotReady) continue;
                     if (q != hipSuccess) { fail("hipEventQuery", q); err = true; return false; }
-                    if (!S.finished.exchange(1) && trace) fprintf(stderr, "[pipe] slab %zu kernels seen finished at %.1f ms\n", j, now_ms());
+                    int expect = 4;
+                    if (S.plan.compare_exchange_strong(expect, 2) && trace)
+                        fprintf(stderr, "[pipe] slab %zu results packed (%.1f MB) at %.1f ms\n", j, S.pk_total / 1e6, now_ms());
+                    pl = 2;
                 }
+                if (S.out_next.load(std::memory_order_relaxed) >= S.nout) continue;
                 const int u = S.out_next.fetch_add(1);
                 if (u >= S.nout) continue;
-                const int b0 = S.lo + u * S.gout, b1 = b0 + S.gout < S.hi ? b0 + S.gout : S.hi;
-                if (!copy_out_unit(pc, b0, b1)) { err = true; return false; }
+                if (pl == 2) {
+                    if (!copy_out_packed(pc, S, u)) { err = true; return false; }
+                } else {
+                    const int b0 = S.lo + u * S.gout, b1 = b0 + S.gout < S.hi ? b0 + S.gout : S.hi;
+                    if (!copy_out_unit(pc, b0, b1)) { err = true; return false; }
+                }
                 return true;
             }
             return false;
