@@ -3,6 +3,8 @@ C ABI, plus the batch calls.  Same names and argument meaning as the C functions
 back as ``None`` exactly where the C functions return NULL."""
 import ctypes as C
 
+import threading
+
 import numpy as np
 
 from . import lib as _lib
@@ -61,8 +63,20 @@ class _Ctx:
         return self.L.rans4x16_hip_last_error(self.h).decode()
 
 
+_tls = threading.local()
+
+
+def _thread_ctx():
+    """One context per host thread, kept between calls: it owns the device arenas, the pinned bounce buffers
+    and the lane contexts of the host-batch pipeline, which are far too expensive to rebuild per call."""
+    ctx = getattr(_tls, "ctx", None)
+    if ctx is None:
+        ctx = _tls.ctx = _Ctx()
+    return ctx
+
+
 def _host_batch(blocks, decode, orders=None, caps=None):
-    ctx = _Ctx()
+    ctx = _thread_ctx()
     L = ctx.L
     n = len(blocks)
     srcs = [np.frombuffer(bytes(b), dtype=np.uint8) for b in blocks]
@@ -96,7 +110,7 @@ def compress_batch(blocks, orders):
 def compress_best_batch(blocks, methods):
     """The reference's caller-side "try several methods, keep the smallest" loop (tokenise_name3.c:1246-1300)
     as one call: list of bytes, list of order values -> (list of bytes|None, chosen order per block, statuses)."""
-    ctx = _Ctx()
+    ctx = _thread_ctx()
     L = ctx.L
     n, k = len(blocks), len(methods)
     srcs = [np.frombuffer(bytes(b), dtype=np.uint8) for b in blocks]

@@ -472,7 +472,8 @@ static int run_slab(rans4x16_hip_ctx *c, int n, bool decode,
 //   * A slab's results are copied out as soon as its kernels finish, beside later slabs' kernels.
 // A chain kernel needs its 25-55 ms per MiB of block size however few blocks it is given, so slabs are
 // large (up to 2 GiB of input + output capacity) and all lanes run at once.
-// Knobs: R4X16_HOST_PIPE_MB (smallest batch that takes this route, default 64; 0 = never),
+// Knobs: R4X16_HOST_PIPE_MB (batches of at least this size, or of 32 blocks and more, take this route; default 64;
+//        0 = never),
 //        R4X16_HOST_THREADS (default 8), R4X16_HOST_LANES (default 2), R4X16_HOST_SLAB_MIN_MB (default 32).
 // ---------------------------------------------------------------------------------------------
 static long env_long(const char *name, long dflt)
@@ -548,9 +549,13 @@ static int pipe_prepare(rans4x16_hip_ctx *c, int threads, int nlanes, size_t nev
             // kernels one after the other.  Lanes therefore take different priorities: different queues.
             int least = 0, greatest = 0;
             if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least > greatest) {
+                // (the copy streams have the default priority, the middle of the range: the first two lanes take
+                //  the two ends, so that no copy shares a queue with a lane's kernels either)
                 const int levels = least - greatest + 1;
+                const int li = (int)(hp->lanes.size() % (size_t)levels);
+                const int prio = li == 0 ? greatest : li == 1 ? least : greatest + li - 1;
                 hipStream_t ps = nullptr;
-                if (hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, greatest + (int)(hp->lanes.size() % (size_t)levels)) == hipSuccess) {
+                if (hipStreamCreateWithPriority(&ps, hipStreamNonBlocking, prio) == hipSuccess) {
                     (void)hipStreamDestroy(l->stream);
                     l->stream = ps;
                 }
@@ -1012,8 +1017,13 @@ static int run_plain_batch(rans4x16_hip_ctx *c, int n, bool decode,
     nlanes = nlanes < 1 ? 1 : nlanes > 16 ? 16 : nlanes;
     size_t tot = 0;
     for (int i = 0; i < n; i++) tot += (size_t)in_size[i] + out_size[i];
-    if (pipe_mb <= 0 || tot < ((size_t)pipe_mb << 20))
+    // small batches of few blocks keep the single pass (no threads to start); many small blocks take the pipeline
+    // whatever their total, because the single pass issues one driver copy per block and direction
+    // (5,000 x 4 KiB: 197 ms single pass, 35 ms pipelined; tools/small_batch_routes.py)
+    if (pipe_mb <= 0 || (tot < ((size_t)pipe_mb << 20) && n < 32))
         return run_slab(c, n, decode, in, in_size, out, out_size, order, status);
+    const long by_work = (long)(tot >> 21) + n / 64 + 1;           // a copier thread per 2 MiB / 64 blocks is plenty
+    if (threads > by_work) threads = by_work;
     const int rc = run_pipelined(c, n, decode, in, in_size, out, out_size, order, status, (int)threads, (int)nlanes);
     // -2: the pipeline's resources (pinned buffers, lane contexts) could not be set up, e.g. a locked-memory limit
     return rc == -2 ? run_slab(c, n, decode, in, in_size, out, out_size, order, status) : rc;
