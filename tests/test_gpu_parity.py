@@ -428,3 +428,28 @@ def test_pack_codes_outside_the_listed_symbols_decode_to_zero(H, oracle):
     dec, st = H.uncompress_batch([first, bad, bad], [640, 64, 64])
     assert st == [0, 0, 0] and dec[0] == bytes(range(65, 81)) * 40
     assert dec[1] == want and dec[2] == want
+
+
+def test_batch_calls_from_several_threads(H, oracle):
+    """A thread pool of callers, each with its own context (SURVEY §8b threading): three threads run pipelined
+    host batches (>= 32 blocks each, so copier threads, lanes and packing are all in play) at the same time."""
+    from concurrent.futures import ThreadPoolExecutor
+    rs = np.random.RandomState(31337)
+    jobs = []
+    for t in range(3):
+        datas = _random_inputs(rs, 150, max_n=60000)
+        orders = [int(rs.choice(sorted(DEVICE_ORDERS) + STRIPE_ORDERS)) for _ in datas]
+        jobs.append((datas, orders))
+
+    def work(job):
+        datas, orders = job
+        ok = True
+        for _ in range(2):
+            enc, st = H.compress_batch(datas, orders)
+            ok &= all(e == oracle.compress(d, o) for d, o, e in zip(datas, orders, enc))
+            dec, st = H.uncompress_batch(enc, [len(d) for d in datas])
+            ok &= dec == datas
+        return ok
+
+    with ThreadPoolExecutor(3) as ex:
+        assert all(ex.map(work, jobs))
