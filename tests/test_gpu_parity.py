@@ -375,10 +375,15 @@ def test_host_batch_pipeline_matches_single_pass(H, oracle, monkeypatch):
     datas += [b"", b"x", datagen.tile("q40+dir", 9 * (1 << 20) + 13, 3).tobytes(), b"", datagen.tile("q4", 1 << 20, 1).tobytes()]
     datas += _random_inputs(rs, 60, max_n=100000)
     orders = [int(rs.choice(sorted(DEVICE_ORDERS))) for _ in datas]
-    enc, st = H.compress_batch(datas, orders)
     want = [oracle.compress(d, o) for d, o in zip(datas, orders)]
-    bad = [(i, len(d), o) for i, (d, o, e, w) in enumerate(zip(datas, orders, enc, want)) if e != w]
-    assert not bad, bad[:10]
+    for pack in ("1", "0"):                 # results gathered on the device / copied from their slots one by one
+        monkeypatch.setenv("R4X16_HOST_PACK", pack)
+        enc, st = H.compress_batch(datas, orders)
+        bad = [(i, len(d), o) for i, (d, o, e, w) in enumerate(zip(datas, orders, enc, want)) if e != w]
+        assert not bad, (pack, bad[:10])
+        got, chosen, st = H.compress_best_batch(datas[:60], [0, 1, 65, 193])
+        for d, g in zip(datas[:60], got):
+            assert g == min((oracle.compress(d, m) for m in [0, 1, 65, 193]), key=len)
     # decode, with some streams damaged so that statuses differ per block
     comps = list(want)
     damaged = set(int(i) for i in rs.choice(len(comps), 25, replace=False) if len(comps[i]) > 40)
