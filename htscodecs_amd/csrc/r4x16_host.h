@@ -1,0 +1,71 @@
+// r4x16_host.h - what the two host-side translation units of librans4x16_hip.so share: the context, the error
+// macro and the entry points of the host-buffer batch machinery (r4x16_host.hip) used by the C ABI (r4x16_api.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+#include <string>
+#include <vector>
+#include <mutex>
+#include <atomic>
+#include <thread>
+#include <chrono>
+#include <algorithm>
+
+#include "../../include/rans4x16_hip.h"
+#include "r4x16_dev.h"
+
+extern "C" {
+void r4x16_launch_dec_front(const BatchArgs *, const DecWs *, int, int, hipStream_t);
+void r4x16_launch_dec_chain(const DecWs *, int, hipStream_t);
+void r4x16_launch_dec_back(const BatchArgs *, const DecWs *, int, int, hipStream_t);
+void r4x16_launch_enc_front(const BatchArgs *, const EncWs *, int, int, hipStream_t);
+void r4x16_launch_enc_tables(const BatchArgs *, const EncWs *, int, int, hipStream_t);
+void r4x16_launch_enc_chain(const EncWs *, int, hipStream_t);
+void r4x16_launch_enc_finish(const BatchArgs *, const EncWs *, int, int, hipStream_t);
+u32  r4x16_compress_bound(u32 size, int order);
+void r4x16_launch_stripe(const u8 *, u8 *, u32, u32, int, hipStream_t);
+}
+
+struct TimedLaunch { hipEvent_t a, b; };
+struct HostPipe;
+void r4x16_pipe_destroy(HostPipe *);
+int r4x16_ensure_stage(rans4x16_hip_ctx *c, size_t bytes);
+int r4x16_run_host_batch(rans4x16_hip_ctx *c, int n, bool decode,
+                          const unsigned char *const *in, const unsigned int *in_size,
+                          unsigned char *const *out, unsigned int *out_size, const int *order, int *status);
+
+struct rans4x16_hip_ctx {
+    int device = 0;
+    std::string err;
+    // one growing device workspace
+    u8 *ws = nullptr;
+    size_t ws_bytes = 0;
+    double *logtab = nullptr;
+    u32 *rcptab = nullptr;
+    // staging for the host-buffer entry points
+    u8 *stage = nullptr;
+    size_t stage_bytes = 0;
+    // timing hook
+    int timing = 0;
+    std::vector<TimedLaunch> timed[2];
+    size_t max_ws = (size_t)48 << 30;       // cap for one chunk of blocks
+    // host-buffer batches: this context's own stream, and the lane contexts large batches are pipelined over
+    hipStream_t stream = nullptr;
+    struct HostPipe *pipe = nullptr;
+};
+
+#define HIPCHK(ctx, call)                                                                   \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                 \
+            return -1;                                                                      \
+        }                                                                                   \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+

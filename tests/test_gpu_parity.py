@@ -363,7 +363,7 @@ def test_alphabet_sizes_at_the_tree_depth_boundaries(H, oracle):
 
 def test_host_batch_pipeline_matches_single_pass(H, oracle, monkeypatch):
     """Large host batches go through the staged pipeline (pinned bounce buffers, copier threads, slabs on
-    several lanes: r4x16_api.hip run_pipelined).  Force that route on a small batch with everything awkward
+    several lanes: r4x16_host.hip run_pipelined).  Force that route on a small batch with everything awkward
     in it: empty and tiny blocks, a block larger than a bounce buffer, per-block orders, blocks that must
     fail on decode - and require reference bytes and the same statuses as the single-pass route."""
     monkeypatch.setenv("R4X16_HOST_PIPE_MB", "1")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak of the host-buffer batch calls at scale (the staged pipeline of r4x16_api.hip): many blocks of irregular
+"""Soak of the host-buffer batch calls at scale (the staged pipeline of r4x16_host.hip): many blocks of irregular
 sizes and per-block orders, every result compared with the oracle.
 usage: soak_host_batch.py [blocks] [max block bytes] [seed]"""
 import os, sys, time
