@@ -591,7 +591,6 @@ struct EncShared {
     u8  present[256];
     u8  idx_of[256];     // byte -> compact
     u8  alpha[256];      // compact -> byte
-    double t10[256], t12[256];
     u8  pmask[256];      // terms present in this row
     u32 nsym, tab_len, bits;
     i32 status;
