@@ -216,6 +216,9 @@ static size_t dec_ws_layout(u8 *base, size_t nblk, u64 tmp_stride, u64 meta_stri
     w->meta = cv.take<u8>(nblk, meta_stride);
     w->tmp_stride = tmp_stride;
     w->meta_stride = meta_stride;
+    w->cls = cv.take<u32>(2 * nblk);
+    w->cls_list = cv.take<u32>(2 * nblk);
+    w->cls_count = cv.take<u32>(3 * CLS_MAX);
     return align_up(cv.off, 256);
 }
 

@@ -203,7 +203,14 @@ struct DecWs {
     u8 *tmp;           // [nblk][tmp_stride]   stage buffer for PACK / RLE
     u8 *meta;          // [nblk][meta_stride]  decoded RLE meta
     u64 tmp_stride, meta_stride;
+    // streams grouped by LDS size class on the device (k_dec_classify .. k_cls_scatter), so that every chain
+    // workgroup gets a full set of streams of its class whatever the mix of blocks in the batch
+    u32 *cls;          // [2*nblk]  class of each item (CLS_NONE: nothing to run)
+    u32 *cls_list;     // [2*nblk]  item indices, grouped by class
+    u32 *cls_count;    // [3][CLS_MAX]  per class: number of items, first position in cls_list, fill cursor
 };
+#define CLS_MAX  32u
+#define CLS_NONE 0xffffffffu
 
 // What the histogram kernel hands to the table kernel (per block).
 struct EncStat {

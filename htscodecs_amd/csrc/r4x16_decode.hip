@@ -965,8 +965,8 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
 // images too big for LDS (lo = largest class).
 // ---------------------------------------------------------------------------------------------
 template <bool LDS_IMG, int LV>
-__global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDesc *desc, int nitems,
-                                                    int qpw, u32 lds_per_item, u32 cls_lo, u32 cls_hi)
+__global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDesc *desc, const u32 *list, const u32 *count,
+                                                    int qpw, u32 lds_per_item)
 {
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
     const u32 lane = threadIdx.x;
@@ -974,16 +974,17 @@ __global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDes
     // Persistent: the grid holds as many workgroups as are resident at once and each walks its share
     // of the batch.  (Re-dispatching a second round of workgroups into slots as they free up left CUs
     // under-filled: 15,360 streams took 153 ms instead of 2 x 63.)
-    const int nwg = (nitems + qpw - 1) / qpw;
+    // the streams of this launch's class: count[0] of them, their item indices at list[count[CLS_MAX] ..]
+    const int nmine = (int)count[0];
+    list += count[CLS_MAX];
+    const int nwg = (nmine + qpw - 1) / qpw;
     for (int wg = (int)blockIdx.x; wg < nwg; wg += (int)gridDim.x) {
-    const int it = wg * qpw + (int)quad;
-    const bool mine = quad < (u32)qpw && it < nitems;
-    const DecItem *I = &items[mine ? it : 0];
+    const int slot = wg * qpw + (int)quad;
+    const bool mine = quad < (u32)qpw && slot < nmine;
+    const DecItem *I = &items[mine ? list[slot] : list[wg * qpw]];
     bool active = mine && I->active;
     const u32 nsym = active ? I->nsym : 1u;
     const u32 img_bytes = active ? I->img_bytes : 0u;
-    const u32 need = img_bytes + RING_BYTES;
-    active = active && need > cls_lo && need <= cls_hi && img_levels(nsym) == (u32)LV;
     if (!wave_any(active)) continue;
 
     // fields are read one by one (a register copy of the struct indexed by lane would spill)
@@ -1241,8 +1242,51 @@ extern "C" int r4x16_resident_grid(size_t lds_bytes, int waves_per_wg, int wante
     const int cap = cu_count() * resident_per_cu(lds_bytes, waves_per_wg);
     return wanted < cap ? wanted : cap;
 }
+// ---- streams -> classes, on the device ---------------------------------------------------------
+// class ids: index into DEC_CLASSES, then one catch-all per tree depth (images too large for LDS)
+#define DEC_NCLS ((u32)(sizeof(DEC_CLASSES) / sizeof(DEC_CLASSES[0])))
+struct DecClassTab { u32 n; u32 bytes[CLS_MAX]; u32 lv[CLS_MAX]; };
+__global__ void k_dec_classify(const DecItem *items, int nitems, DecClassTab tab, u32 *cls, u32 *count)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= nitems) return;
+    const DecItem *I = &items[i];
+    u32 c = CLS_NONE;
+    if (I->active) {
+        const u32 need = I->img_bytes + RING_BYTES, lv = img_levels(I->nsym);
+        c = tab.n + (lv - 2u);                                 // catch-all of this depth
+        for (u32 k = 0; k < tab.n; k++)
+            if (tab.lv[k] == lv && need <= tab.bytes[k]) { c = k; break; }   // classes of a depth ascend
+        atomicAdd(&count[c], 1u);
+    }
+    cls[i] = c;
+}
+__global__ void k_cls_scan(u32 *count)
+{
+    if (threadIdx.x == 0) {
+        u32 at = 0;
+        for (u32 c = 0; c < CLS_MAX; c++) { count[CLS_MAX + c] = at; at += count[c]; count[2 * CLS_MAX + c] = 0; }
+    }
+}
+__global__ void k_cls_scatter(const u32 *cls, int nitems, u32 *count, u32 *list)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= nitems) return;
+    const u32 c = cls[i];
+    if (c != CLS_NONE) list[count[CLS_MAX + c] + atomicAdd(&count[2 * CLS_MAX + c], 1u)] = (u32)i;
+}
+
 extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t s)
 {
+    {
+        DecClassTab tab;
+        tab.n = DEC_NCLS;
+        for (u32 k = 0; k < DEC_NCLS; k++) { tab.bytes[k] = DEC_CLASSES[k].bytes; tab.lv[k] = (u32)DEC_CLASSES[k].lv; }
+        (void)hipMemsetAsync(ws->cls_count, 0, CLS_MAX * 4, s);
+        hipLaunchKernelGGL(k_dec_classify, dim3((nitems + 255) / 256), dim3(256), 0, s, ws->items, nitems, tab, ws->cls, ws->cls_count);
+        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(64), 0, s, ws->cls_count);
+        hipLaunchKernelGGL(k_cls_scatter, dim3((nitems + 255) / 256), dim3(256), 0, s, (const u32 *)ws->cls, nitems, ws->cls_count, ws->cls_list);
+    }
     static bool once = false;
     if (!once) {
         (void)hipFuncSetAttribute((const void *)k_dec_chain<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
@@ -1250,23 +1294,23 @@ extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t 
         (void)hipFuncSetAttribute((const void *)k_dec_chain<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         once = true;
     }
-    u32 lo[5] = {0, 0, 0, 0, 0};                           // each tree depth walks its own classes from 0
     static const int force_qpw = getenv("R4X16_DEC_QPW") ? atoi(getenv("R4X16_DEC_QPW")) : 0;   // tuning aids
     static const int force_small = getenv("R4X16_DEC_QPW_SMALL") ? atoi(getenv("R4X16_DEC_QPW_SMALL")) : 0;
+    u32 ci = 0;
     for (const auto &c : DEC_CLASSES) {
         const int qpw = c.lv != 2 ? c.qpw : (force_qpw && c.bytes == 5360) ? force_qpw : (force_small && c.bytes < 5360) ? force_small : c.qpw;
         const size_t ldsb = (size_t)qpw * c.bytes;
         const int grid = r4x16_resident_grid(ldsb, 1, (nitems + qpw - 1) / qpw);
-        void (*kern)(const DecItem *, DecDesc *, int, int, u32, u32, u32) =
+        void (*kern)(const DecItem *, DecDesc *, const u32 *, const u32 *, int, u32) =
             c.lv == 2 ? k_dec_chain<true, 2> : c.lv == 3 ? k_dec_chain<true, 3> : k_dec_chain<true, 4>;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), ldsb, s, ws->items, ws->desc, nitems, qpw, c.bytes, lo[c.lv], c.bytes);
-        lo[c.lv] = c.bytes;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), ldsb, s, ws->items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci), qpw, c.bytes);
+        ci++;
     }
     // images that fit no LDS class: tables stay in global memory (L2)
     const int grid = (nitems + 15) / 16;
-    hipLaunchKernelGGL((k_dec_chain<false, 2>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, nitems, 16, 0u, lo[2], 0xffffffffu);
-    hipLaunchKernelGGL((k_dec_chain<false, 3>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, nitems, 16, 0u, lo[3], 0xffffffffu);
-    hipLaunchKernelGGL((k_dec_chain<false, 4>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, nitems, 16, 0u, lo[4], 0xffffffffu);
+    hipLaunchKernelGGL((k_dec_chain<false, 2>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci + 0), 16, 0u);
+    hipLaunchKernelGGL((k_dec_chain<false, 3>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci + 1), 16, 0u);
+    hipLaunchKernelGGL((k_dec_chain<false, 4>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci + 2), 16, 0u);
 }
 extern "C" void r4x16_launch_dec_back(const BatchArgs *a, const DecWs *ws, int base, int nblk, hipStream_t s)
 {
