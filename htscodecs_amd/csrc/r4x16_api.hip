@@ -146,6 +146,9 @@ static size_t enc_ws_layout(u8 *base, size_t nblk, u64 scratch_stride, u64 xf_st
     w->scratch2 = cv.take<u8>(nblk, scratch2_stride);
     w->stat = cv.take<EncStat>(nblk);
     w->dump = cv.take<u8>(1, ENC_DUMP_BYTES);
+    w->cls = cv.take<u32>(2 * nblk);
+    w->cls_list = cv.take<u32>(2 * nblk);
+    w->cls_count = cv.take<u32>(3 * CLS_MAX);
     w->xf_stride = xf_stride;
     w->scratch2_stride = scratch2_stride;
     return align_up(cv.off, 256);

@@ -195,6 +195,8 @@ struct EncDesc {
 #define DEC_IMG_SLOT   (IMG_MAX_BYTES + 2u * IMG_O0_BYTES)   // payload image, nested-table image, RLE-meta image
 #define TAB_BYTES      198656u                          // >= 1 + 257*257*3 (assert at rANS_static4x16pr.c:784)
 
+#define CLS_MAX  32u
+#define CLS_NONE 0xffffffffu
 struct DecWs {
     DecDesc *desc;     // [nblk]
     DecItem *items;    // [2*nblk]   [b] = payload stream of block b, [nblk+b] = its RLE meta stream
@@ -209,8 +211,7 @@ struct DecWs {
     u32 *cls_list;     // [2*nblk]  item indices, grouped by class
     u32 *cls_count;    // [3][CLS_MAX]  per class: number of items, first position in cls_list, fill cursor
 };
-#define CLS_MAX  32u
-#define CLS_NONE 0xffffffffu
+
 
 // What the histogram kernel hands to the table kernel (per block).
 struct EncStat {
@@ -244,6 +245,7 @@ struct EncWs {
     EncStat *stat;      // [nblk]
     u8 *dump;           // [ENC_DUMP_BYTES]  target of the chain coder's idle output slots (never read)
     u64 xf_stride, scratch2_stride;
+    u32 *cls, *cls_list, *cls_count;   // streams grouped by LDS size class (as in DecWs)
 };
 #define META_TAB_BYTES 1024u
 #define ENC_DUMP_BYTES 65536u

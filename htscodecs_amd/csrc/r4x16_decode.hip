@@ -1276,6 +1276,12 @@ __global__ void k_cls_scatter(const u32 *cls, int nitems, u32 *count, u32 *list)
     if (c != CLS_NONE) list[count[CLS_MAX + c] + atomicAdd(&count[2 * CLS_MAX + c], 1u)] = (u32)i;
 }
 
+// positions and lists from per-item classes and per-class counts (also used by the encoder's launcher)
+extern "C" void r4x16_launch_cls_group(const u32 *cls, int nitems, u32 *count, u32 *list, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(64), 0, s, count);
+    hipLaunchKernelGGL(k_cls_scatter, dim3((nitems + 255) / 256), dim3(256), 0, s, cls, nitems, count, list);
+}
 extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t s)
 {
     {
@@ -1284,8 +1290,7 @@ extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t 
         for (u32 k = 0; k < DEC_NCLS; k++) { tab.bytes[k] = DEC_CLASSES[k].bytes; tab.lv[k] = (u32)DEC_CLASSES[k].lv; }
         (void)hipMemsetAsync(ws->cls_count, 0, CLS_MAX * 4, s);
         hipLaunchKernelGGL(k_dec_classify, dim3((nitems + 255) / 256), dim3(256), 0, s, ws->items, nitems, tab, ws->cls, ws->cls_count);
-        hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(64), 0, s, ws->cls_count);
-        hipLaunchKernelGGL(k_cls_scatter, dim3((nitems + 255) / 256), dim3(256), 0, s, (const u32 *)ws->cls, nitems, ws->cls_count, ws->cls_list);
+        r4x16_launch_cls_group(ws->cls, nitems, ws->cls_count, ws->cls_list, s);
     }
     static bool once = false;
     if (!once) {

@@ -1671,8 +1671,8 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
 // LDS_IMG: a workgroup of up to four waves shares one LDS copy of the reciprocal table; each quad
 // owns lds_per_item bytes (image, then the word ring).  Waves never meet again after the set-up.
 template <bool LDS_IMG>
-__global__ __launch_bounds__(256) void k_enc_chain(EncItem *items, const u32 *rcptab_, u8 *dump_, int nitems, int qpw, int spw,
-                                                   u32 lds_per_item, u32 cls_lo, u32 cls_hi)
+__global__ __launch_bounds__(256) void k_enc_chain(EncItem *items, const u32 *rcptab_, u8 *dump_, const u32 *list, const u32 *count,
+                                                   int qpw, int spw, u32 lds_per_item)
 {
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
     const u32 tid = threadIdx.x;
@@ -1681,15 +1681,16 @@ __global__ __launch_bounds__(256) void k_enc_chain(EncItem *items, const u32 *rc
     const u32 wq = lane >> 2;
     const u32 quad = (tid >> 6) * (u32)spw + wq;
     // persistent: as many workgroups as are resident at once, each walking its share (see k_dec_chain)
-    const int nwg = (nitems + qpw - 1) / qpw;
+    // the streams of this launch's class, grouped on the device (k_enc_classify, r4x16_launch_cls_group)
+    const int nmine = (int)count[0];
+    list += count[CLS_MAX];
+    const int nwg = (nmine + qpw - 1) / qpw;
     for (int wg = (int)blockIdx.x; wg < nwg; wg += (int)gridDim.x) {
-    const int it = wg * qpw + (int)quad;
-    const bool mine = wq < (u32)spw && quad < (u32)qpw && it < nitems;
-    EncItem *I = &items[mine ? it : 0];
+    const int slot = wg * qpw + (int)quad;
+    const bool mine = wq < (u32)spw && quad < (u32)qpw && slot < nmine;
+    EncItem *I = &items[mine ? list[slot] : list[wg * qpw]];
     bool active = mine && I->active;
     const u32 img_bytes = active ? I->img_bytes : 0u;
-    const u32 need = img_bytes + ENC_RING_BYTES;
-    active = active && need > cls_lo && need <= cls_hi;
     if (LDS_IMG) {
         // workgroup-wide "does anybody have work here" through one dword of the dynamic LDS
         // (__syncthreads_or would bring 256 bytes of static LDS with it: one stream's worth of room)
@@ -1844,14 +1845,37 @@ extern "C" void r4x16_launch_enc_tables(const BatchArgs *a, const EncWs *ws, int
 }
 extern "C" int r4x16_resident_grid(size_t lds_bytes, int waves_per_wg, int wanted);      // r4x16_decode.hip
 extern "C" int r4x16_cu_count(void);
+struct EncClassTab { u32 n; u32 bytes[CLS_MAX]; };
+__global__ void k_enc_classify(const EncItem *items, int nitems, EncClassTab tab, u32 *cls, u32 *count)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= nitems) return;
+    u32 c = CLS_NONE;
+    if (items[i].active) {
+        const u32 need = items[i].img_bytes + ENC_RING_BYTES;
+        c = tab.n;                                             // images too large for LDS
+        for (u32 k = 0; k < tab.n; k++) if (need <= tab.bytes[k]) { c = k; break; }
+        atomicAdd(&count[c], 1u);
+    }
+    cls[i] = c;
+}
+extern "C" void r4x16_launch_cls_group(const u32 *cls, int nitems, u32 *count, u32 *list, hipStream_t s);   // r4x16_decode.hip
 extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t s)
 {
+    {
+        EncClassTab tab;
+        tab.n = 0;
+        for (const u32 bytes : ENC_CLASSES) tab.bytes[tab.n++] = bytes;
+        (void)hipMemsetAsync(ws->cls_count, 0, CLS_MAX * 4, s);
+        hipLaunchKernelGGL(k_enc_classify, dim3((nitems + 255) / 256), dim3(256), 0, s, (const EncItem *)ws->items, nitems, tab, ws->cls, ws->cls_count);
+        r4x16_launch_cls_group(ws->cls, nitems, ws->cls_count, ws->cls_list, s);
+    }
     static bool once = false;
     if (!once) {
         (void)hipFuncSetAttribute((const void *)k_enc_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         once = true;
     }
-    u32 lo = 0;
+    u32 ci = 0;
     static const int force_qpw = getenv("R4X16_ENC_QPW") ? atoi(getenv("R4X16_ENC_QPW")) : 0;   // tuning aids
     static const int force_waves = getenv("R4X16_ENC_WAVES") ? atoi(getenv("R4X16_ENC_WAVES")) : 0;
     for (const u32 bytes : ENC_CLASSES) {
@@ -1872,11 +1896,12 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
         const size_t ldsb = (size_t)ENC_LRCP_BYTES + (size_t)qpw * bytes;
         const int grid = r4x16_resident_grid(ldsb, waves, (nitems + qpw - 1) / qpw);
         hipLaunchKernelGGL(k_enc_chain<true>, dim3(grid), dim3(WAVE * waves), ldsb, s,
-                           ws->items, ws->rcptab, ws->dump, nitems, qpw, spw, bytes, lo, bytes);
-        lo = bytes;
+                           ws->items, ws->rcptab, ws->dump, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci), qpw, spw, bytes);
+        ci++;
     }
     const int grid = (nitems + 15) / 16;
-    hipLaunchKernelGGL(k_enc_chain<false>, dim3(grid), dim3(WAVE), 0, s, ws->items, ws->rcptab, ws->dump, nitems, 16, 16, 0u, lo, 0xffffffffu);
+    hipLaunchKernelGGL(k_enc_chain<false>, dim3(grid), dim3(WAVE), 0, s, ws->items, ws->rcptab, ws->dump,
+                       (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci), 16, 16, 0u);
 }
 extern "C" void r4x16_launch_enc_finish(const BatchArgs *a, const EncWs *ws, int base, int nblk, hipStream_t s)
 {
