@@ -1261,6 +1261,7 @@ __global__ void k_dec_classify(const DecItem *items, int nitems, DecClassTab tab
     }
     cls[i] = c;
 }
+__global__ void k_cls_zero(u32 *count) { if (threadIdx.x < CLS_MAX) count[threadIdx.x] = 0; }
 __global__ void k_cls_scan(u32 *count)
 {
     if (threadIdx.x == 0) {
@@ -1277,6 +1278,10 @@ __global__ void k_cls_scatter(const u32 *cls, int nitems, u32 *count, u32 *list)
 }
 
 // positions and lists from per-item classes and per-class counts (also used by the encoder's launcher)
+extern "C" void r4x16_launch_cls_zero(u32 *count, hipStream_t s)     // (a kernel, not hipMemsetAsync: the runtime's first
+{                                                                      //  memset on a stream cost 0.5 s once per process)
+    hipLaunchKernelGGL(k_cls_zero, dim3(1), dim3(64), 0, s, count);
+}
 extern "C" void r4x16_launch_cls_group(const u32 *cls, int nitems, u32 *count, u32 *list, hipStream_t s)
 {
     hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(64), 0, s, count);
@@ -1288,7 +1293,7 @@ extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t 
         DecClassTab tab;
         tab.n = DEC_NCLS;
         for (u32 k = 0; k < DEC_NCLS; k++) { tab.bytes[k] = DEC_CLASSES[k].bytes; tab.lv[k] = (u32)DEC_CLASSES[k].lv; }
-        (void)hipMemsetAsync(ws->cls_count, 0, CLS_MAX * 4, s);
+        r4x16_launch_cls_zero(ws->cls_count, s);
         hipLaunchKernelGGL(k_dec_classify, dim3((nitems + 255) / 256), dim3(256), 0, s, ws->items, nitems, tab, ws->cls, ws->cls_count);
         r4x16_launch_cls_group(ws->cls, nitems, ws->cls_count, ws->cls_list, s);
     }

@@ -1860,13 +1860,14 @@ __global__ void k_enc_classify(const EncItem *items, int nitems, EncClassTab tab
     cls[i] = c;
 }
 extern "C" void r4x16_launch_cls_group(const u32 *cls, int nitems, u32 *count, u32 *list, hipStream_t s);   // r4x16_decode.hip
+extern "C" void r4x16_launch_cls_zero(u32 *count, hipStream_t s);
 extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t s)
 {
     {
         EncClassTab tab;
         tab.n = 0;
         for (const u32 bytes : ENC_CLASSES) tab.bytes[tab.n++] = bytes;
-        (void)hipMemsetAsync(ws->cls_count, 0, CLS_MAX * 4, s);
+        r4x16_launch_cls_zero(ws->cls_count, s);
         hipLaunchKernelGGL(k_enc_classify, dim3((nitems + 255) / 256), dim3(256), 0, s, (const EncItem *)ws->items, nitems, tab, ws->cls, ws->cls_count);
         r4x16_launch_cls_group(ws->cls, nitems, ws->cls_count, ws->cls_list, s);
     }
