@@ -1846,18 +1846,24 @@ extern "C" void r4x16_launch_enc_tables(const BatchArgs *a, const EncWs *ws, int
 extern "C" int r4x16_resident_grid(size_t lds_bytes, int waves_per_wg, int wanted);      // r4x16_decode.hip
 extern "C" int r4x16_cu_count(void);
 struct EncClassTab { u32 n; u32 bytes[CLS_MAX]; };
-__global__ void k_enc_classify(const EncItem *items, int nitems, EncClassTab tab, u32 *cls, u32 *count)
+__global__ __launch_bounds__(256) void k_enc_classify(const EncItem *items, int nitems, EncClassTab tab, u32 *cls, u32 *count)
 {
+    __shared__ u32 local[CLS_MAX];
+    if (threadIdx.x < CLS_MAX) local[threadIdx.x] = 0;
+    __syncthreads();
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i >= nitems) return;
-    u32 c = CLS_NONE;
-    if (items[i].active) {
-        const u32 need = items[i].img_bytes + ENC_RING_BYTES;
-        c = tab.n;                                             // images too large for LDS
-        for (u32 k = 0; k < tab.n; k++) if (need <= tab.bytes[k]) { c = k; break; }
-        atomicAdd(&count[c], 1u);
+    if (i < nitems) {
+        u32 c = CLS_NONE;
+        if (items[i].active) {
+            const u32 need = items[i].img_bytes + ENC_RING_BYTES;
+            c = tab.n;                                         // images too large for LDS
+            for (u32 k = 0; k < tab.n; k++) if (need <= tab.bytes[k]) { c = k; break; }
+            atomicAdd(&local[c], 1u);
+        }
+        cls[i] = c;
     }
-    cls[i] = c;
+    __syncthreads();
+    if (threadIdx.x < CLS_MAX && local[threadIdx.x]) atomicAdd(&count[threadIdx.x], local[threadIdx.x]);
 }
 extern "C" void r4x16_launch_cls_group(const u32 *cls, int nitems, u32 *count, u32 *list, hipStream_t s);   // r4x16_decode.hip
 extern "C" void r4x16_launch_cls_zero(u32 *count, hipStream_t s);
