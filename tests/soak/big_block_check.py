@@ -1,5 +1,5 @@
 import os, sys, time
-R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np, htscodecs_amd as H, datagen, cpu_libs
 orc = cpu_libs.oracle()

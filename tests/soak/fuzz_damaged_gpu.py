@@ -8,7 +8,7 @@ the oracle.  Contract checked per case:
     device rejects, oracle not -> only with one of the documented stricter statuses (6, 7, 8)
 usage: fuzz_damaged_gpu.py [valid streams] [mutants per stream] [seed]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import htscodecs_amd as H

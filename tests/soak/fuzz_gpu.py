@@ -2,7 +2,7 @@
 """One-off differential fuzz on the GPU box: random inputs x random order flags, device library vs the oracle.
 usage: fuzz_gpu.py [cases] [seed]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import htscodecs_amd as H

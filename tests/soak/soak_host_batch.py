@@ -3,7 +3,7 @@
 sizes and per-block orders, every result compared with the oracle.
 usage: soak_host_batch.py [blocks] [max block bytes] [seed]"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import htscodecs_amd as H

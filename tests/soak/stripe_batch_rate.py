@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Rate of X_STRIPE blocks through the host batch calls (they are expanded into device batches of their planes)."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, htscodecs_amd as H, datagen, cpu_libs
 orc = cpu_libs.oracle()

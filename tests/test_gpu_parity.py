@@ -424,7 +424,7 @@ def test_compress_best_keeps_what_the_reference_loop_keeps(H, oracle):
 
 def test_pack_codes_outside_the_listed_symbols_decode_to_zero(H, oracle):
     """rANS_static4x16pr.c:1524: `uint8_t map[16] = {0}` - a damaged X_PACK stream whose nibbles exceed the
-    symbol count decodes those positions to byte 0 (found by tools/fuzz_damaged_gpu.py, seed 909)."""
+    symbol count decodes those positions to byte 0 (found by tests/soak/fuzz_damaged_gpu.py, seed 909)."""
     bad = bytes.fromhex("a0150800010203040506070b7150338022737671141307")
     want = oracle.uncompress(bad, capacity=64, out_size_hint=64)
     assert want == bytes.fromhex("010700050303000002020307060701070401030107")
