@@ -458,3 +458,36 @@ def test_batch_calls_from_several_threads(H, oracle):
 
     with ThreadPoolExecutor(3) as ex:
         assert all(ex.map(work, jobs))
+
+
+def test_batch_with_undersized_output_slots(H, oracle):
+    """Caller-provided capacities below rans_compress_bound_4x16 fail those blocks (status 1, size 0) and nothing
+    else - on the pipelined route too, where failed blocks take part in the device-side packing with length 0."""
+    import ctypes as C
+    from htscodecs_amd import codec
+    L = H.load()
+    ctx = codec._thread_ctx()
+    rs = np.random.RandomState(808)
+    datas = _random_inputs(rs, 80, max_n=30000)
+    orders = [int(rs.choice([0, 1, 65, 193])) for _ in datas]
+    n = len(datas)
+    srcs = [np.frombuffer(d, dtype=np.uint8) for d in datas]
+    caps = [L.rans_compress_bound_4x16(len(d), o) for d, o in zip(datas, orders)]
+    small = set(range(3, n, 7))
+    for i in small:
+        caps[i] = max(1, caps[i] // 3)
+    outs = [np.empty(max(c, 1), dtype=np.uint8) for c in caps]
+    dummy = np.zeros(1, dtype=np.uint8)
+    in_p = (C.c_void_p * n)(*[(s.ctypes.data if len(s) else dummy.ctypes.data) for s in srcs])
+    out_p = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    in_sz = (C.c_uint * n)(*[len(s) for s in srcs])
+    out_sz = (C.c_uint * n)(*caps)
+    ords = (C.c_int * n)(*orders)
+    status = (C.c_int * n)()
+    rc = L.rans4x16_hip_compress_batch(ctx.h, n, in_p, in_sz, out_p, out_sz, ords, status)
+    assert rc == len(small)
+    for i in range(n):
+        if i in small:
+            assert status[i] == 1 and out_sz[i] == 0
+        else:
+            assert status[i] == 0 and outs[i][:out_sz[i]].tobytes() == oracle.compress(datas[i], orders[i]), i
