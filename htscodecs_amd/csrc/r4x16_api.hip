@@ -183,6 +183,7 @@ extern "C" int rans4x16_hip_compress_dev(rans4x16_hip_ctx *c, int n,
     size_t chunk = c->max_ws / per_blk;
     if (chunk < 1) chunk = 1;
     if (chunk > (size_t)n) chunk = (size_t)n;
+    chunk = ((size_t)n + ((size_t)n + chunk - 1) / chunk - 1) / (((size_t)n + chunk - 1) / chunk);   // equal chunks, not full ones and a rest
     const size_t need = enc_ws_layout(nullptr, chunk, scratch_stride, xf_stride, scratch2_stride, &w);
     if (ensure_ws(c, need) != 0) return -1;
     enc_ws_layout(c->ws, chunk, scratch_stride, xf_stride, scratch2_stride, &w);
@@ -252,6 +253,7 @@ extern "C" int rans4x16_hip_uncompress_dev(rans4x16_hip_ctx *c, int n,
     size_t chunk = c->max_ws / per_blk;
     if (chunk < 1) chunk = 1;
     if (chunk > (size_t)n) chunk = (size_t)n;
+    chunk = ((size_t)n + ((size_t)n + chunk - 1) / chunk - 1) / (((size_t)n + chunk - 1) / chunk);   // equal chunks, not full ones and a rest
     const size_t need = dec_ws_layout(nullptr, chunk, tmp_stride, meta_stride, &w);
     if (ensure_ws(c, need) != 0) return -1;
     dec_ws_layout(c->ws, chunk, tmp_stride, meta_stride, &w);
