@@ -426,7 +426,7 @@ struct FrontShared {
 // or more bytes left the FIRST symbol is accepted even when it is 0) followed by a checked loop
 // with the same body; this is the checked body with that entry rule.  Marks present[]; returns
 // bytes consumed, 0 on failure.
-__device__ u32 get_alphabet(ByteSrc &s, u32 pos, u32 end, u8 *present)
+__device__ __forceinline__ u32 get_alphabet(ByteSrc &s, u32 pos, u32 end, u8 *present)
 {
     if (pos >= end) return 0;
     u32 p = pos;
@@ -517,7 +517,7 @@ __device__ void write_row(u8 *rowp, const FrontShared &S, u32 n, bool empty, u32
 // Order-0 stream front end: src[pos, pos+len) holds table, states, words.
 // rANS_static4x16pr.c:500-561.  All lanes call; on return S.status / S.R / S.words_pos are set
 // and the single-row image is at `img`.
-__device__ void o0_front(ByteSrc &src, u32 pos, u32 len, u32 out_sz, u8 *img, FrontShared &S, u32 lane)
+__device__ __forceinline__ void o0_front(ByteSrc &src, u32 pos, u32 len, u32 out_sz, u8 *img, FrontShared &S, u32 lane)
 {
     for (u32 j = lane; j < 256; j += WAVE) { S.present[j] = 0; S.F[j] = 0; }
     __syncthreads();
