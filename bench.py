@@ -12,8 +12,11 @@ with the serial per-block loop replaced by batch calls).
   cpu_baseline  the reference C library (oracle/_ref, built from the untouched sources) — or the
              oracle port when that .so is absent — timed on this host's cores on a bounded sample
 
-Launch: python bench.py [--gpus N --steps K --warmup W]; for N>1 under torch.distributed.run
-(one rank per GPU; blocks are independent, so ranks share nothing but the final barrier/max).
+Launch: python bench.py [--gpus N --steps K --warmup W].  N > 1: one rank per GPU, either started by
+torch.distributed.run (RANK / WORLD_SIZE / LOCAL_RANK in the environment) or - when those are absent - by
+this script itself, which then spawns N child ranks BEFORE it touches the GPU and relays rank 0's JSON line.
+Blocks are independent: the global batch of N x blocks is cut by the library's own partition
+(rans4x16_hip_partition) and the ranks share nothing but the final barrier / max.
 """
 import argparse
 import ctypes as C
@@ -116,6 +119,36 @@ def cpu_baseline(order, blk_size, name, seconds_target=12.0):
     }
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (fresh processes; this parent
+    never initialises the GPU), wait for them, pass rank 0's output through."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()            # counts devices without initialising the runtime
+    env = dict(os.environ)
+    if have < n:
+        if os.environ.get("R4X16_OVERSUBSCRIBE") != "1":
+            sys.exit(f"bench.py: --gpus {n} but {have} GPU(s) visible (R4X16_OVERSUBSCRIBE=1 rehearses "
+                     f"{n} ranks on the cards present, over gloo)")
+        env["R4X16_DIST_BACKEND"] = "gloo"
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                 MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if have and have < n:
+            e["R4X16_FORCE_DEVICE"] = str(r % have)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,7 +160,11 @@ def main():
     ap.add_argument("--data", default="q40+dir")
     ap.add_argument("--order", type=int, default=1)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-host", action="store_true", help="skip the PCIe-inclusive host-buffer figure")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)                       # does not return
 
     import torch
     import htscodecs_amd as H
@@ -145,7 +182,11 @@ def main():
 
     nblk, bs, order = args.blocks, args.block_size, args.order
     dc = H.DeviceCodec(local)
-    d_in, in_off, in_size = build_batch(torch, dev, args.data, nblk, bs, rank * nblk)
+    # the job is world x nblk blocks; this rank's contiguous share comes from the library's partition
+    lo, hi = shard.uniform_share(world * nblk, world, rank)
+    assert hi - lo == nblk, (lo, hi, nblk)
+    first = lo
+    d_in, in_off, in_size = build_batch(torch, dev, args.data, nblk, bs, first)
     cap = H.rans_compress_bound_4x16(bs, order)
     slot = (cap + 255) // 256 * 256
     d_comp = torch.zeros(nblk * slot, dtype=torch.uint8, device=dev)
@@ -199,7 +240,7 @@ def main():
         import datagen
         chk = cpu_libs.reference() or cpu_libs.oracle()
         for b in (0, nblk // 2, nblk - 1):
-            want = chk.compress(block_bytes(args.data, bs, b, rank * nblk).tobytes(), order)
+            want = chk.compress(block_bytes(args.data, bs, b, first).tobytes(), order)
             got = d_comp[b * slot:b * slot + int(csz[b])].cpu().numpy().tobytes()
             assert got == want, f"block {b}: device stream differs from the CPU reference"
 

@@ -11,11 +11,11 @@ this package is the thin Python mirror of that interface used by the tests and t
 from .lib import load, LibraryNotBuilt, STATUS_NAMES  # noqa: F401
 from .codec import (  # noqa: F401
     rans_compress_bound_4x16, rans_compress_4x16, rans_uncompress_4x16,
-    compress_batch, compress_best_batch, uncompress_batch, DeviceCodec,
+    compress_batch, compress_best_batch, uncompress_batch, DeviceCodec, MultiCodec,
 )
 
 __all__ = [
     "load", "LibraryNotBuilt", "STATUS_NAMES",
     "rans_compress_bound_4x16", "rans_compress_4x16", "rans_uncompress_4x16",
-    "compress_batch", "compress_best_batch", "uncompress_batch", "DeviceCodec",
+    "compress_batch", "compress_best_batch", "uncompress_batch", "DeviceCodec", "MultiCodec",
 ]

@@ -102,6 +102,59 @@ def _host_batch(blocks, decode, orders=None, caps=None):
     return res, list(status)
 
 
+class MultiCodec:
+    """Host-buffer batches over several GPUs of one node (include/rans4x16_hip.h part 3): the library cuts the
+    batch into contiguous ranges, one per device.  devices=None: every visible device; a device may be listed
+    twice (two pipelines on one card)."""
+
+    def __init__(self, devices=None):
+        self.L = _lib.load()
+        if devices is None:
+            self.h = self.L.rans4x16_hip_multi_create(0, None)
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            self.h = self.L.rans4x16_hip_multi_create(len(devices), arr)
+        if not self.h:
+            raise RuntimeError("rans4x16_hip_multi_create failed: no usable HIP device (no CPU path exists)")
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.L.rans4x16_hip_multi_destroy(self.h)
+        except Exception:
+            pass
+
+    def devices(self):
+        return self.L.rans4x16_hip_multi_devices(self.h)
+
+    def _run(self, blocks, decode, orders=None, caps=None):
+        L = self.L
+        n = len(blocks)
+        srcs = [np.frombuffer(bytes(b), dtype=np.uint8) for b in blocks]
+        capv = list(caps) if decode else [L.rans_compress_bound_4x16(len(s), o) for s, o in zip(srcs, orders)]
+        outs = [np.empty(max(c, 1), dtype=np.uint8) for c in capv]
+        dummy = np.zeros(1, dtype=np.uint8)
+        in_p = (C.c_void_p * n)(*[(s.ctypes.data if len(s) else dummy.ctypes.data) for s in srcs])
+        out_p = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        in_sz = (C.c_uint * n)(*[len(s) for s in srcs])
+        out_sz = (C.c_uint * n)(*capv)
+        status = (C.c_int * n)()
+        if decode:
+            rc = L.rans4x16_hip_uncompress_batch_multi(self.h, n, in_p, in_sz, out_p, out_sz, status)
+        else:
+            ords = (C.c_int * n)(*orders)
+            rc = L.rans4x16_hip_compress_batch_multi(self.h, n, in_p, in_sz, out_p, out_sz, ords, status)
+        if rc < 0:
+            raise RuntimeError("multi-device batch failed: " + L.rans4x16_hip_multi_last_error(self.h).decode())
+        return [outs[i][:out_sz[i]].tobytes() if status[i] == 0 else None for i in range(n)], list(status)
+
+    def compress_batch(self, blocks, orders):
+        return self._run(blocks, False, orders=orders)
+
+    def uncompress_batch(self, blocks, caps):
+        return self._run(blocks, True, caps=caps)
+
+
 def compress_batch(blocks, orders):
     """list of bytes, list of int -> (list of bytes|None, list of status)."""
     return _host_batch(blocks, False, orders=orders)

@@ -59,6 +59,7 @@ extern "C" void rans4x16_hip_destroy(rans4x16_hip_ctx *c)
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (int w = 0; w < 2; w++)
         for (auto &t : c->timed[w]) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    if (c->ws_done) (void)hipEventDestroy(c->ws_done);
     if (c->ws) (void)hipFree(c->ws);
     if (c->stage) (void)hipFree(c->stage);
     if (c->logtab) (void)hipFree(c->logtab);
@@ -96,8 +97,47 @@ static int ensure_ws(rans4x16_hip_ctx *c, size_t bytes)
 {
     if (bytes <= c->ws_bytes) return 0;
     if (c->ws) { HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, hipFree(c->ws)); c->ws = nullptr; c->ws_bytes = 0; }
-    HIPCHK(c, hipMalloc((void **)&c->ws, bytes));
+    const hipError_t e = hipMalloc((void **)&c->ws, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();                   // not sticky: the caller retries with a smaller chunk
+        c->ws = nullptr;
+        c->err = std::string("hipMalloc of the workspace (") + std::to_string(bytes >> 20) + " MiB): " + hipGetErrorString(e);
+        return -1;
+    }
     c->ws_bytes = bytes;
+    return 0;
+}
+
+// Blocks per workspace chunk: as many as the cap allows (a fixed ceiling, and three quarters of what the device has
+// free right now - other contexts and other processes share the card), in equal chunks rather than full ones and a rest.
+static size_t plan_chunk(rans4x16_hip_ctx *c, size_t n, size_t per_blk)
+{
+    size_t cap = c->max_ws;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const size_t room = (free_b + c->ws_bytes) / 4 * 3;
+        if (room < cap) cap = room;
+    }
+    size_t chunk = cap / per_blk;
+    if (chunk < 1) chunk = 1;
+    if (chunk > n) chunk = n;
+    const size_t rounds = (n + chunk - 1) / chunk;
+    return (n + rounds - 1) / rounds;
+}
+
+// A context has ONE workspace: calls on different streams must not overlap on it.  Every *_dev call ends with an
+// event on its stream; a call on another stream first waits for the previous call's event.
+static int ws_order_begin(rans4x16_hip_ctx *c, hipStream_t s)
+{
+    if (c->ws_busy && s != c->ws_stream) HIPCHK(c, hipStreamWaitEvent(s, c->ws_done, 0));
+    return 0;
+}
+static int ws_order_end(rans4x16_hip_ctx *c, hipStream_t s)
+{
+    if (!c->ws_done) HIPCHK(c, hipEventCreateWithFlags(&c->ws_done, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->ws_done, s));
+    c->ws_stream = s;
+    c->ws_busy = true;
     return 0;
 }
 
@@ -180,12 +220,14 @@ extern "C" int rans4x16_hip_compress_dev(rans4x16_hip_ctx *c, int n,
     const u64 scratch2_stride = xf ? align_up((size_t)r4x16_compress_bound(max_in_size + 768, 0) + 64, 256) : 0;
     EncWs w;
     const size_t per_blk = enc_ws_layout(nullptr, 1, scratch_stride, xf_stride, scratch2_stride, &w) + 4096;
-    size_t chunk = c->max_ws / per_blk;
-    if (chunk < 1) chunk = 1;
-    if (chunk > (size_t)n) chunk = (size_t)n;
-    chunk = ((size_t)n + ((size_t)n + chunk - 1) / chunk - 1) / (((size_t)n + chunk - 1) / chunk);   // equal chunks, not full ones and a rest
-    const size_t need = enc_ws_layout(nullptr, chunk, scratch_stride, xf_stride, scratch2_stride, &w);
-    if (ensure_ws(c, need) != 0) return -1;
+    size_t chunk = plan_chunk(c, (size_t)n, per_blk);
+    if (ws_order_begin(c, s) != 0) return -1;
+    for (;;) {                                     // out of memory: walk the batch in smaller chunks
+        const size_t need = enc_ws_layout(nullptr, chunk, scratch_stride, xf_stride, scratch2_stride, &w);
+        if (ensure_ws(c, need) == 0) break;
+        if (chunk == 1) return -1;
+        chunk = (chunk + 1) / 2;
+    }
     enc_ws_layout(c->ws, chunk, scratch_stride, xf_stride, scratch2_stride, &w);
     w.logtab = c->logtab;
     w.rcptab = c->rcptab;
@@ -206,7 +248,7 @@ extern "C" int rans4x16_hip_compress_dev(rans4x16_hip_ctx *c, int n,
         r4x16_launch_enc_finish(&a, &w, (int)base, nb, s);
     }
     HIPCHK(c, hipGetLastError());
-    return 0;
+    return ws_order_end(c, s);
 }
 
 static size_t dec_ws_layout(u8 *base, size_t nblk, u64 tmp_stride, u64 meta_stride, DecWs *w)
@@ -250,12 +292,14 @@ extern "C" int rans4x16_hip_uncompress_dev(rans4x16_hip_ctx *c, int n,
     const u64 meta_stride = align_up((size_t)max_out_cap + 512, 256);
     DecWs w;
     const size_t per_blk = dec_ws_layout(nullptr, 1, tmp_stride, meta_stride, &w) + 4096;
-    size_t chunk = c->max_ws / per_blk;
-    if (chunk < 1) chunk = 1;
-    if (chunk > (size_t)n) chunk = (size_t)n;
-    chunk = ((size_t)n + ((size_t)n + chunk - 1) / chunk - 1) / (((size_t)n + chunk - 1) / chunk);   // equal chunks, not full ones and a rest
-    const size_t need = dec_ws_layout(nullptr, chunk, tmp_stride, meta_stride, &w);
-    if (ensure_ws(c, need) != 0) return -1;
+    size_t chunk = plan_chunk(c, (size_t)n, per_blk);
+    if (ws_order_begin(c, s) != 0) return -1;
+    for (;;) {                                     // out of memory: walk the batch in smaller chunks
+        const size_t need = dec_ws_layout(nullptr, chunk, tmp_stride, meta_stride, &w);
+        if (ensure_ws(c, need) == 0) break;
+        if (chunk == 1) return -1;
+        chunk = (chunk + 1) / 2;
+    }
     dec_ws_layout(c->ws, chunk, tmp_stride, meta_stride, &w);
 
     BatchArgs a;
@@ -273,7 +317,7 @@ extern "C" int rans4x16_hip_uncompress_dev(rans4x16_hip_ctx *c, int n,
         r4x16_launch_dec_back(&a, &w, (int)base, nb, s);
     }
     HIPCHK(c, hipGetLastError());
-    return 0;
+    return ws_order_end(c, s);
 }
 
 extern "C" int rans4x16_hip_compress_batch(rans4x16_hip_ctx *c, int n,
@@ -294,6 +338,9 @@ extern "C" int rans4x16_hip_uncompress_batch(rans4x16_hip_ctx *c, int n,
 // ---------------------------------------------------------------------------------------------
 // The five htscodecs entry points (htscodecs/rANS_static4x16.h:41-50).
 // ---------------------------------------------------------------------------------------------
+// device memory a thread's context keeps between single-block calls; a call that needed more gives it back
+#define SINGLE_CALL_KEEP ((size_t)1 << 30)
+
 static rans4x16_hip_ctx *thread_ctx()
 {
     // one context per host thread: the reference API is re-entrant from thread pools
@@ -322,7 +369,9 @@ extern "C" unsigned char *rans_compress_to_4x16(unsigned char *in, unsigned int 
     unsigned char *outs[1] = { out };
     unsigned int isz[1] = { in_size };
     int ord[1] = { order };
-    if (r4x16_run_host_batch(c, 1, false, ins, isz, outs, out_size, ord, nullptr) != 0) { free(mine); return nullptr; }
+    const int rc = r4x16_run_host_batch(c, 1, false, ins, isz, outs, out_size, ord, nullptr);
+    r4x16_trim(c, SINGLE_CALL_KEEP);
+    if (rc != 0) { free(mine); return nullptr; }
     return out;
 }
 
@@ -361,7 +410,9 @@ extern "C" unsigned char *rans_uncompress_to_4x16(unsigned char *in, unsigned in
     const unsigned char *ins[1] = { in };
     unsigned char *outs[1] = { out };
     unsigned int isz[1] = { in_size };
-    if (r4x16_run_host_batch(c, 1, true, ins, isz, outs, out_size, nullptr, nullptr) != 0) { free(mine); return nullptr; }
+    const int rc = r4x16_run_host_batch(c, 1, true, ins, isz, outs, out_size, nullptr, nullptr);
+    r4x16_trim(c, SINGLE_CALL_KEEP);
+    if (rc != 0) { free(mine); return nullptr; }
     return out;
 }
 

@@ -11,6 +11,8 @@
 //   k_dec_back  : one wave per block.  RLE expansion, bit-unpacking, CAT copies, final size
 //                 and status.  Replaces :1578-1629, rle.c:142-187, pack.c:211-348.
 #include <stdlib.h>
+#include <stdio.h>
+#include <mutex>
 #include <type_traits>
 #include "r4x16_dev.h"
 
@@ -1226,17 +1228,38 @@ static int resident_per_cu(size_t lds_bytes, int waves_per_wg)
     if (n * waves_per_wg > 32) n = 32 / waves_per_wg;
     return n < 1 ? 1 : n;
 }
+// Per-device state of the launchers: a process may hold contexts on several devices, on several host threads.
+#define MAX_DEVICES 64
+static std::mutex g_dev_mu;
+static int g_cu_count[MAX_DEVICES];
+static u32 g_setup_done[MAX_DEVICES];
 static int cu_count()
 {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= MAX_DEVICES) return 256;
+    std::lock_guard<std::mutex> g(g_dev_mu);
+    int &n = g_cu_count[dev];
+    if (!n && (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)) n = 256;
     return n;
 }
 extern "C" int r4x16_cu_count(void) { return cu_count(); }
+// true exactly once per (current device, bit): kernel attributes such as the dynamic-LDS limit are per device
+extern "C" bool r4x16_first_on_device(u32 bit)
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= MAX_DEVICES) return true;
+    std::lock_guard<std::mutex> g(g_dev_mu);
+    if (g_setup_done[dev] & bit) return false;
+    g_setup_done[dev] |= bit;
+    return true;
+}
+static void lds_limit(const void *kernel, int bytes)
+{
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) fprintf(stderr, "rans4x16_hip: cannot raise a kernel's dynamic LDS limit to %d bytes: %s\n", bytes, hipGetErrorString(e));
+}
 extern "C" int r4x16_resident_grid(size_t lds_bytes, int waves_per_wg, int wanted)
 {
     const int cap = cu_count() * resident_per_cu(lds_bytes, waves_per_wg);
@@ -1313,12 +1336,10 @@ extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t 
         hipLaunchKernelGGL(k_dec_classify, dim3((nitems + 255) / 256), dim3(256), 0, s, ws->items, nitems, tab, ws->cls, ws->cls_count);
         r4x16_launch_cls_group(ws->cls, nitems, ws->cls_count, ws->cls_list, s);
     }
-    static bool once = false;
-    if (!once) {
-        (void)hipFuncSetAttribute((const void *)k_dec_chain<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-        (void)hipFuncSetAttribute((const void *)k_dec_chain<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-        (void)hipFuncSetAttribute((const void *)k_dec_chain<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-        once = true;
+    if (r4x16_first_on_device(1u)) {
+        lds_limit((const void *)k_dec_chain<true, 2>, 163840);
+        lds_limit((const void *)k_dec_chain<true, 3>, 163840);
+        lds_limit((const void *)k_dec_chain<true, 4>, 163840);
     }
     static const int force_qpw = getenv("R4X16_DEC_QPW") ? atoi(getenv("R4X16_DEC_QPW")) : 0;   // tuning aids
     static const int force_small = getenv("R4X16_DEC_QPW_SMALL") ? atoi(getenv("R4X16_DEC_QPW_SMALL")) : 0;

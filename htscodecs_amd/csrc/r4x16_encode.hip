@@ -1263,6 +1263,9 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
         u32 go = 0;
         H.flags = 0; H.hl = 0;
         if (cap < compress_bound(in_size, order)) st = ST_CAPACITY;
+        // the backward-write area was sized from the caller's max_in_size: a larger block would run the
+        // table and chain coders past the start of its slot, into its neighbour's
+        else if ((u64)compress_bound(in_size, 0xc1) + 64u > ws.scratch_stride) st = ST_UNSUPPORTED;
         else {
             if (in_size <= 20) order &= ~X_STRIPE;                         // :1151
             if (order & X_STRIPE) st = ST_UNSUPPORTED;                     // host entry points split stripes
@@ -1815,14 +1818,12 @@ __global__ __launch_bounds__(FINISH_THREADS) void k_enc_finish(BatchArgs a, EncW
 }
 
 // ---- host-callable launchers -------------------------------------------------------------------
+extern "C" bool r4x16_first_on_device(u32 bit);                                          // r4x16_decode.hip
 extern "C" void r4x16_launch_enc_front(const BatchArgs *a, const EncWs *ws, int base, int nblk, hipStream_t s)
 {
     // static + dynamic LDS exceeds the 64 KB default; gfx950 has 160 KB per CU
-    static bool once = false;
-    if (!once) {
+    if (r4x16_first_on_device(2u))
         (void)hipFuncSetAttribute((const void *)k_enc_front, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_DYN_LDS);
-        once = true;
-    }
     hipLaunchKernelGGL(k_enc_front, dim3(nblk), dim3(FRONT_THREADS), FRONT_DYN_LDS, s, *a, *ws, base);
 }
 // {LDS bytes per stream, streams per wave}; LDS is allocated in 1,280-byte granules.
@@ -1877,11 +1878,8 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
         hipLaunchKernelGGL(k_enc_classify, dim3((nitems + 255) / 256), dim3(256), 0, s, (const EncItem *)ws->items, nitems, tab, ws->cls, ws->cls_count);
         r4x16_launch_cls_group(ws->cls, nitems, ws->cls_count, ws->cls_list, s);
     }
-    static bool once = false;
-    if (!once) {
+    if (r4x16_first_on_device(4u))
         (void)hipFuncSetAttribute((const void *)k_enc_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-        once = true;
-    }
     u32 ci = 0;
     static const int force_qpw = getenv("R4X16_ENC_QPW") ? atoi(getenv("R4X16_ENC_QPW")) : 0;   // tuning aids
     static const int force_waves = getenv("R4X16_ENC_WAVES") ? atoi(getenv("R4X16_ENC_WAVES")) : 0;

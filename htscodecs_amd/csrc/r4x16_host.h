@@ -34,6 +34,7 @@ struct TimedLaunch { hipEvent_t a, b; };
 struct HostPipe;
 void r4x16_pipe_destroy(HostPipe *);
 int r4x16_ensure_stage(rans4x16_hip_ctx *c, size_t bytes);
+void r4x16_trim(rans4x16_hip_ctx *c, size_t keep);
 int r4x16_run_host_batch(rans4x16_hip_ctx *c, int n, bool decode,
                           const unsigned char *const *in, const unsigned int *in_size,
                           unsigned char *const *out, unsigned int *out_size, const int *order, int *status);
@@ -52,7 +53,11 @@ struct rans4x16_hip_ctx {
     // timing hook
     int timing = 0;
     std::vector<TimedLaunch> timed[2];
-    size_t max_ws = (size_t)48 << 30;       // cap for one chunk of blocks
+    size_t max_ws = (size_t)48 << 30;       // ceiling for one chunk of blocks (plan_chunk also looks at free memory)
+    // calls on different streams are ordered on the one workspace through this event
+    hipEvent_t ws_done = nullptr;
+    hipStream_t ws_stream = nullptr;
+    bool ws_busy = false;
     // host-buffer batches: this context's own stream, and the lane contexts large batches are pipelined over
     hipStream_t stream = nullptr;
     struct HostPipe *pipe = nullptr;

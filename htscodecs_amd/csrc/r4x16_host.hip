@@ -11,9 +11,34 @@ int r4x16_ensure_stage(rans4x16_hip_ctx *c, size_t bytes)
 {
     if (bytes <= c->stage_bytes) return 0;
     if (c->stage) { HIPCHK(c, hipDeviceSynchronize()); HIPCHK(c, hipFree(c->stage)); c->stage = nullptr; c->stage_bytes = 0; }
-    HIPCHK(c, hipMalloc((void **)&c->stage, bytes));
+    // never more than half of what the card has free: sizes come from the caller's arrays, and through the
+    // out == NULL decode entry from a size field of the stream itself (hostile input must not exhaust the device)
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && bytes > free_b / 2) {
+        c->err = "host batch: staging of " + std::to_string(bytes >> 20) + " MiB exceeds half of the free device memory";
+        return -1;
+    }
+    const hipError_t e = hipMalloc((void **)&c->stage, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        c->stage = nullptr;
+        c->err = std::string("hipMalloc of the staging arena: ") + hipGetErrorString(e);
+        return -1;
+    }
     c->stage_bytes = bytes;
     return 0;
+}
+
+// Give back device memory above `keep` bytes (the single-block entry points call this after an unusually large
+// block, so that one call - or one hostile size field - does not pin gigabytes to the calling thread for good).
+void r4x16_trim(rans4x16_hip_ctx *c, size_t keep)
+{
+    if (!c || c->stage_bytes + c->ws_bytes <= keep) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    if (c->stage) { (void)hipFree(c->stage); c->stage = nullptr; c->stage_bytes = 0; }
+    if (c->ws) { (void)hipFree(c->ws); c->ws = nullptr; c->ws_bytes = 0; }
+    c->ws_busy = false;
 }
 
 static int stripe_compress_many(rans4x16_hip_ctx *, const std::vector<int> &, const unsigned char *const *, const unsigned int *,
@@ -96,7 +121,8 @@ static int run_slab(rans4x16_hip_ctx *c, int n, bool decode,
         cap[i] = out_size[i];
         out_off[i] = out_tot; out_tot += align_up((size_t)cap[i] + 16, 256);
         if (in_size[i] > max_in) max_in = in_size[i];
-        if (cap[i] > max_cap) max_cap = cap[i];
+        // decode: only blocks with PACK / RLE need the stage buffers that max_out_cap sizes (r4x16_api.hip)
+        if (cap[i] > max_cap && (!decode || (in_size[i] && (in[i][0] & (X_PACK | X_RLE))))) max_cap = cap[i];
         ord[i] = order ? order[i] : 0;
     }
     const size_t arr = align_up((size_t)n * 8, 256);
@@ -364,12 +390,15 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
     }
     for (size_t j = 0; j < nslab; j++) {
         PipeSlab &S = slabs[j];
+        u32 widest = 0;
         for (int i = S.lo; i < S.hi; i++) {
             if (in_size[i] > S.max_in) S.max_in = in_size[i];
-            if (out_size[i] > S.max_cap) S.max_cap = out_size[i];
+            if (out_size[i] > widest) widest = out_size[i];
+            // decode: only blocks with PACK / RLE need the stage buffers that max_out_cap sizes (r4x16_api.hip)
+            if (out_size[i] > S.max_cap && (!decode || (in_size[i] && (in[i][0] & (X_PACK | X_RLE))))) S.max_cap = out_size[i];
         }
         const size_t gi = PIPE_CHUNK / (align_up((size_t)S.max_in + 16, 256));
-        const size_t go = PIPE_CHUNK / ((size_t)S.max_cap + 64);
+        const size_t go = PIPE_CHUNK / ((size_t)widest + 64);
         S.gin = (int)(gi < 1 ? 1 : gi > 512 ? 512 : gi);
         S.gout = (int)(go < 1 ? 1 : go > 512 ? 512 : go);
         S.nin = (S.hi - S.lo + S.gin - 1) / S.gin;

@@ -6,21 +6,27 @@ import os
 
 
 def contiguous_partition(sizes, world):
-    """Split blocks 0..n-1 into `world` contiguous ranges with near-equal total uncompressed bytes
-    (greedy on the cumulative sum).  Returns [(lo, hi)] * world; ranges may be empty."""
+    """Split blocks 0..n-1 into `world` contiguous ranges with near-equal total uncompressed bytes.
+    The split itself is the library's (rans4x16_hip_partition, pure host arithmetic: it needs no GPU), the
+    same code the C-level multi-device calls use.  Returns [(lo, hi)] * world; ranges may be empty."""
+    import ctypes as C
+    from . import lib as _lib
     n = len(sizes)
-    total = sum(sizes)
-    bounds = [0]
-    acc = 0
-    i = 0
-    for r in range(1, world):
-        target = total * r / world
-        while i < n and acc + sizes[i] / 2 <= target:
-            acc += sizes[i]
-            i += 1
-        bounds.append(i)
-    bounds.append(n)
+    w = (C.c_uint * max(n, 1))(*[int(x) for x in sizes])
+    bounds = (C.c_int * (world + 1))()
+    if _lib.load().rans4x16_hip_partition(n, w, world, bounds) != 0:
+        raise ValueError("rans4x16_hip_partition: bad arguments")
     return [(bounds[r], bounds[r + 1]) for r in range(world)]
+
+
+def uniform_share(nblocks_total, world, rank):
+    """Range of rank `rank` when all blocks have the same size (weights NULL in the C call)."""
+    import ctypes as C
+    from . import lib as _lib
+    bounds = (C.c_int * (world + 1))()
+    if _lib.load().rans4x16_hip_partition(int(nblocks_total), None, world, bounds) != 0:
+        raise ValueError("rans4x16_hip_partition: bad arguments")
+    return bounds[rank], bounds[rank + 1]
 
 
 def env_rank():

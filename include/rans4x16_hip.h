@@ -27,6 +27,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the functions declared here are exported. */
+#pragma GCC visibility push(default)
 
 /* ---- 1. drop-in replacements (htscodecs/rANS_static4x16.h:41-50) ------------------------- */
 
@@ -137,6 +139,43 @@ int  rans4x16_hip_timing_read(rans4x16_hip_ctx *ctx, int which /*0 enc chain, 1 
 
 /* Library/ABI version and the gfx target the code object was built for. */
 const char *rans4x16_hip_version(void);
+
+/* ---- 3. several GPUs of one node ---------------------------------------------------------------
+ * Blocks are independent (every table travels in-band), so a batch is cut into contiguous ranges, one
+ * per device, and each device runs the single-GPU pipeline on its range: no collective, no peer
+ * traffic.  The split is the library's, not the caller's. */
+
+/* Contiguous partition of n blocks into `parts` ranges of near-equal total weight (greedy on the
+ * cumulative sum; a block goes to the range in which its midpoint falls).  Range r is
+ * [bounds[r], bounds[r+1]); bounds has parts + 1 entries, bounds[0] = 0, bounds[parts] = n; ranges may
+ * be empty.  weight == NULL means equal weights.  Pure host arithmetic, usable without a GPU (a
+ * multi-process launcher calls it to find its rank's share).  Returns 0, or -1 on bad arguments. */
+int rans4x16_hip_partition(int n, const unsigned int *weight, int parts, int *bounds);
+
+typedef struct rans4x16_hip_multi rans4x16_hip_multi;
+
+/* One context per listed device.  devices == NULL: devices 0 .. ndev-1; ndev <= 0: every visible device.
+ * A device may be listed more than once (two pipelines on one card: how a one-GPU box rehearses the
+ * multi-device path).  NULL if any context cannot be created. */
+rans4x16_hip_multi *rans4x16_hip_multi_create(int ndev, const int *devices);
+void                rans4x16_hip_multi_destroy(rans4x16_hip_multi *m);
+int                 rans4x16_hip_multi_devices(const rans4x16_hip_multi *m);
+const char         *rans4x16_hip_multi_last_error(const rans4x16_hip_multi *m);
+
+/* rans4x16_hip_{compress,uncompress}_batch over all devices of `m`: the batch is partitioned by
+ * uncompressed bytes (in_size for encode, the out_size capacities for decode), one host thread per
+ * device runs its range through the host-buffer pipeline, and sizes / statuses land in the caller's
+ * arrays in block order.  Same return value as the single-device calls. */
+int rans4x16_hip_compress_batch_multi(rans4x16_hip_multi *m, int n,
+                                      const unsigned char *const *in, const unsigned int *in_size,
+                                      unsigned char *const *out, unsigned int *out_size,
+                                      const int *order, int *status);
+int rans4x16_hip_uncompress_batch_multi(rans4x16_hip_multi *m, int n,
+                                        const unsigned char *const *in, const unsigned int *in_size,
+                                        unsigned char *const *out, unsigned int *out_size,
+                                        int *status);
+
+#pragma GCC visibility pop
 
 #ifdef __cplusplus
 }

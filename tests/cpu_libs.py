@@ -21,6 +21,7 @@ class _Codec:
     def __init__(self, path, prefix=""):
         self.lib = C.CDLL(path)
         self.path = path
+        self._prefix = prefix
         g = lambda n: getattr(self.lib, prefix + n)
         self.bound = g("rans_compress_bound_4x16")
         self.bound.restype = C.c_uint
@@ -31,6 +32,21 @@ class _Codec:
         self.uncompress_to = g("rans_uncompress_to_4x16")
         self.uncompress_to.restype = C.c_void_p
         self.uncompress_to.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.POINTER(C.c_uint)]
+
+    def uncompress_malloc(self, comp):
+        """The out == NULL entry (rans_uncompress_4x16, rANS_static4x16pr.c:1638): the callee sizes and mallocs
+        the result from the stream's own size field.  bytes -> bytes (None on failure)."""
+        fn = getattr(self.lib, self._prefix + "rans_uncompress_4x16")
+        fn.restype = C.c_void_p
+        fn.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_uint)]
+        src = np.ascontiguousarray(np.frombuffer(bytes(comp), dtype=np.uint8))
+        n = C.c_uint(0)
+        p = fn(src.ctypes.data, len(src), C.byref(n))
+        if not p:
+            return None
+        res = C.string_at(p, n.value)
+        C.CDLL(None).free(C.c_void_p(p))
+        return res
 
     def compress(self, data, order):
         """bytes-like -> bytes (None on failure)."""

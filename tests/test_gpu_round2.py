@@ -1,0 +1,225 @@
+"""GPU tests added in round 2: the reference driver's calling pattern, arbitrary bytes through the malloc'ing
+entry point, an oversized block inside a device batch, the multi-device calls, the per-GPU share of
+BASELINE.json configs[4], and bench.py's own N-rank launch."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import datagen
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def H():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import htscodecs_amd
+    htscodecs_amd.load()
+    return htscodecs_amd
+
+
+ALL_ORDERS = [0, 1, 64, 65, 128, 129, 192, 193, 8, 9, 0x48, 0xc9, (2 << 8) | 9, 16 | 1, 32]
+
+
+def test_in_size_larger_than_the_stream(H, oracle):
+    """tests/rANS_static4x16pr_test.c:206 hands rans_uncompress_to_4x16 the CAPACITY of the compressed buffer
+    as in_size: the stream is followed by slack.  Every flag set (stripe included) must decode to the same
+    bytes as with the exact length - checked against the oracle given the same oversized in_size - through
+    the single-block symbol and through the batch call."""
+    rs = np.random.RandomState(206)
+    names = ["q4", "q8", "q40+dir", "qvar"]
+    comps, datas = [], []
+    for k, order in enumerate(ALL_ORDERS * 2):
+        n = int(rs.choice([37, 1000, 30011, 70000]))
+        d = datagen.tile(names[k % 4], n, k).tobytes()
+        c = oracle.compress(d, order)
+        slack = int(rs.choice([1, 2, 7, 64, 1000, len(c)]))
+        fill = bytes(rs.randint(0, 256, size=slack).astype(np.uint8)) if k % 2 else b"\0" * slack
+        comps.append(c + fill)
+        datas.append(d)
+    for c, d in zip(comps, datas):
+        want = oracle.uncompress(c, capacity=len(d), out_size_hint=len(d))
+        assert want == d                                   # the oracle (pinned to the reference) accepts slack
+        if not (c[0] & 0x10):
+            assert H.rans_uncompress_4x16(c) == d          # out == NULL
+        assert H.rans_uncompress_4x16(c, len(d)) == d      # caller buffer
+    dec, st = H.uncompress_batch(comps, [len(d) for d in datas])
+    assert all(s == 0 for s in st), st
+    assert dec == datas
+
+
+def test_arbitrary_bytes_through_the_malloc_entry(H, oracle):
+    """tests/rANS_static4x16pr_fuzz.c:70-76 feeds arbitrary bytes to rans_uncompress_4x16 (out == NULL: the callee
+    sizes its buffer from the stream's own varint).  Outcome per input must match the oracle: rejected there ->
+    rejected here; accepted by both -> same bytes.  Includes hostile size fields (up to 2^31 - 1) on tiny inputs."""
+    rs = np.random.RandomState(7076)
+    junk = []
+    for n in (1, 2, 3, 5, 8, 16, 17, 40, 100, 300, 2000):
+        for _ in range(40):
+            junk.append(bytes(rs.randint(0, 256, size=n).astype(np.uint8)))
+    # plausible headers in front of random payloads: every flag combination, small stored sizes
+    for _ in range(600):
+        flags = int(rs.randint(0, 256)) & ~0x08
+        n = int(rs.randint(1, 400))
+        body = bytes(rs.randint(0, 256, size=int(rs.randint(0, 120))).astype(np.uint8))
+        junk.append(bytes([flags]) + (bytes([n]) if n < 128 else bytes([0x80 | (n >> 7), n & 0x7f])) + body)
+    # valid streams with a few damaged bytes (these reach the chain kernels)
+    for k in range(200):
+        d = datagen.tile(["q4", "q8", "q40+dir"][k % 3], int(rs.randint(50, 3000)), k).tobytes()
+        c = bytearray(oracle.compress(d, int(rs.choice([0, 1, 65, 129, 193]))))
+        for _ in range(int(rs.randint(0, 3))):
+            c[int(rs.randint(1, len(c)))] ^= 1 << int(rs.randint(0, 8))
+        if not c[0] & 0x08:
+            junk.append(bytes(c))
+    hostile = [bytes([0x00, 0x87, 0xff, 0xff, 0xff, 0x7e]) + bytes(24),          # order 0, claims 2^31 - 2 bytes
+               bytes([0x01, 0x87, 0xff, 0xff, 0xff, 0x7e]) + bytes(40),
+               bytes([0xc0, 0x84, 0x80, 0x80, 0x80, 0x00]) + bytes(30),          # PACK|RLE, claims 1 GiB
+               bytes([0x20, 0x87, 0xff, 0xff, 0xff, 0x7e]) + b"abc"]             # CAT longer than the input
+    agree = 0
+    for j in junk + hostile:
+        want = oracle.uncompress_malloc(j)
+        got = H.rans_uncompress_4x16(j)
+        if want is None:
+            assert got is None, j[:16].hex()
+        elif got is not None:
+            assert got == want, j[:16].hex()
+            agree += 1
+    assert agree > 100
+    # the same inputs as one batch, capacities from the streams' own size fields (bounded for the test)
+    import cpu_libs
+    small = [j for j in junk if cpu_libs.peek_ulen(j) <= 1 << 16 and not (j[0] & 0x10)]
+    caps = [cpu_libs.peek_ulen(j) for j in small]
+    dec, st = H.uncompress_batch(small, caps)
+    for j, cap, x, s in zip(small, caps, dec, st):
+        want = oracle.uncompress(j, capacity=cap, out_size_hint=cap)
+        if want is None:
+            assert x is None and s != 0
+        elif x is not None:
+            assert x == want
+        else:
+            assert s in (6, 7, 8)
+    # a hostile size field must not leave gigabytes pinned to the calling thread
+    from htscodecs_amd import codec
+    L = H.load()
+    assert H.rans_uncompress_4x16(hostile[0]) is None
+    assert H.rans_compress_4x16(b"abcd" * 100, 1) == oracle.compress(b"abcd" * 100, 1)
+
+
+def test_oversized_block_in_a_device_batch_fails_alone(H, oracle):
+    """rans4x16_hip_compress_dev sizes its backward-write areas from max_in_size; a block larger than that must be
+    refused (UNSUPPORTED) without touching its neighbours' scratch (it used to write backwards past
+    the start of its slot)."""
+    import torch
+    dc = H.DeviceCodec(0)
+    dev = dc.dev
+    sizes = [20000, 20000, 90000, 20000, 20000, 20000]
+    blocks = [datagen.tile("q40+dir", s, i) for i, s in enumerate(sizes)]
+    for order in (1, 0):
+        in_off = np.cumsum([0] + [(s + 255) // 256 * 256 for s in sizes])[:-1].astype(np.int64)
+        arena = np.zeros(int(in_off[-1]) + sizes[-1] + 256, dtype=np.uint8)
+        for b, off in zip(blocks, in_off):
+            arena[off:off + len(b)] = b
+        caps = np.array([H.rans_compress_bound_4x16(s, order) for s in sizes], dtype=np.int32)
+        out_off = np.cumsum([0] + [(int(c) + 255) // 256 * 256 for c in caps])[:-1].astype(np.int64)
+        t = lambda a: torch.from_numpy(a).to(dev)
+        d_in = t(arena)
+        d_out = torch.zeros(int(out_off[-1]) + int(caps[-1]) + 256, dtype=torch.uint8, device=dev)
+        d_osz = torch.zeros(len(sizes), dtype=torch.int32, device=dev)
+        d_st = torch.full((len(sizes),), -1, dtype=torch.int32, device=dev)
+        # the caller lies: max_in_size = 20000 although block 2 has 90000 bytes
+        dc.compress(d_in, t(in_off), t(np.array(sizes, dtype=np.int32)), d_out, t(out_off), t(caps), d_osz, d_st,
+                    order, 20000)
+        torch.cuda.synchronize()
+        st, osz, comp = d_st.cpu().numpy(), d_osz.cpu().numpy(), d_out.cpu().numpy()
+        assert st[2] == 6 and osz[2] == 0, st.tolist()
+        for i in (0, 1, 3, 4, 5):
+            assert st[i] == 0
+            assert comp[out_off[i]:out_off[i] + osz[i]].tobytes() == oracle.compress(blocks[i].tobytes(), order), (i, order)
+
+
+def test_multi_device_batch_calls(H, oracle):
+    """rans4x16_hip_{compress,uncompress}_batch_multi: the library partitions the batch, one host thread and
+    context per listed device (the one card of this box listed twice and three times), sizes and statuses land
+    in block order - also for blocks that fail."""
+    rs = np.random.RandomState(808)
+    names = ["q4", "q8", "q40+dir"]
+    datas = [datagen.tile(names[b % 3], int(rs.choice([300, 5000, 65536, 200000])), b).tobytes() for b in range(150)]
+    datas += [b"", b"z"]
+    orders = [int(rs.choice([0, 1, 65, 193, 9])) for _ in datas]
+    want = [oracle.compress(d, o) for d, o in zip(datas, orders)]
+    for devs in ([0, 0], [0, 0, 0], [0]):
+        mc = H.MultiCodec(devs)
+        assert mc.devices() == len(devs)
+        enc, st = mc.compress_batch(datas, orders)
+        assert all(s == 0 for s in st)
+        assert enc == want
+        comps = list(want)
+        broken = [5, 77, 149]
+        for i in broken:
+            comps[i] = comps[i][:max(1, len(comps[i]) // 3)]
+        dec, st = mc.uncompress_batch(comps, [len(d) for d in datas])
+        for i, (d, x, s) in enumerate(zip(datas, dec, st)):
+            if i in broken:
+                assert x is None and s != 0
+            else:
+                assert s == 0 and x == d, i
+
+
+def test_configs4_share_device_resident(H, oracle):
+    """BASELINE.json configs[4], one GPU's share: 32,768 blocks of 64 KiB cycling q4 / q8 / q40 by b mod 3, order 1,
+    through rans4x16_hip_{compress,uncompress}_dev.  Every block must round-trip (checked on the device) and a
+    sample of 120 compressed blocks is compared byte-for-byte with the oracle."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    dc = H.DeviceCodec(0)
+    dev = dc.dev
+    nblk, bs, order = 32768, 65536, 1
+    d_in, in_off, in_size = bench.build_batch(torch, dev, "mixed", nblk, bs, 0)
+    cap = H.rans_compress_bound_4x16(bs, order)
+    slot = (cap + 255) // 256 * 256
+    d_comp = torch.zeros(nblk * slot, dtype=torch.uint8, device=dev)
+    comp_off = torch.arange(nblk, dtype=torch.int64, device=dev) * slot
+    comp_cap = torch.full((nblk,), cap, dtype=torch.int32, device=dev)
+    comp_size = torch.zeros(nblk, dtype=torch.int32, device=dev)
+    st_enc = torch.full((nblk,), -1, dtype=torch.int32, device=dev)
+    dc.compress(d_in, in_off, in_size, d_comp, comp_off, comp_cap, comp_size, st_enc, order, bs)
+    d_back = torch.zeros_like(d_in)
+    back_size = torch.zeros(nblk, dtype=torch.int32, device=dev)
+    st_dec = torch.full((nblk,), -1, dtype=torch.int32, device=dev)
+    dc.uncompress(d_comp, comp_off, comp_size, d_back, in_off, in_size, back_size, st_dec, cap, bs)
+    torch.cuda.synchronize()
+    assert int((st_enc != 0).sum()) == 0 and int((st_dec != 0).sum()) == 0
+    assert torch.equal(back_size, in_size)
+    assert torch.equal(d_back, d_in)
+    csz = comp_size.cpu().numpy()
+    rs = np.random.RandomState(4)
+    for b in sorted(set([0, 1, 2, nblk - 1] + [int(x) for x in rs.randint(0, nblk, size=120)])):
+        raw = bench.block_bytes("mixed", bs, b, 0)
+        assert (d_in[b * bs:(b + 1) * bs].cpu().numpy() == raw).all(), b
+        got = d_comp[b * slot:b * slot + int(csz[b])].cpu().numpy().tobytes()
+        assert got == oracle.compress(raw.tobytes(), order), b
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher: the script spawns two ranks itself (before touching the GPU);
+    on this one-GPU box both share the card over gloo (R4X16_OVERSUBSCRIBE=1).  One JSON line, n_gpus == 2."""
+    env = dict(os.environ, R4X16_OVERSUBSCRIBE="1")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--blocks", "600",
+                        "--steps", "2", "--warmup", "1", "--no-cpu", "--no-host"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["blocks_per_gpu"] == 600
+    assert out["value"] > 0 and out["roofline"]["achieved"] > 0

@@ -78,3 +78,32 @@ def test_partition_properties():
                 assert b == c and a <= b
     parts = shard.contiguous_partition([1 << 20] * 16, 8)
     assert all(hi - lo == 2 for lo, hi in parts)
+
+
+def test_partition_is_the_librarys():
+    """shard.contiguous_partition is rans4x16_hip_partition (host arithmetic inside librans4x16_hip.so, the code the
+    C-level *_batch_multi calls use): midpoint rule, equal weights with NULL, bad arguments refused."""
+    import ctypes as C
+    import htscodecs_amd
+    L = htscodecs_amd.load()
+    b = (C.c_int * 4)()
+    w = (C.c_uint * 6)(1, 100, 1, 1, 50, 7)
+    assert L.rans4x16_hip_partition(6, w, 3, b) == 0
+    assert list(b) == [0, 2, 4, 6]          # targets 53.3 / 106.7; midpoints 0.5, 51 | 101.5, 102.5 | 128, 156.5
+    assert L.rans4x16_hip_partition(10, None, 3, b) == 0 and list(b) == [0, 3, 7, 10]
+    assert L.rans4x16_hip_partition(-1, None, 3, b) == -1
+    assert L.rans4x16_hip_partition(5, None, 0, b) == -1
+    assert shard.uniform_share(8 * 15360, 8, 3) == (3 * 15360, 4 * 15360)
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """bench.py --gpus 2 on a box with fewer GPUs says so instead of running a 1-rank job (the flag used
+    to be parsed and dropped)."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "R4X16_OVERSUBSCRIBE")}
+    if torch.cuda.device_count() >= 2:
+        return
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 2" in r.stderr
