@@ -165,10 +165,15 @@ def test_multi_device_batch_calls(H, oracle):
         broken = [5, 77, 149]
         for i in broken:
             comps[i] = comps[i][:max(1, len(comps[i]) // 3)]
+        comps[77] = b"\x01" + comps[77][1:9]          # order-1 flag, 8 bytes of payload: TRUNCATED for certain
         dec, st = mc.uncompress_batch(comps, [len(d) for d in datas])
         for i, (d, x, s) in enumerate(zip(datas, dec, st)):
             if i in broken:
-                assert x is None and s != 0
+                # a truncated stream may still decode (rANS_word.h:402-410 stops refilling at the end of the
+                # input): whatever the oracle says for this input is the expected outcome
+                ref = oracle.uncompress(comps[i], capacity=len(d), out_size_hint=len(d))
+                assert x == ref, i
+                assert (s != 0) == (ref is None)
             else:
                 assert s == 0 and x == d, i
 
