@@ -119,6 +119,67 @@ def cpu_baseline(order, blk_size, name, seconds_target=12.0):
     }
 
 
+def library_hash():
+    import hashlib
+    from htscodecs_amd import lib as _lib
+    with open(_lib.LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def chain_figure(torch, dc, kname, kernel_ms, launches_per_step, nblk, bs, spc, lanes, cus, probe, sq):
+    """SURVEY 8(d)'s second figure for the dominant chain kernel: symbols/s against (resident lanes / measured
+    per-step latency).  The latency is measured live on ONE workgroup holding its full set of streams with the
+    rest of the chip idle (`probe`); the whole-grid figure shows what contention for a CU's LDS and issue slots
+    costs on top of it."""
+    clk_khz = torch.cuda.get_device_properties(dc.dev).clock_rate
+    resident = spc * cus
+    per_launch = nblk / launches_per_step
+    rounds = per_launch / resident
+    steps = bs // 4                                        # steps of one chain over one block
+    which = 1 if kname == "k_dec_chain" else 0
+    k, ms1 = probe[which]
+    iso_ns = ms1 * 1e6 / steps if ms1 > 0 else None
+    grid_ns = kernel_ms * 1e6 / (max(1.0, float(-(-per_launch // resident))) * steps)
+    sym_s = per_launch * bs / (kernel_ms / 1e3)
+    ideal = resident * 4 / (iso_ns * 1e-9) if iso_ns else None
+    out = {"kernel": kname, "streams_per_cu": spc, "lanes_live_per_wave": lanes, "compute_units": cus,
+           "resident_streams": resident, "rounds": round(rounds, 3), "steps_per_chain": steps,
+           "ns_per_step_whole_grid": round(grid_ns, 1), "cycles_per_step_whole_grid": round(grid_ns * clk_khz / 1e6, 1),
+           "ns_per_step_one_workgroup_alone": round(iso_ns, 1) if iso_ns else None,
+           "probe_streams": k, "symbols_per_s": round(sym_s, 0),
+           "ideal_symbols_per_s": round(ideal, 0) if ideal else None,
+           "frac": round(sym_s / ideal, 4) if ideal else None,
+           "meaning": "ideal = resident streams x 4 chains / the step latency of one workgroup alone; "
+                      "frac < 1 is contention inside a CU plus a partly filled last round"}
+    if sq:
+        out["sq_counters"] = sq                            # VALU issue fraction etc. from the committed PMC pass (same build)
+    return out
+
+
+def host_path(H, name, bs, order, nblk=2048):
+    """PCIe-inclusive rate through rans4x16_hip_{compress,uncompress}_batch (host buffers in, host buffers out):
+    a bounded sample of the same workload, one warm call (contexts, pinned buffers) and one timed call each way.
+    Reported beside `value`, never as `value`."""
+    import datagen
+    blocks = [datagen.tile(name if name != "mixed" else ["q4", "q8", "q40+dir"][b % 3], bs, b).tobytes() for b in range(nblk)]
+    orders = [order] * nblk
+    H.compress_batch(blocks[:64], orders[:64])
+    t0 = time.perf_counter()
+    enc, st = H.compress_batch(blocks, orders)
+    t1 = time.perf_counter()
+    assert all(x == 0 for x in st)
+    H.uncompress_batch(enc[:64], [bs] * 64)
+    t2 = time.perf_counter()
+    dec, st = H.uncompress_batch(enc, [bs] * nblk)
+    t3 = time.perf_counter()
+    assert all(x == 0 for x in st) and dec[0] == blocks[0] and dec[-1] == blocks[-1]
+    tot = nblk * bs
+    return {"enc_MBps": round(tot / (t1 - t0) / 1e6, 1), "dec_MBps": round(tot / (t3 - t2) / 1e6, 1),
+            "value": round(tot / ((t1 - t0) + (t3 - t2)) / 1e6, 1), "unit": "MB/s",
+            "sample": f"{nblk} x {bs} B {name} blocks, order {order}, pageable host buffers through the C batch calls "
+                      f"(includes the Python marshalling of {nblk} buffers)"}
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script (fresh processes; this parent
     never initialises the GPU), wait for them, pass rank 0's output through."""
@@ -154,8 +215,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    # 15360 = 2 full rounds of the decoder's 7680 resident streams (30 per CU); the encoder holds 7936 (31 per CU)
-    ap.add_argument("--blocks", type=int, default=int(os.environ.get("R4X16_BLOCKS", 15360)))
+    # default: two full rounds of the decode chain kernel's resident streams (rans4x16_hip_residency x CUs; 45 per CU
+    # x 256 = 11,520 for the 46-symbol order-1 tables of q40): the chain kernels are persistent, a batch is walked
+    # in rounds of the resident stream count, and a partly filled last round costs a whole one
+    ap.add_argument("--blocks", type=int, default=int(os.environ.get("R4X16_BLOCKS", 0)))
     ap.add_argument("--block-size", type=int, default=1 << 20)
     ap.add_argument("--data", default="q40+dir")
     ap.add_argument("--order", type=int, default=1)
@@ -180,8 +243,14 @@ def main():
     dist = shard.init(backend, device_id=dev)       # nccl = RCCL; used for the barrier and the max only
     red_dev = dev if backend == "nccl" else None
 
-    nblk, bs, order = args.blocks, args.block_size, args.order
+    bs, order = args.block_size, args.order
     dc = H.DeviceCodec(local)
+    import datagen
+    names = ["q4", "q8", "q40+dir"] if args.data == "mixed" else [args.data]
+    nsym = max(len(set(datagen.base_text(nm).tolist()) | ({0} if order & 1 else set())) for nm in names)
+    dec_spc, dec_lanes, cus = dc.residency(True, nsym, order & 1, 10)      # (every BASELINE text chooses shift 10)
+    enc_spc, enc_lanes, _ = dc.residency(False, nsym, order & 1, 10)
+    nblk = args.blocks if args.blocks > 0 else 2 * dec_spc * cus
     # the job is world x nblk blocks; this rank's contiguous share comes from the library's partition
     lo, hi = shard.uniform_share(world * nblk, world, rank)
     assert hi - lo == nblk, (lo, hi, nblk)
@@ -198,11 +267,14 @@ def main():
     back_size = torch.zeros(nblk, dtype=torch.int32, device=dev)
     st_dec = torch.zeros(nblk, dtype=torch.int32, device=dev)
 
+    # stage buffers for the inverse transforms only when the streams can carry them (include/rans4x16_hip.h)
+    xf_cap = bs if order & 0xc0 else 0
+
     def step(ev=None):
         dc.compress(d_in, in_off, in_size, d_comp, comp_off, comp_cap, comp_size, st_enc, order, bs)
         if ev is not None:
             ev.record()
-        dc.uncompress(d_comp, comp_off, comp_size, d_back, in_off, in_size, back_size, st_dec, cap, bs)
+        dc.uncompress(d_comp, comp_off, comp_size, d_back, in_off, in_size, back_size, st_dec, cap, xf_cap)
 
     def barrier():
         torch.cuda.synchronize()
@@ -244,6 +316,23 @@ def main():
             got = d_comp[b * slot:b * slot + int(csz[b])].cpu().numpy().tobytes()
             assert got == want, f"block {b}: device stream differs from the CPU reference"
 
+    # ---- one workgroup alone: the per-step latency of a full set of streams without neighbours on the chip
+    probe = None
+    if rank == 0:
+        probe = {}
+        for which, spc, lanes in ((1, dec_spc, dec_lanes), (0, enc_spc, enc_lanes)):
+            k = lanes // 4 if which == 1 else spc          # decode: one wave per workgroup; encode: one workgroup per CU
+            k = min(k, nblk)
+            dc.timing(True); dc.timing_read(which)
+            if which == 1:
+                dc.uncompress(d_comp, comp_off[:k], comp_size[:k], d_back, in_off[:k], in_size[:k], back_size[:k], st_dec[:k], cap, xf_cap)
+            else:
+                dc.compress(d_in, in_off[:k], in_size[:k], d_comp, comp_off[:k], comp_cap[:k], comp_size[:k], st_enc[:k], order, bs)
+            torch.cuda.synchronize()
+            ms, _ = dc.timing_read(which)
+            dc.timing(False)
+            probe[which] = (k, ms)
+
     elapsed = shard.max_over_ranks(dist, elapsed, red_dev)
 
     if rank == 0:
@@ -262,17 +351,27 @@ def main():
         alg_bytes = (nblk * bs + comp_bytes) / launches_per_step
         achieved = alg_bytes / (kavg / 1e3) / 1e9
         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE, separate runs, gfx950 FETCH correction applied) — only if taken on this very workload
-        traffic = None
+        # WRITE_SIZE, separate runs, gfx950 FETCH correction applied) - only if they were taken on this very
+        # workload AND with this very build of the library (its hash is stored with them): a kernel change without
+        # a counter refresh reports null, never a stale figure
+        traffic, traffic_source, sq = None, None, None
+        build = library_hash()
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
                 pmc = json.load(f)
             w = pmc["workload"]
-            if (w["blocks"], w["block_size"], w["data"], w["order"]) == (nblk, bs, args.data, order):
-                key = "k_dec_chain<true, 2>" if kname == "k_dec_chain" else "k_enc_chain<true>"
-                traffic = pmc["kernels"][key]["traffic_bytes"]
+            if (w["blocks"], w["block_size"], w["data"], w["order"]) == (nblk, bs, args.data, order) \
+                    and pmc.get("library_sha256_16") == build:
+                for key, v in pmc["kernels"].items():
+                    if key.startswith(kname):
+                        traffic = v["traffic_bytes"]
+                        traffic_source = "profiles/r02_pmc_traffic.json"
+                sq = pmc.get("sq", {}).get(kname)
         except (OSError, KeyError, ValueError):
             pass
+        chain = chain_figure(torch, dc, kname, dec_avg if kname == "k_dec_chain" else enc_avg, launches_per_step,
+                             nblk, bs, dec_spc if kname == "k_dec_chain" else enc_spc,
+                             dec_lanes if kname == "k_dec_chain" else enc_lanes, cus, probe, sq)
         out = {
             "metric": "MB/s uncompressed throughput (encode+decode), rANS4x16 order-1, q40 blocks",
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
@@ -285,14 +384,20 @@ def main():
             "enc_MBps": round(nblk * bs / t_enc / 1e6, 1), "dec_MBps": round(nblk * bs / t_dec / 1e6, 1),
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": traffic, "avg_kernel_ms": round(kavg, 3),
+                         "traffic": traffic, "traffic_source": traffic_source, "library_sha256_16": build,
+                         "limiter": "dependent-chain latency x resident streams, not bandwidth (see chain)",
+                         "chain": chain, "avg_kernel_ms": round(kavg, 3),
                          "enc_chain_ms": round(enc_avg, 3), "dec_chain_ms": round(dec_avg, 3),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "note": "avg_kernel_ms = HIP-event time of the chain kernel per step; the kernel is launched "
                                  "once per LDS size class and all but one class exit in microseconds, so compare with "
-                                 "rocprof's TotalDurationNs / steps (profiles/r01_final_working_launches.csv)"},
+                                 "rocprof's TotalDurationNs / steps (profiles/r02_final_working_launches.csv)"},
             "workspace_GB": round(dc.workspace_bytes() / 2**30, 2),
         }
+        if world == 1 and not args.no_host:
+            del d_back, d_comp                              # room for the host path's own staging
+            torch.cuda.empty_cache()
+            out["host_path"] = host_path(H, args.data, bs, order)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(order, bs, args.data)
         print(json.dumps(out), flush=True)

@@ -215,6 +215,14 @@ class DeviceCodec:
     def workspace_bytes(self):
         return self.L.rans4x16_hip_workspace_bytes(self.ctx.h)
 
+    def residency(self, decode, nsym, order, shift=10):
+        """(streams per CU, live lanes per wave, CUs) of the chain kernel for this kind of stream."""
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        if self.L.rans4x16_hip_residency(self.ctx.h, 1 if decode else 0, nsym, order, shift,
+                                         C.byref(a), C.byref(b), C.byref(c)) != 0:
+            raise RuntimeError("residency query failed")
+        return a.value, b.value, c.value
+
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
 

@@ -320,6 +320,29 @@ extern "C" int rans4x16_hip_uncompress_dev(rans4x16_hip_ctx *c, int n,
     return ws_order_end(c, s);
 }
 
+extern "C" int r4x16_dec_residency(u32 nsym, int order, u32 bits, int *streams_per_wave, int *waves_per_cu);
+extern "C" int r4x16_enc_residency(u32 nsym, int order, int *streams_per_wave, int *waves_per_cu);
+extern "C" int r4x16_cu_count(void);
+
+extern "C" int rans4x16_hip_residency(rans4x16_hip_ctx *c, int decode, unsigned int nsym, int order, unsigned int shift,
+                                      int *streams_per_cu, int *lanes_live_per_wave, int *compute_units)
+{
+    if (!c) return -1;
+    if (hipSetDevice(c->device) != hipSuccess) return -1;
+    int spw = 0, wpc = 0, total = 0;
+    if (decode) {
+        if (r4x16_dec_residency(nsym, order & 1, shift, &spw, &wpc) != 0) return -1;
+        total = spw * wpc;
+    } else {
+        total = r4x16_enc_residency(nsym, order & 1, &spw, &wpc);
+        if (total < 0) return -1;
+    }
+    if (streams_per_cu) *streams_per_cu = total;
+    if (lanes_live_per_wave) *lanes_live_per_wave = 4 * spw;
+    if (compute_units) *compute_units = r4x16_cu_count();
+    return 0;
+}
+
 extern "C" int rans4x16_hip_compress_batch(rans4x16_hip_ctx *c, int n,
                                            const unsigned char *const *in, const unsigned int *in_size,
                                            unsigned char *const *out, unsigned int *out_size,

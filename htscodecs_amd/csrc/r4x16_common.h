@@ -96,6 +96,32 @@ static inline __host__ __device__ u32 img_row_bytes(u32 n)
     return img_levels(n) == 2 ? 8u + 2u * img_leaf_len(n) : (304u + 2u * img_leaf_len(n) + 7u) & ~7u;
 }
 static inline __host__ __device__ u32 img_bytes(u32 n, u32 rows) { return img_alpha_bytes(n) + rows * img_row_bytes(n); }
+// ---------------------------------------------------------------------------------------------
+// Packed rows ("level 1"): order-1 streams with 10-bit tables (every total is 1024) and at most 48 symbols -
+// the quality alphabets the headline benchmark is made of.  LDS bytes per stream decide how many streams a CU
+// holds, and resident streams are the decoder's throughput, so these rows spend 10 bits per entry instead of 16:
+//
+//   alpha[s] (u16) additionally carries, in bits 10..15, `first` of the row of context s: the index of that row's
+//   first symbol of non-zero frequency.
+//   A row is a run of dwords of three 10-bit fields at bit 0, 11 and 22 (bits 10 and 21 are zero: guard bits for
+//   a compare-free "field >= m" test, see lookup in r4x16_decode.hip).  Fields L[0..]:
+//       L[0] = 1023 (stands for -1), L[j] = cum[first + j] - 1 for 1 <= j <= n - first, 1023 beyond:
+//   the INCLUSIVE end of each symbol's slot range, so that every value fits ten bits (an exclusive end can be
+//   1024, a start cannot say where the last symbol ends).  Symbol first + c, c = #{j >= 1 : L[j] < m}, owns slot m;
+//   its range is L[c] + 1 .. L[c + 1].  Leading symbols of zero frequency (byte 0 is in every order-1 alphabet
+//   and in almost no row) are skipped through `first`; later ones repeat their predecessor's end.
+//       dword 0      : root  = L[12], L[24], L[36]       (which group of twelve)
+//       dword 1 + i  : L[3i], L[3i + 1], L[3i + 2]       (group g is dwords 1 + 4g .. 1 + 4g + 4)
+//   G = ceil(n / 12) groups, 4G + 2 dwords (4G + 1 unless n = 12G): 68 bytes for 46 symbols against 108 of the u16 rows.
+// ---------------------------------------------------------------------------------------------
+#define PK_MAX_NSYM 48u
+#define PK_FIRST_SHIFT 10
+static inline __host__ __device__ u32 pk_groups(u32 n) { return n <= 12 ? 1u : n <= 24 ? 2u : n <= 36 ? 3u : 4u; }
+// (the last dword, L[12G ..], can only be selected when the alphabet fills its last group: left out otherwise, and
+//  that read runs into the next row's root or the word ring - as with the u16 rows' last dword)
+static inline __host__ __device__ u32 pk_row_bytes(u32 n) { return 8u + 16u * pk_groups(n) - (n % 12u ? 4u : 0u); }
+static inline __host__ __device__ u32 pk_img_bytes(u32 n) { return img_alpha_bytes(n) + n * pk_row_bytes(n); }
+
 #define IMG_O0_BYTES  1344u                       // 256 symbols, one row
 #define IMG_MAX_BYTES (512u + 256u * 824u)        // 256 symbols, 256 rows
 
@@ -113,8 +139,10 @@ struct DecItem {
     u32 active;      // 0 = nothing to do (failed block, CAT, empty)
     u32 blk;         // owning block (errors are reported there)
     u32 nsym;        // compact alphabet size n (decides the tree depth and the row size)
-    u32 pad[2];
+    u32 packed;      // 1: packed 10-bit rows (level 1), 0: u16 rows of img_levels(nsym) levels
+    u32 pad;
 };
+static inline __host__ __device__ u32 item_levels(u32 nsym, u32 packed) { return packed ? 1u : img_levels(nsym); }
 
 // Per-block record of the decode pipeline.
 struct DecDesc {

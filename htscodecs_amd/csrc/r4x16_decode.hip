@@ -121,6 +121,46 @@ __device__ __forceinline__ u32 lookup_step(const IMG &img, u32 row, u32 look, u3
     return e + (up ? 1u : 0u);                  //  turn it into a select of 0/1 and an or, e being even)
 }
 
+// One lookup + state update on a packed row (r4x16_common.h, "level 1": 10-bit tables, <= 48 symbols).
+// `row` is the LDS address of the context's row, `root` its first dword (read a step ahead), `first` the index of
+// the row's first symbol of non-zero frequency.  Fields sit at bits 0, 11 and 22 of a dword with zero bits at 10 and
+// 21: adding GM = guards - (m | m << 11 | m << 22) leaves guard bit i set exactly when field i >= m (a field plus
+// 1024 minus m stays inside its eleven bits), so two "field < m" tests cost one add, one and, one popcount.
+// Returns the compact symbol index; x becomes freq * (x >> 10) + m - start.
+__device__ __forceinline__ u32 lookup_step_pk(u32 row, u32 root, u32 first, u32 &x)
+{
+    const LImg img0{0u};
+    const u32 GB = 0x00200400u;
+    const u32 m = x & 1023u;
+    const u32 GM = GB - __umul24(m, 0x400801u);
+    // group of twelve: #{L[12], L[24], L[36]} below m
+    const u32 gneg = __popc((root + GM) & GB);                // 2 - #{L[12], L[24] < m}
+    const bool r3 = root < (m << 22);                         // L[36] < m: the top field needs no guard
+    const u32 g = (r3 ? 3u : 2u) - gneg;
+    const u32 ga = row + 4u + 16u * g;
+    const u32 D0 = img0.ld32(ga), D1 = img0.ld32(ga + 4), D2 = img0.ld32(ga + 8), D3 = img0.ld32(ga + 12),
+              D4 = img0.ld32(ga + 16);
+    // dword of three: the low fields of D1, D2, D3 are L[12g + 3], L[12g + 6], L[12g + 9]
+    const bool s0 = (D1 & 1023u) < m, s1 = (D2 & 1023u) < m, s2 = (D3 & 1023u) < m;
+    u32 D = D0, Dn = D1;
+    if (s0) { D = D1; Dn = D2; }
+    if (s1) { D = D2; Dn = D3; }
+    if (s2) { D = D3; Dn = D4; }
+    const u32 q = (u32)s0 + (u32)s1 + (u32)s2;
+    // fields 1, 2 of D and field 0 of Dn, in the same guarded layout
+    const u32 Fu = (D >> 11) + (Dn << 22);
+    const u32 rneg = __popc((Fu + GM) & GB);                  // 2 - r,  r = #{fields 1, 2 of D below m}
+    const u32 r11 = 22u - 11u * rneg;
+    const u32 prev = __builtin_amdgcn_ubfe(D, r11, 10);       // L[c]: end of the symbol before (1023 stands for -1)
+    const u32 cur = __builtin_amdgcn_ubfe(Fu, r11, 10);       // L[c + 1]: end of this symbol
+    const u32 np = ~prev;
+    const u32 fm1 = (cur + np) & 1023u;                       // freq - 1
+    const u32 off = (m + np) & 1023u;                         // m - start
+    const u32 xs = x >> 10;
+    x = __umul24(fm1, xs) + xs + off;                         // freq <= 1024, x >> 10 < 2^22: exact mod 2^32
+    return first + 12u * g + 3u * q + 2u - rneg;
+}
+
 // ---------------------------------------------------------------------------------------------
 // The chain decoder, general form: image and words read straight from global memory.  Used for
 // the small nested streams inside k_dec_front and for images too large for LDS.
@@ -198,6 +238,9 @@ __device__ __forceinline__ u32 chain_decode(IMG img, u32 nsym, gcu8 *words, u32 
 //     wave issues one store per four symbols instead of four.
 // LDS per stream: image, then RING_BYTES.
 // ---------------------------------------------------------------------------------------------
+#ifndef PK_MIN_NSYM
+#define PK_MIN_NSYM 13u      // smaller alphabets keep the u16 rows: their streams' LDS is mostly the word ring anyway
+#endif
 #define RING_BYTES 272u      // 256-byte ring (four 64-byte quarters) + 8-byte mirror of its head (+8 pad)
 #define TRIP_STEPS 8         // steps per loop trip: at most 64 bytes of words, one quarter of the ring
 
@@ -211,7 +254,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     const LImg img0{0u};                                   // row reads: `row` is an absolute LDS address
     const u32 k = lane & 3;
     const u32 mask = (1u << look) - 1;
-    const u32 rows = lds_addr(img_lds) + img_alpha_bytes(nsym), roww = img_row_bytes(nsym);
+    const u32 rows = lds_addr(img_lds) + img_alpha_bytes(nsym), roww = LV == 1 ? pk_row_bytes(nsym) : img_row_bytes(nsym);
     const u32 nwords = words_len >> 1;
     const u32 below = (1u << k) - 1u;                      // quad lanes below this one
     u32 count;
@@ -255,11 +298,12 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     u32 row = rows, cursor = 0, bad = 0, t = 0;
     // root separators of `row`, read as soon as the row is known (one step ahead of their use,
     // so that this LDS round trip runs beside the renormalisation instead of after it)
-    u32x2 root = img0.ld64(row);
+    u32x2 root = LV == 1 ? u32x2{img0.ld32(row), 0u} : img0.ld64(row);
     u32 acc = 0;                                          // order-1: the last (up to) 4 decoded bytes
     u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;                   // order-1: completed dwords not yet stored (a3 newest)
     u32 hdr = 0, hdr_even = 0;                            // order-1: alpha[] word of the symbol decoded last step
     if (ORDER == 1 && count) bad = img.ld16(0);
+    if (LV == 1) hdr = img.ld16(0);                       // packed rows: bits 10.. of the context's alpha word = its `first`
 
     // Four steps per trip: one loop test, one store and one ring check per trip.  A trip in which
     // every stream of the wave is still running on all four chains and has at least 16 words left
@@ -285,7 +329,15 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             RootSpec spec;
             spec.rows = rows; spec.roww = roww;
             const bool speculate = ORDER == 1 && LV == 2;
-            const u32 s = lookup_step<LV>(img0, row, look, mask, xn, LV == 2 ? &root : nullptr, speculate ? &spec : nullptr);
+            u32 s, rown1 = 0, rootn1 = 0;
+            if (LV == 1) {
+                s = lookup_step_pk(row, root.x, hdr >> PK_FIRST_SHIFT, xn);
+                // the next row's root: requested as soon as the symbol is known, used at the top of the next step
+                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(rown1) : "v"(s), "v"(roww), "v"(rows));   // (the compiler's own choice is a 64-bit multiply-add)
+                rootn1 = *(LAS const volatile u32 *)(unsigned long)rown1;
+            } else {
+                s = lookup_step<(LV == 1 ? 2 : LV)>(img0, row, look, mask, xn, LV == 2 ? &root : nullptr, speculate ? &spec : nullptr);
+            }
             const u32 hn = img.ld16(2 * s);               // byte value | ROW_EMPTY of the new context
             u32 byte0 = 0;
             if (ORDER == 0) {
@@ -311,7 +363,10 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
                     }
                 }
                 hdr = live ? hn : hdr;
-                if (speculate) {
+                if (LV == 1) {
+                    row = live ? rown1 : row;
+                    root.x = live ? rootn1 : root.x;
+                } else if (speculate) {
                     const u32 rown = spec.rowE + (spec.up ? roww : 0u);
                     const u32x2 rootn = {spec.up ? spec.rb.x : spec.ra.x, spec.up ? spec.rb.y : spec.ra.y};
                     row = live ? rown : row;
@@ -417,6 +472,7 @@ struct FrontShared {
     u16 rankof[256];   // compact index -> its rank among the alphabet members that have a row entry, or 0xffff
     u32 Fk[256];       // order-1: frequencies of the row being parsed, by that rank
     u32 np;            // number of ranked members
+    u32 first;         // packed rows: index of the row's first symbol of non-zero frequency
     // scalars handed from lane 0 to the wave
     i32 status;
     u32 empty, pos, nsym, bits, look, go;
@@ -516,6 +572,25 @@ __device__ void write_row(u8 *rowp, const FrontShared &S, u32 n, bool empty, u32
     }
 }
 
+// Whole wave: one packed row (r4x16_common.h, "level 1") from S.cum / S.first.  An empty row is all 1023: any
+// lookup lands on its first symbol and the stream is failed through the ROW_EMPTY flag of that context.
+__device__ void write_row_pk(u8 *rowp, const FrontShared &S, u32 n, bool empty, u32 lane)
+{
+    const u32 first = S.first;
+    auto L = [&](u32 j) -> u32 {
+        if (empty || j == 0) return 1023u;
+        const u32 idx = first + j;
+        return idx <= n ? (u32)S.cum[idx] - 1u : 1023u;       // cum[first + 1 ..] >= 1: `first` has a frequency
+    };
+    const u32 ndw = pk_row_bytes(n) / 4u;
+    if (lane < ndw) {
+        u32 v;
+        if (lane == 0) v = L(12) | (L(24) << 11) | (L(36) << 22);
+        else { const u32 i = 3u * (lane - 1u); v = L(i) | (L(i + 1) << 11) | (L(i + 2) << 22); }
+        ((u32 *)rowp)[lane] = v;
+    }
+}
+
 // Order-0 stream front end: src[pos, pos+len) holds table, states, words.
 // rANS_static4x16pr.c:500-561.  All lanes call; on return S.status / S.R / S.words_pos are set
 // and the single-row image is at `img`.
@@ -603,6 +678,7 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
     if (lane == 0) {
         I0->active = 0; I1->active = 0;
         I0->blk = b; I1->blk = b;
+        I0->packed = 0; I1->packed = 0;
         D->status = ST_OK; D->cat_src = 0; D->cat_len = 0; D->osz = 0; D->s1_size = 0;
         D->pack_per = 1; D->rle_meta_len = 0; D->rle_meta = 0;
         i32 st = ST_OK;
@@ -820,7 +896,9 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
     if (H.status != ST_OK) { if (lane == 0) D->status = H.status; return; }
 
     const u32 nsym = S.nsym;
-    const u32 stride = img_row_bytes(nsym);
+    // 10-bit tables of quality-sized alphabets take the packed rows (smaller images: more streams per CU)
+    const bool packed = bits == 10 && nsym >= PK_MIN_NSYM && nsym <= PK_MAX_NSYM;
+    const u32 stride = packed ? pk_row_bytes(nsym) : img_row_bytes(nsym);
     u8 *rows0 = img + img_alpha_bytes(nsym);
 
     // Every row lists a frequency for each member of F0 (decode_freq_d :327-358): rank them once.
@@ -899,7 +977,7 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
             total = __shfl(total, 0);
             u32 sh = 0;
             if (total != (1u << bits)) { u32 size = total; while (size < (1u << bits)) { size *= 2; sh++; } }
-            u32 f[4], sum = 0;
+            u32 f[4], sum = 0, lowest = 4;
             bool bad = false;
 #pragma unroll
             for (u32 c = 0; c < 4; c++) {
@@ -908,6 +986,13 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
                 f[c] = rk != 0xffffu ? S.Fk[rk] << sh : 0u;
                 bad |= f[c] > (1u << bits);
                 sum += f[c];
+                if (f[c] && lowest == 4) lowest = c;
+            }
+            if (packed) {                                              // first symbol of the row with a frequency
+                const u64 has = __ballot(lowest != 4);
+                const int fl = has ? __ffsll((unsigned long long)has) - 1 : 0;
+                const u32 fst = (u32)__shfl((int)(4 * lane + (lowest & 3u)), fl);
+                if (lane == 0) S.first = has ? fst : 0u;
             }
             const bool anybad = wave_any(bad);
             if (anybad) sum = 0;                                       // keeps the scan below from wrapping
@@ -928,7 +1013,11 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
             __syncthreads();
             if (!S.go) break;
         }
-        write_row(rows0 + (u64)ci * stride, S, nsym, S.empty != 0, lane);
+        if (packed) {
+            if (lane == 0 && !S.empty) ((u16 *)img)[ci] |= (u16)(S.first << PK_FIRST_SHIFT);
+            write_row_pk(rows0 + (u64)ci * stride, S, nsym, S.empty != 0, lane);
+        } else
+            write_row(rows0 + (u64)ci * stride, S, nsym, S.empty != 0, lane);
         __syncthreads();
     }
     if (H.status != ST_OK) { if (lane == 0) D->status = H.status; return; }
@@ -951,7 +1040,8 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
             I0->words = (u64)(in + p);
             I0->words_len = end - p;
             I0->out = D->s1; I0->out_sz = s1_size; I0->image = (u64)img;
-            I0->img_bytes = img_bytes(nsym, nsym); I0->nsym = nsym;
+            I0->img_bytes = packed ? pk_img_bytes(nsym) : img_bytes(nsym, nsym); I0->nsym = nsym;
+            I0->packed = packed ? 1u : 0u;
             I0->look = look; I0->order = 1;
             __threadfence();
             I0->active = s1_size != 0;
@@ -1013,11 +1103,12 @@ __global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDes
         u8 *ring = lds + (u64)quad * lds_per_item + (lds_per_item - RING_BYTES);
         // order-0 and order-1 streams may share a wave: run the two loops back to back
         bad = chain_decode_lds<1, LV>(im, nsym, ring, words, words_len, out, out_sz, x0, look, active && order == 1, lane);
-        bad |= chain_decode_lds<0, LV>(im, nsym, ring, words, words_len, out, out_sz, x0, look, active && order == 0, lane);
+        if (LV != 1)                                          // packed rows exist for order-1 streams only
+            bad |= chain_decode_lds<0, (LV == 1 ? 2 : LV)>(im, nsym, ring, words, words_len, out, out_sz, x0, look, active && order == 0, lane);
     } else {
-        GImg im{(gcu8 *)I->image};
-        bad = chain_decode<1, LV>(im, nsym, words, words_len, out, out_sz, x0, look, active && order == 1, lane);
-        bad |= chain_decode<0, LV>(im, nsym, words, words_len, out, out_sz, x0, look, active && order == 0, lane);
+        GImg im{(gcu8 *)I->image};                            // (never level 1: packed images always fit a class)
+        bad = chain_decode<1, (LV == 1 ? 2 : LV)>(im, nsym, words, words_len, out, out_sz, x0, look, active && order == 1, lane);
+        bad |= chain_decode<0, (LV == 1 ? 2 : LV)>(im, nsym, words, words_len, out, out_sz, x0, look, active && order == 0, lane);
     }
     if (active && bad) desc[I->blk].status = ST_CONTEXT;
     __syncthreads();                                       // LDS is reused by the next share
@@ -1213,6 +1304,9 @@ extern "C" void r4x16_launch_dec_front(const BatchArgs *a, const DecWs *ws, int 
 // images at least 21 KB (or the lone 1.3 KB row of a large order-0 alphabet), so the two groups of
 // classes are walked separately.
 static const struct { u32 bytes; int qpw; int lv; } DEC_CLASSES[] = {
+    // packed rows (level 1): 13..36 symbols in rows of up to 56 bytes, 37..48 of up to 72 (46 symbols: 68-byte rows,
+    // 3,496 bytes with alphabet and ring: 3 x 15 streams per CU)
+    {1424, 16, 1}, {2448, 16, 1}, {3344, 16, 1}, {3496, 15, 1}, {3856, 13, 1},
     {656, 16, 2}, {1296, 16, 2}, {2576, 16, 2}, {3856, 16, 2}, {5008, 16, 2}, {5360, 10, 2}, {5392, 15, 2}, {6416, 12, 2},
     // 51..150 symbols, 3 reads: one-row order-0 images, then order-1 images of 9..55 KB (one stream per wave,
     // as many waves per CU as LDS granules allow)
@@ -1281,8 +1375,8 @@ __global__ __launch_bounds__(256) void k_dec_classify(const DecItem *items, int 
         const DecItem *I = &items[i];
         u32 c = CLS_NONE;
         if (I->active) {
-            const u32 need = I->img_bytes + RING_BYTES, lv = img_levels(I->nsym);
-            c = tab.n + (lv - 2u);                             // catch-all of this depth
+            const u32 need = I->img_bytes + RING_BYTES, lv = item_levels(I->nsym, I->packed);
+            c = tab.n + (lv < 2u ? 0u : lv - 2u);               // catch-all of this depth (level 1 always fits a class)
             for (u32 k = 0; k < tab.n; k++)
                 if (tab.lv[k] == lv && need <= tab.bytes[k]) { c = k; break; }   // classes of a depth ascend
             atomicAdd(&local[c], 1u);
@@ -1337,6 +1431,7 @@ extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t 
         r4x16_launch_cls_group(ws->cls, nitems, ws->cls_count, ws->cls_list, s);
     }
     if (r4x16_first_on_device(1u)) {
+        lds_limit((const void *)k_dec_chain<true, 1>, 163840);
         lds_limit((const void *)k_dec_chain<true, 2>, 163840);
         lds_limit((const void *)k_dec_chain<true, 3>, 163840);
         lds_limit((const void *)k_dec_chain<true, 4>, 163840);
@@ -1345,11 +1440,13 @@ extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t 
     static const int force_small = getenv("R4X16_DEC_QPW_SMALL") ? atoi(getenv("R4X16_DEC_QPW_SMALL")) : 0;
     u32 ci = 0;
     for (const auto &c : DEC_CLASSES) {
-        const int qpw = c.lv != 2 ? c.qpw : (force_qpw && c.bytes == 5360) ? force_qpw : (force_small && c.bytes < 5360) ? force_small : c.qpw;
+        static const int force_pk = getenv("R4X16_DEC_QPW_PK") ? atoi(getenv("R4X16_DEC_QPW_PK")) : 0;
+        const int qpw = (c.lv == 1 && force_pk && c.bytes == 3496) ? force_pk :
+                        c.lv != 2 ? c.qpw : (force_qpw && c.bytes == 5360) ? force_qpw : (force_small && c.bytes < 5360) ? force_small : c.qpw;
         const size_t ldsb = (size_t)qpw * c.bytes;
         const int grid = r4x16_resident_grid(ldsb, 1, (nitems + qpw - 1) / qpw);
         void (*kern)(const DecItem *, DecDesc *, const u32 *, const u32 *, int, u32) =
-            c.lv == 2 ? k_dec_chain<true, 2> : c.lv == 3 ? k_dec_chain<true, 3> : k_dec_chain<true, 4>;
+            c.lv == 1 ? k_dec_chain<true, 1> : c.lv == 2 ? k_dec_chain<true, 2> : c.lv == 3 ? k_dec_chain<true, 3> : k_dec_chain<true, 4>;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), ldsb, s, ws->items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci), qpw, c.bytes);
         ci++;
     }
@@ -1358,6 +1455,22 @@ extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t 
     hipLaunchKernelGGL((k_dec_chain<false, 2>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci + 0), 16, 0u);
     hipLaunchKernelGGL((k_dec_chain<false, 3>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci + 1), 16, 0u);
     hipLaunchKernelGGL((k_dec_chain<false, 4>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci + 2), 16, 0u);
+}
+// Streams of one kind that a CU holds at once in the chain decoder (host arithmetic on the class table above).
+extern "C" int r4x16_dec_residency(u32 nsym, int order, u32 bits, int *streams_per_wave, int *waves_per_cu)
+{
+    if (nsym == 0 || nsym > 256) return -1;
+    const bool packed = order == 1 && bits == 10 && nsym >= PK_MIN_NSYM && nsym <= PK_MAX_NSYM;
+    const u32 lv = item_levels(nsym, packed ? 1u : 0u);
+    const u32 need = (packed ? pk_img_bytes(nsym) : img_bytes(nsym, order ? nsym : 1u)) + RING_BYTES;
+    for (const auto &c : DEC_CLASSES) {
+        if ((u32)c.lv != lv || need > c.bytes) continue;
+        *streams_per_wave = c.qpw;
+        *waves_per_cu = resident_per_cu((size_t)c.qpw * c.bytes, 1);
+        return 0;
+    }
+    *streams_per_wave = 16; *waves_per_cu = 8;              // tables in global memory: bounded by wave slots
+    return 0;
 }
 extern "C" void r4x16_launch_dec_back(const BatchArgs *a, const DecWs *ws, int base, int nblk, hipStream_t s)
 {

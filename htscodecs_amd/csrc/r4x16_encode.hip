@@ -1908,6 +1908,22 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
     hipLaunchKernelGGL(k_enc_chain<false>, dim3(grid), dim3(WAVE), 0, s, ws->items, ws->rcptab, ws->dump,
                        (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci), 16, 16, 0u);
 }
+extern "C" int r4x16_enc_residency(u32 nsym, int order, int *streams_per_wave, int *waves_per_cu)
+{
+    if (nsym == 0 || nsym > 256) return -1;
+    const u32 need = (order ? ENC_IMG_IDX + 2u * nsym * (nsym + 1) : ENC_IMG_IDX + 2u * 257u) + ENC_RING_BYTES;
+    for (const u32 bytes : ENC_CLASSES) {
+        if (need > bytes) continue;
+        const int qpw = enc_class_qpw(bytes);
+        int waves = (qpw + 7) / 8;
+        if (waves > 4) waves = 4;
+        *streams_per_wave = (qpw + waves - 1) / waves;
+        *waves_per_cu = waves;                               // one workgroup per CU
+        return qpw;
+    }
+    *streams_per_wave = 16; *waves_per_cu = 8;
+    return 128;
+}
 extern "C" void r4x16_launch_enc_finish(const BatchArgs *a, const EncWs *ws, int base, int nblk, hipStream_t s)
 {
     hipLaunchKernelGGL(k_enc_finish, dim3(nblk), dim3(FINISH_THREADS), 0, s, *a, *ws, base);

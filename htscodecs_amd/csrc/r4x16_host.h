@@ -53,7 +53,7 @@ struct rans4x16_hip_ctx {
     // timing hook
     int timing = 0;
     std::vector<TimedLaunch> timed[2];
-    size_t max_ws = (size_t)48 << 30;       // ceiling for one chunk of blocks (plan_chunk also looks at free memory)
+    size_t max_ws = (size_t)96 << 30;       // ceiling for one chunk of blocks (plan_chunk also looks at free memory)
     // calls on different streams are ordered on the one workspace through this event
     hipEvent_t ws_done = nullptr;
     hipStream_t ws_stream = nullptr;

@@ -108,7 +108,9 @@ int rans4x16_hip_compress_best_batch(rans4x16_hip_ctx *ctx, int n,
  *   d_out_size[i]         : bytes produced (0 on failure);  d_status[i]: code above
  * `order` applies to all blocks unless d_order != NULL (device array of n ints).
  * max_in_size / max_out_cap are host-side upper bounds on the per-block sizes, used only to
- * size the workspace (no device->host read-back happens inside these calls).
+ * size the workspace (no device->host read-back happens inside these calls).  For decode, max_out_cap sizes
+ * the stage buffers of X_PACK / X_RLE blocks only: it may be the largest output of THOSE blocks, 0 if the batch
+ * has none (a transformed block larger than that reports UNSUPPORTED).
  * `stream` is a hipStream_t (NULL = default stream).  The call only enqueues work.
  * X_STRIPE (0x08) is handled by the host entry points, not by *_dev (status UNSUPPORTED).
  * Returns 0 if enqueued, -1 on argument / allocation / launch errors. */
@@ -136,6 +138,13 @@ size_t rans4x16_hip_workspace_bytes(const rans4x16_hip_ctx *ctx);
 void rans4x16_hip_timing(rans4x16_hip_ctx *ctx, int enable);
 int  rans4x16_hip_timing_read(rans4x16_hip_ctx *ctx, int which /*0 enc chain, 1 dec chain*/,
                               double *ms_total, int *launches, int reset);
+
+/* How many streams of one kind the chain kernel of this build keeps resident per compute unit (the unit of
+ * parallelism is the stream): `nsym` symbols in the alphabet, order 0 / 1, table precision `shift`
+ * (10 or 12; ignored for order 0).  Host arithmetic on the kernels' LDS size classes; bench.py reports it next
+ * to the measured step latency, and sizes its batch in whole rounds of it. */
+int rans4x16_hip_residency(rans4x16_hip_ctx *ctx, int decode, unsigned int nsym, int order, unsigned int shift,
+                           int *streams_per_cu, int *lanes_live_per_wave, int *compute_units);
 
 /* Library/ABI version and the gfx target the code object was built for. */
 const char *rans4x16_hip_version(void);
