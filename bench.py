@@ -131,7 +131,7 @@ def chain_figure(torch, dc, kname, kernel_ms, launches_per_step, nblk, bs, spc, 
     per-step latency).  The latency is measured live on ONE workgroup holding its full set of streams with the
     rest of the chip idle (`probe`); the whole-grid figure shows what contention for a CU's LDS and issue slots
     costs on top of it."""
-    clk_khz = torch.cuda.get_device_properties(dc.dev).clock_rate
+    clk_khz = dc.L.rans4x16_hip_device_clock_khz(dc.ctx.h)
     resident = spc * cus
     per_launch = nblk / launches_per_step
     rounds = per_launch / resident

@@ -343,6 +343,13 @@ extern "C" int rans4x16_hip_residency(rans4x16_hip_ctx *c, int decode, unsigned 
     return 0;
 }
 
+extern "C" int rans4x16_hip_device_clock_khz(rans4x16_hip_ctx *c)
+{
+    int khz = 0;
+    if (!c || hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, c->device) != hipSuccess) return -1;
+    return khz;
+}
+
 extern "C" int rans4x16_hip_compress_batch(rans4x16_hip_ctx *c, int n,
                                            const unsigned char *const *in, const unsigned int *in_size,
                                            unsigned char *const *out, unsigned int *out_size,

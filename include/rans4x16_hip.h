@@ -146,6 +146,9 @@ int  rans4x16_hip_timing_read(rans4x16_hip_ctx *ctx, int which /*0 enc chain, 1 
 int rans4x16_hip_residency(rans4x16_hip_ctx *ctx, int decode, unsigned int nsym, int order, unsigned int shift,
                            int *streams_per_cu, int *lanes_live_per_wave, int *compute_units);
 
+/* Peak shader clock of the context's device in kHz (for cycles-per-step figures), -1 on error. */
+int rans4x16_hip_device_clock_khz(rans4x16_hip_ctx *ctx);
+
 /* Library/ABI version and the gfx target the code object was built for. */
 const char *rans4x16_hip_version(void);
 

@@ -8,7 +8,7 @@
  * includes, links or calls anything in this directory.
  *
  * Parity pin: tests/test_oracle.py checks this restatement against all 24 committed
- * reference fixtures (tests/golden/r4x16/*), the varint known-answer tables and the
+ * reference fixtures (tests/golden/r4x16/), the varint known-answer tables and the
  * generated edge vectors in tests/golden/edge/ (made by oracle/make_golden.py from the
  * real reference compiled into oracle/_ref).
  *
@@ -55,6 +55,10 @@ int orc_compress_many(int n, unsigned char *const *in, const unsigned int *in_si
                       unsigned char *const *out, unsigned int *out_size, int order, int nthreads);
 int orc_uncompress_many(int n, unsigned char *const *in, const unsigned int *in_size,
                         unsigned char *const *out, unsigned int *out_size, int nthreads);
+
+/* rANS 4x8 (rans4x8_oracle.c): htscodecs/rANS_static.h:41-44 with an orc8_ prefix; malloc'd results. */
+unsigned char *orc8_rans_compress(unsigned char *in, unsigned int in_size, unsigned int *out_size, int order);
+unsigned char *orc8_rans_uncompress(unsigned char *in, unsigned int in_size, unsigned int *out_size);
 
 #ifdef __cplusplus
 }
