@@ -156,28 +156,49 @@ def chain_figure(torch, dc, kname, kernel_ms, launches_per_step, nblk, bs, spc, 
     return out
 
 
-def host_path(H, name, bs, order, nblk=2048):
-    """PCIe-inclusive rate through rans4x16_hip_{compress,uncompress}_batch (host buffers in, host buffers out):
-    a bounded sample of the same workload, one warm call (contexts, pinned buffers) and one timed call each way.
+def host_path(H, name, bs, order, nblk=3072):
+    """PCIe-inclusive rate through rans4x16_hip_{compress,uncompress}_batch, called as a C program would call them
+    (ctypes straight onto the C ABI: pageable host arenas, pointer / size arrays, no per-block Python work):
+    a bounded sample of the same workload - the shape of the reference's `-t` loop
+    (tests/rANS_static4x16pr_test.c:191-206) with the serial loop replaced by the batch calls.  One warm pass
+    (contexts, pinned bounce buffers, arenas), then the best of two timed passes each way.
     Reported beside `value`, never as `value`."""
     import datagen
-    blocks = [datagen.tile(name if name != "mixed" else ["q4", "q8", "q40+dir"][b % 3], bs, b).tobytes() for b in range(nblk)]
-    orders = [order] * nblk
-    H.compress_batch(blocks[:64], orders[:64])
-    t0 = time.perf_counter()
-    enc, st = H.compress_batch(blocks, orders)
-    t1 = time.perf_counter()
-    assert all(x == 0 for x in st)
-    H.uncompress_batch(enc[:64], [bs] * 64)
-    t2 = time.perf_counter()
-    dec, st = H.uncompress_batch(enc, [bs] * nblk)
-    t3 = time.perf_counter()
-    assert all(x == 0 for x in st) and dec[0] == blocks[0] and dec[-1] == blocks[-1]
+    from htscodecs_amd import codec
+    L = H.load()
+    ctx = codec._thread_ctx()
+    names = ["q4", "q8", "q40+dir"] if name == "mixed" else [name]
+    src = np.empty(nblk * bs, dtype=np.uint8)
+    for b in range(nblk):
+        src[b * bs:(b + 1) * bs] = datagen.tile(names[b % len(names)], bs, b)
+    cap = L.rans_compress_bound_4x16(bs, order)
+    comp = np.ones(nblk * cap, dtype=np.uint8)             # (ones: every page is touched before the clock starts)
+    back = np.ones(nblk * bs, dtype=np.uint8)
+    vp = lambda a, stride: (C.c_void_p * nblk)(*[a.ctypes.data + i * stride for i in range(nblk)])
+    in_p, comp_p, back_p = vp(src, bs), vp(comp, cap), vp(back, bs)
+    in_sz = (C.c_uint * nblk)(*([bs] * nblk))
+    ords = (C.c_int * nblk)(*([order] * nblk))
+    status = (C.c_int * nblk)()
+    t_enc, t_dec = [], []
+    for rep in range(3):
+        comp_sz = (C.c_uint * nblk)(*([cap] * nblk))
+        t0 = time.perf_counter()
+        rc = L.rans4x16_hip_compress_batch(ctx.h, nblk, in_p, in_sz, comp_p, comp_sz, ords, status)
+        t1 = time.perf_counter()
+        assert rc == 0, ctx.error()
+        back_sz = (C.c_uint * nblk)(*([bs] * nblk))
+        t2 = time.perf_counter()
+        rc = L.rans4x16_hip_uncompress_batch(ctx.h, nblk, comp_p, comp_sz, back_p, back_sz, status)
+        t3 = time.perf_counter()
+        assert rc == 0, ctx.error()
+        if rep:
+            t_enc.append(t1 - t0); t_dec.append(t3 - t2)
+    assert (back == src).all(), "host path round trip mismatch"
     tot = nblk * bs
-    return {"enc_MBps": round(tot / (t1 - t0) / 1e6, 1), "dec_MBps": round(tot / (t3 - t2) / 1e6, 1),
-            "value": round(tot / ((t1 - t0) + (t3 - t2)) / 1e6, 1), "unit": "MB/s",
-            "sample": f"{nblk} x {bs} B {name} blocks, order {order}, pageable host buffers through the C batch calls "
-                      f"(includes the Python marshalling of {nblk} buffers)"}
+    return {"enc_MBps": round(tot / min(t_enc) / 1e6, 1), "dec_MBps": round(tot / min(t_dec) / 1e6, 1),
+            "value": round(tot / (min(t_enc) + min(t_dec)) / 1e6, 1), "unit": "MB/s",
+            "sample": f"{nblk} x {bs} B {name} blocks, order {order}: pageable host buffers in, pageable host buffers out, "
+                      f"through rans4x16_hip_compress_batch / rans4x16_hip_uncompress_batch; best of two passes after a warm one"}
 
 
 def spawn_ranks(n):
