@@ -195,8 +195,18 @@ struct EncItem {
     u32 blk;
     u32 ns;          // symbols per image row (a row is ns+1 u16)
     u32 img_bytes;   // bytes of the image (what must sit in LDS)
-    u32 pad[2];
+    u32 packed;      // 1: rows are 11-bit bit streams (below), 0: u16 rows
+    u32 pad;
 };
+// Packed encoder rows: order-1 streams with 10-bit tables and 20..64 symbols (the quality alphabets).  Row r is a
+// bit stream of 11-bit entries cum[r][0..ns] (11 bits hold the total 1024), entry j at bit 11 j; W = ceil(11 (ns + 1)
+// / 32) dwords per row.  A symbol's (start, next) pair is 22 bits out of two adjacent dwords (one ds_read2 at a
+// 4-byte aligned address and a funnel shift).  46 symbols: 68-byte rows instead of 94, 3.5 KB per stream instead
+// of 4.7: 45 streams per CU - the decoder's count, so that a batch is a whole number of rounds for both.
+#define ENC_PK_MIN_NS 20u
+#define ENC_PK_MAX_NS 64u
+static inline __host__ __device__ u32 enc_pk_row_dwords(u32 ns) { return (11u * (ns + 1u) + 31u) / 32u; }
+static inline __host__ __device__ u32 enc_pk_img_bytes(u32 ns) { return ENC_IMG_IDX + 4u * ns * enc_pk_row_dwords(ns) + 4u; }
 
 // Per-block record of the encode pipeline.
 struct EncDesc {

@@ -286,19 +286,35 @@ struct EncOut {
     }
 };
 
+// PK: packed rows (r4x16_common.h) and a reciprocal table of the 1,025 frequencies a 10-bit table can hold.
+template <bool PK>
 __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, u8 *ring, const u32 *lrcp, gcu8 *data, u32 n, u32 ns,
                                                    u32 bits, gcu8 *safe, gu8 *scratch_end, gu8 *dump, bool active, u32 lane)
 {
     const u32 k = lane & 3;
     const u8 *idx = img_lds;
     const u8 *cumb = img_lds + ENC_IMG_IDX;
-    const u32 rs = ns + 1;                                // u16 per context row
-    // start | next << 16 of symbol si in context ci: one dword read at a 2-byte aligned LDS address
-    auto pair = [&](u32 ci, u32 si) -> u32 { return *(LAS const u32 *)(cumb + 2u * (__umul24(ci, rs) + si)); };
-    auto rcpof = [&](u32 pk) -> u32 { const u32 f = pk >> 16; return lrcp[f < RCPTAB_ENTRIES - 1u ? f : RCPTAB_ENTRIES - 1u]; };   // (clamp: idle lanes hold garbage)
-    // start | next << 16  ->  start | freq << 16 (the empty asm keeps this a shift and a subtract
-    // instead of a quarter-rate multiply by 0xFFFF0001)
-    auto topk = [&](u32 p) -> u32 { u32 hi = p << 16; asm("" : "+v"(hi)); return p - hi; };
+    const u32 rs = PK ? 4u * enc_pk_row_dwords(ns) : ns + 1;       // bytes (packed) / u16 entries per context row
+    const u32 cumb_lds = (u32)(unsigned long)(LAS const u8 *)cumb;
+    // the (start, next) pair of symbol si in context ci.  u16 rows: start | next << 16, one dword read at a 2-byte
+    // aligned LDS address.  Packed rows: 22 bits at bit 11 si of the row, from two aligned dwords and a funnel shift.
+    auto pair = [&](u32 ci, u32 si) -> u32 {
+        if (PK) {
+            const u32 b = __umul24(si, 11u);
+            const u32 a = cumb_lds + __umul24(ci, rs) + ((b >> 5) << 2);
+            const u32x2 d = *(LAS const u32x2_a4 *)(unsigned long)a;
+            return __builtin_amdgcn_alignbit(d.y, d.x, b);                   // (the shift uses the low five bits of b)
+        }
+        return *(LAS const u32 *)(cumb + 2u * (__umul24(ci, rs) + si));
+    };
+    const u32 rcp_last = PK ? 1024u : RCPTAB_ENTRIES - 1u;
+    auto rcpof = [&](u32 pk) -> u32 { const u32 f = pk >> 16; return lrcp[f < rcp_last ? f : rcp_last]; };   // (clamp: idle lanes hold garbage)
+    // pair -> start | freq << 16.  u16 rows: a shift and a subtract (the empty asm keeps it from becoming a
+    // quarter-rate multiply by 0xFFFF0001); packed rows: two field extractions, a subtract, a shift-or
+    auto topk = [&](u32 p) -> u32 {
+        if (PK) { const u32 st = p & 2047u; return st | ((__builtin_amdgcn_ubfe(p, 11, 11) - st) << 16); }
+        u32 hi = p << 16; asm("" : "+v"(hi)); return p - hi;
+    };
     auto fetch = [&](u32 ci, u32 si) -> u32x2 {           // {rcp, start | freq << 16}
         const u32 pk = topk(pair(ci, si));
         u32x2 r = {rcpof(pk), pk};
@@ -1256,7 +1272,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
     if (tid == 0) {
         H.run = 0;
         ws.stat[b].run = 0;
-        I0->active = 0; I1->active = 0; I0->pay_len = 0; I1->pay_len = 0;
+        I0->active = 0; I1->active = 0; I0->pay_len = 0; I1->pay_len = 0; I0->packed = 0; I1->packed = 0;
         I0->blk = b; I1->blk = b;
         D->cat = 0; D->rle_on = 0; D->tab_len = 0; D->hdr_len = 0; D->dlen = 0; D->tab = (u64)tab;
         i32 st = ST_OK;
@@ -1580,6 +1596,8 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
     // ---- encoder image: scale each row up to 1<<bits (:756) and build entries (:759-762) -----------
     for (u32 j = lane; j < 256; j += WAVE) img[j] = S.present[j] ? S.idx_of[j] : (u8)0;
     u16 *cumimg = (u16 *)(img + ENC_IMG_IDX);            // cum[r][0..ns]
+    const bool packed = bits == 10 && ns >= ENC_PK_MIN_NS && ns <= ENC_PK_MAX_NS;
+    const u32 W = enc_pk_row_dwords(ns);
     for (u32 r = 0; r < ns; r++) {
         u32 sh = 0;
         const u32 tgt = (u32)S.S[r];
@@ -1589,11 +1607,25 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
             const u32 j = jb + lane;
             const u32 f = (j < ns) ? (Fp[r * ns + j] << sh) : 0u;
             const u32 incl = wave_incl_scan(f, lane);
-            if (j < ns) cumimg[r * (ns + 1) + j] = (u16)(carry + incl - f);
+            if (j < ns) { if (packed) S.F[j] = carry + incl - f; else cumimg[r * (ns + 1) + j] = (u16)(carry + incl - f); }
             carry += __shfl(incl, WAVE - 1);
         }
-        if (lane == 0) cumimg[r * (ns + 1) + ns] = (u16)carry;
+        if (!packed) { if (lane == 0) cumimg[r * (ns + 1) + ns] = (u16)carry; continue; }
+        // packed row (r4x16_common.h): entry j at bit 11 j; lane d gathers the entries that touch dword d
+        if (lane == 0) S.F[ns] = carry;
+        wsync();
+        if (lane < W) {
+            u32 word = 0;
+            for (u32 j = (32u * lane) / 11u; j <= ns && 11u * j < 32u * lane + 32u; j++) {
+                const u32 e = S.F[j];
+                const int at = (int)(11u * j) - (int)(32u * lane);
+                word |= at >= 0 ? e << at : e >> -at;
+            }
+            ((u32 *)(img + ENC_IMG_IDX))[r * W + lane] = word;
+        }
+        wsync();
     }
+    if (packed && lane == 0) ((u32 *)(img + ENC_IMG_IDX))[ns * W] = 0;      // the pair window's second dword past the last row
     __threadfence();
     wsync();
 
@@ -1661,7 +1693,8 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
     if (lane == 0) {
         D->tab_len = final_len;
         I0->data = (u64)data; I0->n = n; I0->image = (u64)img; I0->bits = bits; I0->order = 1;
-        I0->ns = ns; I0->img_bytes = ENC_IMG_IDX + 2u * ns * (ns + 1);
+        I0->ns = ns; I0->img_bytes = packed ? enc_pk_img_bytes(ns) : ENC_IMG_IDX + 2u * ns * (ns + 1);
+        I0->packed = packed ? 1u : 0u;
         I0->scratch_end = (u64)scratch_end;
         __threadfence();
         I0->active = 1;
@@ -1673,7 +1706,9 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
 // ---------------------------------------------------------------------------------------------
 // LDS_IMG: a workgroup of up to four waves shares one LDS copy of the reciprocal table; each quad
 // owns lds_per_item bytes (image, then the word ring).  Waves never meet again after the set-up.
-template <bool LDS_IMG>
+// PK: the class holds packed order-1 streams only (10-bit tables): a 1,025-entry reciprocal table suffices.
+#define ENC_LRCP_PK_BYTES 4112u      // 1,025 dwords, padded to 16
+template <bool LDS_IMG, bool PK>
 __global__ __launch_bounds__(256) void k_enc_chain(EncItem *items, const u32 *rcptab_, u8 *dump_, const u32 *list, const u32 *count,
                                                    int qpw, int spw, u32 lds_per_item)
 {
@@ -1715,8 +1750,8 @@ __global__ __launch_bounds__(256) void k_enc_chain(EncItem *items, const u32 *rc
     u32 pay;
     if (LDS_IMG) {
         u32 *lrcp = (u32 *)lds;
-        u8 *slots = lds + ENC_LRCP_BYTES;
-        for (u32 j = tid; j < RCPTAB_ENTRIES; j += blockDim.x) lrcp[j] = rcptab[j];
+        u8 *slots = lds + (PK ? ENC_LRCP_PK_BYTES : ENC_LRCP_BYTES);
+        for (u32 j = tid; j < (PK ? 1025u : RCPTAB_ENTRIES); j += blockDim.x) lrcp[j] = rcptab[j];
         // each wave copies the images of its own quads (16-byte pieces)
         const u64 my_img = active ? I->image : 0ull;
         const u32 wq0 = (tid >> 6) * (u32)spw;             // first stream slot of this wave
@@ -1734,8 +1769,8 @@ __global__ __launch_bounds__(256) void k_enc_chain(EncItem *items, const u32 *rc
         const u8 *im = slots + (u64)slot * lds_per_item;
         u8 *ring = slots + (u64)slot * lds_per_item + (lds_per_item - ENC_RING_BYTES);
         gu8 *dump = to_global(dump_) + 16u * ((blockIdx.x * blockDim.x + tid) & (ENC_DUMP_BYTES / 16u - 1u));
-        pay = chain_encode_o1_lds(im, ring, lrcp, data, n, ns, bits, (gcu8 *)rcptab, send, dump, order == 1, lane);
-        pay |= chain_encode_o0_pipe(im, ring, lrcp, data, n, bits, (gcu8 *)rcptab, send, dump, order == 0, lane);
+        pay = chain_encode_o1_lds<PK>(im, ring, lrcp, data, n, ns, bits, (gcu8 *)rcptab, send, dump, order == 1, lane);
+        if (!PK) pay |= chain_encode_o0_pipe(im, ring, lrcp, data, n, bits, (gcu8 *)rcptab, send, dump, order == 0, lane);
     } else {
         gcu8 *im = (gcu8 *)I->image;
         pay = chain_encode<1>(data, n, im, ns, bits, rcptab, send, order == 1, lane);
@@ -1833,9 +1868,14 @@ extern "C" void r4x16_launch_enc_front(const BatchArgs *a, const EncWs *ws, int 
 // (sizes are 16 mod 128: consecutive streams start four LDS banks apart, so that the eight streams of a
 // 32-lane access group do not all hit the same bank when they touch the same offset)
 static const u32 ENC_CLASSES[] = {656, 1296, 2576, 4752, 6416, 12816, 33296, 73616, 147344};
-static int enc_class_qpw(u32 bytes)
+// packed rows (20..64 symbols, 10-bit tables): 46 symbols need 3,532 bytes -> 45 streams per CU beside the small
+// reciprocal table (3,536 is 80 mod 128: consecutive streams start 20 banks apart)
+static const u32 ENC_PK_CLASSES[] = {1168, 2064, 2832, 3536, 3728, 4752, 6416};
+#define ENC_NCLS    ((u32)(sizeof(ENC_CLASSES) / sizeof(ENC_CLASSES[0])))
+#define ENC_PK_NCLS ((u32)(sizeof(ENC_PK_CLASSES) / sizeof(ENC_PK_CLASSES[0])))
+static int enc_class_qpw(u32 bytes, bool pk = false)
 {
-    const u32 room = 163840u - ENC_LRCP_BYTES;
+    const u32 room = 163840u - (pk ? ENC_LRCP_PK_BYTES : ENC_LRCP_BYTES);
     const u32 fit = room / bytes;
     static const int cap = getenv("R4X16_ENC_QPW_CAP") ? atoi(getenv("R4X16_ENC_QPW_CAP")) : 64;   // tuning aid
     return (int)(fit > (u32)cap ? (u32)cap : fit);
@@ -1846,7 +1886,7 @@ extern "C" void r4x16_launch_enc_tables(const BatchArgs *a, const EncWs *ws, int
 }
 extern "C" int r4x16_resident_grid(size_t lds_bytes, int waves_per_wg, int wanted);      // r4x16_decode.hip
 extern "C" int r4x16_cu_count(void);
-struct EncClassTab { u32 n; u32 bytes[CLS_MAX]; };
+struct EncClassTab { u32 n; u32 bytes[CLS_MAX]; u32 pk[CLS_MAX]; };     // classes: u16 images, then packed ones
 __global__ __launch_bounds__(256) void k_enc_classify(const EncItem *items, int nitems, EncClassTab tab, u32 *cls, u32 *count)
 {
     __shared__ u32 local[CLS_MAX];
@@ -1856,9 +1896,9 @@ __global__ __launch_bounds__(256) void k_enc_classify(const EncItem *items, int 
     if (i < nitems) {
         u32 c = CLS_NONE;
         if (items[i].active) {
-            const u32 need = items[i].img_bytes + ENC_RING_BYTES;
-            c = tab.n;                                         // images too large for LDS
-            for (u32 k = 0; k < tab.n; k++) if (need <= tab.bytes[k]) { c = k; break; }
+            const u32 need = items[i].img_bytes + ENC_RING_BYTES, pk = items[i].packed;
+            c = tab.n;                                         // images too large for LDS (never a packed one)
+            for (u32 k = 0; k < tab.n; k++) if (tab.pk[k] == pk && need <= tab.bytes[k]) { c = k; break; }
             atomicAdd(&local[c], 1u);
         }
         cls[i] = c;
@@ -1873,18 +1913,24 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
     {
         EncClassTab tab;
         tab.n = 0;
-        for (const u32 bytes : ENC_CLASSES) tab.bytes[tab.n++] = bytes;
+        for (const u32 bytes : ENC_CLASSES) { tab.pk[tab.n] = 0; tab.bytes[tab.n++] = bytes; }
+        for (const u32 bytes : ENC_PK_CLASSES) { tab.pk[tab.n] = 1; tab.bytes[tab.n++] = bytes; }
         r4x16_launch_cls_zero(ws->cls_count, s);
         hipLaunchKernelGGL(k_enc_classify, dim3((nitems + 255) / 256), dim3(256), 0, s, (const EncItem *)ws->items, nitems, tab, ws->cls, ws->cls_count);
         r4x16_launch_cls_group(ws->cls, nitems, ws->cls_count, ws->cls_list, s);
     }
-    if (r4x16_first_on_device(4u))
-        (void)hipFuncSetAttribute((const void *)k_enc_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    if (r4x16_first_on_device(4u)) {
+        (void)hipFuncSetAttribute((const void *)k_enc_chain<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        (void)hipFuncSetAttribute((const void *)k_enc_chain<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    }
     u32 ci = 0;
     static const int force_qpw = getenv("R4X16_ENC_QPW") ? atoi(getenv("R4X16_ENC_QPW")) : 0;   // tuning aids
     static const int force_waves = getenv("R4X16_ENC_WAVES") ? atoi(getenv("R4X16_ENC_WAVES")) : 0;
-    for (const u32 bytes : ENC_CLASSES) {
-        int qpw = (force_qpw && bytes == 4752) ? force_qpw : enc_class_qpw(bytes);
+    for (u32 cls = 0; cls < ENC_NCLS + ENC_PK_NCLS; cls++) {
+        const bool pk = cls >= ENC_NCLS;
+        const u32 bytes = pk ? ENC_PK_CLASSES[cls - ENC_NCLS] : ENC_CLASSES[cls];
+        const u32 tuned = pk ? 3536u : 4752u;                // the class of the 46-symbol quality tables
+        int qpw = (force_qpw && bytes == tuned) ? force_qpw : enc_class_qpw(bytes, pk);
         // One workgroup per CU is the best shape (measured: 30 streams per CU as 1 x 32 beat 2 x 16 by a
         // third and half-filled 64s by a fifth), so a batch that cannot fill the class's workgroups on
         // every CU gets smaller ones (items [0, n/2) are the payload streams).
@@ -1896,25 +1942,31 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
         }
         int waves = (qpw + 7) / 8;                         // about eight streams per wave measured best (fewer
         if (waves > 4) waves = 4;                          // lanes per LDS access, one wave per SIMD)
-        if (force_waves && bytes == 4752) waves = force_waves;
+        if (force_waves && bytes == tuned) waves = force_waves;
         const int spw = (qpw + waves - 1) / waves;
-        const size_t ldsb = (size_t)ENC_LRCP_BYTES + (size_t)qpw * bytes;
+        const size_t ldsb = (size_t)(pk ? ENC_LRCP_PK_BYTES : ENC_LRCP_BYTES) + (size_t)qpw * bytes;
         const int grid = r4x16_resident_grid(ldsb, waves, (nitems + qpw - 1) / qpw);
-        hipLaunchKernelGGL(k_enc_chain<true>, dim3(grid), dim3(WAVE * waves), ldsb, s,
+        void (*kern)(EncItem *, const u32 *, u8 *, const u32 *, const u32 *, int, int, u32) =
+            pk ? k_enc_chain<true, true> : k_enc_chain<true, false>;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE * waves), ldsb, s,
                            ws->items, ws->rcptab, ws->dump, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci), qpw, spw, bytes);
         ci++;
     }
     const int grid = (nitems + 15) / 16;
-    hipLaunchKernelGGL(k_enc_chain<false>, dim3(grid), dim3(WAVE), 0, s, ws->items, ws->rcptab, ws->dump,
+    hipLaunchKernelGGL((k_enc_chain<false, false>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->rcptab, ws->dump,
                        (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci), 16, 16, 0u);
 }
 extern "C" int r4x16_enc_residency(u32 nsym, int order, int *streams_per_wave, int *waves_per_cu)
 {
     if (nsym == 0 || nsym > 256) return -1;
-    const u32 need = (order ? ENC_IMG_IDX + 2u * nsym * (nsym + 1) : ENC_IMG_IDX + 2u * 257u) + ENC_RING_BYTES;
-    for (const u32 bytes : ENC_CLASSES) {
+    // (the packed rows need a 10-bit table: what every BASELINE text chooses; a 12-bit stream keeps the u16 rows)
+    const bool pk = order && nsym >= ENC_PK_MIN_NS && nsym <= ENC_PK_MAX_NS;
+    const u32 need = (pk ? enc_pk_img_bytes(nsym) : order ? ENC_IMG_IDX + 2u * nsym * (nsym + 1) : ENC_IMG_IDX + 2u * 257u) + ENC_RING_BYTES;
+    for (u32 cls = 0; cls < ENC_NCLS + ENC_PK_NCLS; cls++) {
+        if ((cls >= ENC_NCLS) != pk) continue;
+        const u32 bytes = pk ? ENC_PK_CLASSES[cls - ENC_NCLS] : ENC_CLASSES[cls];
         if (need > bytes) continue;
-        const int qpw = enc_class_qpw(bytes);
+        const int qpw = enc_class_qpw(bytes, pk);
         int waves = (qpw + 7) / 8;
         if (waves > 4) waves = 4;
         *streams_per_wave = (qpw + waves - 1) / waves;

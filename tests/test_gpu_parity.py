@@ -343,7 +343,10 @@ def test_alphabet_sizes_at_the_tree_depth_boundaries(H, oracle):
     orders, uniform and skewed, must round-trip bit-exactly."""
     rs = np.random.RandomState(5150)
     datas, orders = [], []
-    for nsym in (1, 2, 9, 10, 11, 19, 20, 21, 39, 40, 41, 49, 50, 51, 52, 89, 90, 91, 119, 120, 121, 149, 150, 151, 152, 200, 255, 256):
+    # (round 2: plus the packed-row boundaries - decode rows of 1..4 groups of twelve for 13..48 symbols, encode bit
+    #  streams for 20..64 symbols; order-1 alphabets gain byte 0, hence the neighbours on both sides)
+    for nsym in (1, 2, 9, 10, 11, 12, 13, 14, 19, 20, 21, 23, 24, 25, 35, 36, 37, 39, 40, 41, 46, 47, 48, 49, 50, 51, 52, 62, 63, 64, 65,
+                 89, 90, 91, 119, 120, 121, 149, 150, 151, 152, 200, 255, 256):
         for order in (0, 1):
             n = 30000 + int(rs.randint(0, 7))
             datas.append(datagen.rand(n, int(rs.randint(1, 1 << 30)), nsym, int(rs.randint(0, 257 - nsym))).tobytes())
