@@ -1,14 +1,21 @@
 #!/bin/bash
-# Runs on the GPU box (through gpurun): the bench line, the rocprofv3 kernel statistics of the same command and
-# the two PMC passes for HBM traffic; everything lands under gpurun_out/refresh/.  Post-process with
-# tools/summarize_trace.py and tools/pmc_traffic.py, then copy the summaries into profiles/.
+# Runs on the GPU box (through gpurun): the bench line, the rocprofv3 kernel statistics of the same command, the two
+# PMC passes for HBM traffic and two SQ passes for the chain kernels' issue / LDS figures; everything lands under
+# gpurun_out/refresh/.  Afterwards, in the container: python3 tools/make_profiles.py r02  (summaries -> profiles/).
 set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/refresh   # (delete the local copy first: gpurun merges new files into it)
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 $R/bench.py --no-cpu > $O/bench_prof.json 2> $O/bench_prof.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu > $O/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write --output-format csv -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu > $O/write.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 $R/bench.py --no-cpu --no-host > $O/bench_prof.json 2> $O/bench_prof.err
+P="--steps 1 --warmup 1 --no-cpu --no-host"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch --output-format csv -- python3 $R/bench.py $P > $O/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write --output-format csv -- python3 $R/bench.py $P > $O/write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY \
+    -d $O/sq1 --output-format csv -- python3 $R/bench.py $P > $O/sq1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR \
+    -d $O/sq2 --output-format csv -- python3 $R/bench.py $P > $O/sq2.log 2>&1 || echo "sq2 pass failed (counter set not available)"
+# keep the merge small: only the CSVs the summaries need
+find $O -name "*agent_info.csv" -delete
 tail -n 1 $O/bench.json
