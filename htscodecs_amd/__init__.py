@@ -12,10 +12,12 @@ from .lib import load, LibraryNotBuilt, STATUS_NAMES  # noqa: F401
 from .codec import (  # noqa: F401
     rans_compress_bound_4x16, rans_compress_4x16, rans_uncompress_4x16,
     compress_batch, compress_best_batch, uncompress_batch, DeviceCodec, MultiCodec,
+    rans_compress, rans_uncompress, compress_batch_4x8, uncompress_batch_4x8,
 )
 
 __all__ = [
     "load", "LibraryNotBuilt", "STATUS_NAMES",
     "rans_compress_bound_4x16", "rans_compress_4x16", "rans_uncompress_4x16",
     "compress_batch", "compress_best_batch", "uncompress_batch", "DeviceCodec", "MultiCodec",
+    "rans_compress", "rans_uncompress", "compress_batch_4x8", "uncompress_batch_4x8",
 ]

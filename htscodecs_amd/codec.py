@@ -45,6 +45,66 @@ def rans_uncompress_4x16(comp, out_size=None):
     return out[:n.value].tobytes() if r else None
 
 
+# ---- rANS 4x8 (include/rans4x8_hip.h; htscodecs/rANS_static.h:41-44) ---------------------------------------
+
+def rans_compress(data, order):
+    """bytes -> rANS 4x8 stream, or None (C: NULL).  rANS_static.c:927."""
+    L = _lib.load()
+    src = np.frombuffer(bytes(data), dtype=np.uint8)
+    n = C.c_uint(0)
+    dummy = np.zeros(1, dtype=np.uint8)
+    p = L.rans_compress(src.ctypes.data if len(src) else dummy.ctypes.data, len(src), C.byref(n), order)
+    if not p:
+        return None
+    res = C.string_at(p, n.value)
+    C.CDLL(None).free(C.c_void_p(p))
+    return res
+
+
+def rans_uncompress(comp):
+    """rANS 4x8 stream -> bytes, or None.  rANS_static.c:934."""
+    L = _lib.load()
+    src = np.frombuffer(bytes(comp) + bytes(16), dtype=np.uint8)
+    n = C.c_uint(0)
+    p = L.rans_uncompress(src.ctypes.data, len(comp), C.byref(n))
+    if not p:
+        return None
+    res = C.string_at(p, n.value)
+    C.CDLL(None).free(C.c_void_p(p))
+    return res
+
+
+def _host_batch8(blocks, decode, orders=None, caps=None):
+    ctx = _thread_ctx()
+    L = ctx.L
+    n = len(blocks)
+    srcs = [np.frombuffer(bytes(b), dtype=np.uint8) for b in blocks]
+    capv = list(caps) if decode else [L.rans4x8_hip_compress_bound(len(s)) for s in srcs]
+    outs = [np.empty(max(c, 1), dtype=np.uint8) for c in capv]
+    dummy = np.zeros(1, dtype=np.uint8)
+    in_p = (C.c_void_p * n)(*[(s.ctypes.data if len(s) else dummy.ctypes.data) for s in srcs])
+    out_p = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    in_sz = (C.c_uint * n)(*[len(s) for s in srcs])
+    out_sz = (C.c_uint * n)(*capv)
+    status = (C.c_int * n)()
+    if decode:
+        rc = L.rans4x8_hip_uncompress_batch(ctx.h, n, in_p, in_sz, out_p, out_sz, status)
+    else:
+        ords = (C.c_int * n)(*orders)
+        rc = L.rans4x8_hip_compress_batch(ctx.h, n, in_p, in_sz, out_p, out_sz, ords, status)
+    if rc < 0:
+        raise RuntimeError("rans4x8 batch call failed: " + ctx.error())
+    return [outs[i][:out_sz[i]].tobytes() if status[i] == 0 else None for i in range(n)], list(status)
+
+
+def compress_batch_4x8(blocks, orders):
+    return _host_batch8(blocks, False, orders=orders)
+
+
+def uncompress_batch_4x8(blocks, caps):
+    return _host_batch8(blocks, True, caps=caps)
+
+
 class _Ctx:
     def __init__(self, device=-1):
         self.L = _lib.load()

@@ -450,3 +450,189 @@ extern "C" unsigned char *rans_uncompress_4x16(unsigned char *in, unsigned int i
 {
     return rans_uncompress_to_4x16(in, in_size, nullptr, out_size);
 }
+
+// =============================================================================================
+// rANS 4x8 (CRAM 3.0): include/rans4x8_hip.h.  Same context, same workspace; kernels at the end of
+// r4x16_encode.hip / r4x16_decode.hip.
+// =============================================================================================
+extern "C" size_t r4x8_dec_ws_bytes(size_t nblk);
+extern "C" void r4x8_launch_decode(const BatchArgs *, u8 *, int, int, hipStream_t);
+extern "C" void r4x8_launch_encode(const BatchArgs *, const EncWs *, int, int, hipStream_t);
+extern "C" u32 r4x8_compress_bound(u32);
+
+extern "C" unsigned int rans4x8_hip_compress_bound(unsigned int size) { return r4x8_compress_bound(size); }
+
+extern "C" int rans4x8_hip_compress_dev(rans4x16_hip_ctx *c, int n,
+                                        const unsigned char *d_in, const uint64_t *d_in_off, const uint32_t *d_in_size,
+                                        unsigned char *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap,
+                                        uint32_t *d_out_size, int32_t *d_status, int order, const int32_t *d_order,
+                                        uint32_t max_in_size, void *stream)
+{
+    if (!c) return -1;
+    if (n < 0 || (n && (!d_in || !d_in_off || !d_in_size || !d_out || !d_out_off || !d_out_cap || !d_out_size || !d_status))) {
+        c->err = "rans4x8 compress_dev: bad arguments";
+        return -1;
+    }
+    if (n == 0) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const u64 scratch_stride = align_up((size_t)r4x8_compress_bound(max_in_size) + 64, 256);
+    EncWs w;
+    const size_t per_blk = enc_ws_layout(nullptr, 1, scratch_stride, 0, 0, &w) + 4096;
+    size_t chunk = plan_chunk(c, (size_t)n, per_blk);
+    if (ws_order_begin(c, s) != 0) return -1;
+    for (;;) {
+        if (ensure_ws(c, enc_ws_layout(nullptr, chunk, scratch_stride, 0, 0, &w)) == 0) break;
+        if (chunk == 1) return -1;
+        chunk = (chunk + 1) / 2;
+    }
+    enc_ws_layout(c->ws, chunk, scratch_stride, 0, 0, &w);
+    w.logtab = c->logtab;
+    w.rcptab = c->rcptab;
+    BatchArgs a;
+    a.in = d_in; a.in_off = d_in_off; a.in_size = d_in_size;
+    a.out = d_out; a.out_off = d_out_off; a.out_cap = d_out_cap; a.out_size = d_out_size;
+    a.status = d_status; a.d_order = d_order; a.order = order; a.n = n;
+    for (size_t base = 0; base < (size_t)n; base += chunk) {
+        const int nb = (int)((size_t)n - base < chunk ? (size_t)n - base : chunk);
+        r4x8_launch_encode(&a, &w, (int)base, nb, s);
+    }
+    HIPCHK(c, hipGetLastError());
+    return ws_order_end(c, s);
+}
+
+extern "C" int rans4x8_hip_uncompress_dev(rans4x16_hip_ctx *c, int n,
+                                          const unsigned char *d_in, const uint64_t *d_in_off, const uint32_t *d_in_size,
+                                          unsigned char *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap,
+                                          uint32_t *d_out_size, int32_t *d_status, void *stream)
+{
+    if (!c) return -1;
+    if (n < 0 || (n && (!d_in || !d_in_off || !d_in_size || !d_out || !d_out_off || !d_out_cap || !d_out_size || !d_status))) {
+        c->err = "rans4x8 uncompress_dev: bad arguments";
+        return -1;
+    }
+    if (n == 0) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t per_blk = r4x8_dec_ws_bytes(1) + 4096;
+    size_t chunk = plan_chunk(c, (size_t)n, per_blk);
+    if (ws_order_begin(c, s) != 0) return -1;
+    for (;;) {
+        if (ensure_ws(c, r4x8_dec_ws_bytes(chunk)) == 0) break;
+        if (chunk == 1) return -1;
+        chunk = (chunk + 1) / 2;
+    }
+    BatchArgs a;
+    a.in = d_in; a.in_off = d_in_off; a.in_size = d_in_size;
+    a.out = d_out; a.out_off = d_out_off; a.out_cap = d_out_cap; a.out_size = d_out_size;
+    a.status = d_status; a.d_order = nullptr; a.order = 0; a.n = n;
+    for (size_t base = 0; base < (size_t)n; base += chunk) {
+        const int nb = (int)((size_t)n - base < chunk ? (size_t)n - base : chunk);
+        r4x8_launch_decode(&a, c->ws, (int)base, nb, s);
+    }
+    HIPCHK(c, hipGetLastError());
+    return ws_order_end(c, s);
+}
+
+// host buffers: one staging pass (copy in, kernels, sizes back, copy out) on the context's stream
+static int run_host8(rans4x16_hip_ctx *c, int n, bool decode,
+                     const unsigned char *const *in, const unsigned int *in_size,
+                     unsigned char *const *out, unsigned int *out_size, const int *order, int *status)
+{
+    if (!c) return -1;
+    if (n <= 0) return n == 0 ? 0 : -1;
+    if (!in || !in_size || !out || !out_size) { c->err = "rans4x8 batch: bad arguments"; return -1; }
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    std::vector<u64> in_off(n), out_off(n);
+    std::vector<u32> cap(n);
+    std::vector<i32> ord(n);
+    size_t in_tot = 0, out_tot = 0;
+    u32 max_in = 0;
+    for (int i = 0; i < n; i++) {
+        in_off[i] = in_tot; in_tot += align_up((size_t)in_size[i] + 16, 256);
+        cap[i] = out_size[i];
+        out_off[i] = out_tot; out_tot += align_up((size_t)cap[i] + 16, 256);
+        if (in_size[i] > max_in) max_in = in_size[i];
+        ord[i] = order ? order[i] : 0;
+    }
+    const size_t arr = align_up((size_t)n * 8, 256);
+    if (r4x16_ensure_stage(c, in_tot + out_tot + 6 * arr) != 0) return -1;
+    u8 *d_in = c->stage, *d_out = d_in + in_tot, *meta = d_out + out_tot;
+    u64 *d_in_off = (u64 *)meta, *d_out_off = (u64 *)(meta + arr);
+    u32 *d_in_size = (u32 *)(meta + 2 * arr), *d_cap = (u32 *)(meta + 3 * arr), *d_osz = (u32 *)(meta + 4 * arr);
+    i32 *d_status = (i32 *)(meta + 5 * arr), *d_order = (i32 *)(meta + 5 * arr + arr / 2);
+    for (int i = 0; i < n; i++)
+        if (in_size[i]) HIPCHK(c, hipMemcpyAsync(d_in + in_off[i], in[i], in_size[i], hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_in_off, in_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_out_off, out_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_in_size, in_size, (size_t)n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_cap, cap.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_order, ord.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+    const int rc = decode ? rans4x8_hip_uncompress_dev(c, n, d_in, d_in_off, d_in_size, d_out, d_out_off, d_cap, d_osz, d_status, s)
+                          : rans4x8_hip_compress_dev(c, n, d_in, d_in_off, d_in_size, d_out, d_out_off, d_cap, d_osz, d_status,
+                                                     0, d_order, max_in, s);
+    if (rc != 0) return -1;
+    std::vector<u32> osz(n);
+    std::vector<i32> st(n);
+    HIPCHK(c, hipMemcpyAsync(osz.data(), d_osz, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipMemcpyAsync(st.data(), d_status, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    int failed = 0;
+    for (int i = 0; i < n; i++) {
+        if (status) status[i] = st[i];
+        if (st[i] != 0) { out_size[i] = 0; failed++; continue; }
+        out_size[i] = osz[i];
+        if (osz[i]) HIPCHK(c, hipMemcpyAsync(out[i], d_out + out_off[i], osz[i], hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    return failed;
+}
+
+extern "C" int rans4x8_hip_compress_batch(rans4x16_hip_ctx *c, int n, const unsigned char *const *in, const unsigned int *in_size,
+                                          unsigned char *const *out, unsigned int *out_size, const int *order, int *status)
+{
+    return run_host8(c, n, false, in, in_size, out, out_size, order, status);
+}
+extern "C" int rans4x8_hip_uncompress_batch(rans4x16_hip_ctx *c, int n, const unsigned char *const *in, const unsigned int *in_size,
+                                            unsigned char *const *out, unsigned int *out_size, int *status)
+{
+    return run_host8(c, n, true, in, in_size, out, out_size, nullptr, status);
+}
+
+// htscodecs/rANS_static.h:41-44: malloc'd results, NULL on failure
+extern "C" unsigned char *rans_compress(unsigned char *in, unsigned int in_size, unsigned int *out_size, int order)
+{
+    rans4x16_hip_ctx *c = thread_ctx();
+    if (!c || !out_size || !in_size) return nullptr;
+    unsigned int cap = r4x8_compress_bound(in_size);
+    unsigned char *out = (unsigned char *)malloc(cap);
+    if (!out) return nullptr;
+    const unsigned char *ins[1] = { in };
+    unsigned char *outs[1] = { out };
+    unsigned int isz[1] = { in_size };
+    int ord[1] = { order ? 1 : 0 };
+    const int rc = run_host8(c, 1, false, ins, isz, outs, &cap, ord, nullptr);
+    r4x16_trim(c, SINGLE_CALL_KEEP);
+    if (rc != 0) { free(out); return nullptr; }
+    *out_size = cap;
+    return out;
+}
+
+extern "C" unsigned char *rans_uncompress(unsigned char *in, unsigned int in_size, unsigned int *out_size)
+{
+    rans4x16_hip_ctx *c = thread_ctx();
+    if (!c || !out_size || in_size < 9) return nullptr;                          // rANS_static.c:937
+    unsigned int usz = (unsigned int)in[5] | ((unsigned int)in[6] << 8) | ((unsigned int)in[7] << 16) | ((unsigned int)in[8] << 24);
+    if (usz >= INT_MAX) return nullptr;
+    unsigned char *out = (unsigned char *)malloc(usz ? usz : 1);
+    if (!out) return nullptr;
+    const unsigned char *ins[1] = { in };
+    unsigned char *outs[1] = { out };
+    unsigned int isz[1] = { in_size };
+    const int rc = run_host8(c, 1, true, ins, isz, outs, &usz, nullptr, nullptr);
+    r4x16_trim(c, SINGLE_CALL_KEEP);
+    if (rc != 0) { free(out); return nullptr; }
+    *out_size = usz;
+    return out;
+}

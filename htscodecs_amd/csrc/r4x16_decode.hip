@@ -16,6 +16,8 @@
 #include <type_traits>
 #include "r4x16_dev.h"
 
+static inline size_t align_up_sz(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
 // ---- image access: global memory or LDS ------------------------------------------------------
 struct GImg {
     gcu8 *p;
@@ -1505,4 +1507,325 @@ extern "C" void r4x16_launch_stripe(const u8 *src, u8 *dst, u32 n, u32 N, int jo
     const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     if (join) hipLaunchKernelGGL(k_stripe_join, dim3(grid), dim3(256), 0, s, src, dst, n, N);
     else      hipLaunchKernelGGL(k_stripe_split, dim3(grid), dim3(256), 0, s, src, dst, n, N);
+}
+
+// =============================================================================================
+// rANS 4x8 decode (CRAM 3.0's codec: htscodecs/rANS_static.c:231-383, :676-916, rANS_byte.h).
+// the same four interleaved chains per block, 12-bit tables, but BYTE-wise
+// renormalisation (L = 2^23, up to two bytes per chain and step) and its own table grammar.
+//
+//   k8_dec_front : one wave per block: the 9-byte header, the frequency table(s) -> a lookup image in
+//                  the 4x16 decoder's u16 format (r4x16_common.h) with one extra, flagged symbol for the
+//                  slot a 4095-sum table leaves unowned.
+//   k8_dec_chain : a quad per block, 16 blocks per wave; the general-form chain loop (tables read
+//                  through L2) with the byte renormalisation: a chain takes (x < 2^23) + (x < 2^15) bytes
+//                  - both known before any byte is read - at the quad's cursor plus the counts of the
+//                  chains below it.
+// Plain first version of this codec (no LDS images, no word ring): correctness and the boundary first.
+//
+// Stricter than the reference on damaged input (valid encoder output never gets here), all reported as
+// R4X16_E_TABLE / R4X16_E_CONTEXT: symbols or contexts not listed in ascending order (the reference assigns
+// slots in listing order, which a cumulative table over the sorted alphabet cannot express); slot 4095 of a
+// table that sums to 4095 and contexts without a table (undefined in the reference, see oracle/rans4x8_oracle.c).
+// =============================================================================================
+#define X8_LOW   (1u << 23)
+#define X8_BITS  12u
+#define ROW_BAD  0x200u                                   // alpha[] flag: decoding this symbol is an error
+#define IMG8_MAX_NSYM 257u                                // 256 symbols + the flagged one
+#define IMG8_SLOT ((528u + 257u * 832u + 255u) & ~255u)   // alpha[257] + 257 four-level rows
+
+struct X8Item {
+    u64 bytes;       // first renormalisation byte (just after the 4 states)
+    u64 out;
+    u64 image;
+    u32 bytes_len;   // bytes from `bytes` to the end of the input
+    u32 out_sz;
+    u32 R[4];
+    u32 order, nsym; // nsym counts the flagged extra symbol
+    u32 active, pad;
+};
+
+struct Front8Shared {
+    FrontShared S;
+    u32 Fsym[256];       // frequency by byte value of the table being parsed (0 = not listed)
+    u8 listed[256];      // listed in the table being parsed
+    u8 ctx_seen[256];    // order-1: context has a table
+    i32 status;
+    u32 pos, total, n, go;
+};
+
+// One table of the 4x8 grammar (rANS_static.c:274-310 / :760-805) by one lane: symbols with a run-length
+// shortcut, each followed by a one- or two-byte frequency, closed by a zero symbol.  Fills Fsym / listed;
+// returns the new position or 0 with `st` set.  `collect` != nullptr: only mark the symbols seen (first pass
+// of the order-1 parse, which needs the whole alphabet before it can lay out rows).
+__device__ u32 x8_get_table(ByteSrc &src, u32 cp, u32 end, u32 *Fsym, u8 *listed, u32 *total, bool zero_is_total,
+                            u8 *collect, i32 &st)
+{
+    u32 x = 0, rle = 0, prev = 0;
+    bool first = true;
+    u32 j = src.at(cp++);
+    do {
+        if (cp + 16 > end) { st = ST_TRUNCATED; return 0; }
+        u32 F = src.at(cp++);
+        if (F >= 128) F = ((F & 127) << 8) | src.at(cp++);
+        if (!F && zero_is_total) F = 4096u;
+        if (x + F > 4096u) { st = ST_TABLE; return 0; }
+        if (!first && j <= prev) { st = ST_TABLE; return 0; }          // ascending listing only (see the header)
+        first = false; prev = j;
+        if (collect) collect[j] = 1;
+        else { Fsym[j] = F; listed[j] = 1; }
+        x += F;
+        const u32 nx = src.at(cp);
+        if (!rle && j + 1 == nx) { j = src.at(cp++); rle = src.at(cp++); }
+        else if (rle) { rle--; j++; if (j > 255) { st = ST_TABLE; return 0; } }
+        else j = src.at(cp++);
+    } while (j);
+    if (x < 4095u || x > 4096u) { st = ST_TABLE; return 0; }
+    *total = x;
+    return cp;
+}
+
+// Whole wave: cumulative starts of the current table over the compact alphabet S.alpha[0..n) (the last entry is
+// the flagged extra symbol, which owns [total, 4096)), then the row.
+__device__ void x8_build_row(Front8Shared &Z, u8 *rowp, u32 n, u32 lane)
+{
+    FrontShared &S = Z.S;
+    u32 carry = 0;
+    for (u32 cb = 0; cb < n; cb += WAVE) {
+        const u32 c = cb + lane;
+        const u32 f = (c + 1 < n) ? Z.Fsym[S.alpha[c]] : 0u;
+        const u32 incl = wave_incl_scan(f, lane);
+        if (c < n) S.cum[c] = (u16)(carry + incl - f);
+        carry += (u32)__shfl((int)incl, WAVE - 1);
+    }
+    if (lane == 0) { S.cum[n - 1] = (u16)Z.total; S.cum[n] = 4096; S.cum[n + 1] = S.cum[n + 2] = S.cum[n + 3] = 0x7fffu; }
+    __syncthreads();
+    write_row(rowp, S, n, false, lane);
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(WAVE) void k8_dec_front(BatchArgs a, X8Item *items, u8 *images, int base)
+{
+    __shared__ Front8Shared Z;
+    FrontShared &S = Z.S;
+    const u32 lane = threadIdx.x;
+    const u32 b = blockIdx.x;
+    const int i = base + (int)b;
+    X8Item *I = &items[b];
+    const u8 *in = a.in + a.in_off[i];
+    const u32 in_size = a.in_size[i];
+    u8 *img = images + (u64)b * IMG8_SLOT;
+    ByteSrc src(in);
+
+    for (u32 j = lane; j < 256; j += WAVE) { Z.Fsym[j] = 0; Z.listed[j] = 0; Z.ctx_seen[j] = 0; S.present[j] = 0; }
+    if (lane == 0) {
+        I->active = 0;
+        i32 st = ST_OK;
+        u32 order = 0, out_sz = 0;
+        if (in_size == 0) st = ST_EMPTY;
+        else if (in_size < 9) st = ST_TRUNCATED;                                 // rANS_static.c:937
+        else {
+            order = src.at(0);
+            if (order > 1) st = ST_UNSUPPORTED;                                  // :715 (anything non-zero goes to the order-1 decoder, which wants 1)
+            else if (in_size < (order ? 27u : 26u)) st = ST_TRUNCATED;           // :245, :711
+            else {
+                const u32 in_sz = (u32)src.at(1) | ((u32)src.at(2) << 8) | ((u32)src.at(3) << 16) | ((u32)src.at(4) << 24);
+                out_sz = (u32)src.at(5) | ((u32)src.at(6) << 8) | ((u32)src.at(7) << 16) | ((u32)src.at(8) << 24);
+                if (in_sz != in_size - 9) st = ST_SIZE;                          // :252
+                else if (out_sz >= 0x7fffffffu) st = ST_SIZE;                    // :255
+                else if (a.out_cap[i] < out_sz) st = ST_CAPACITY;
+            }
+        }
+        Z.status = st;
+        I->order = order; I->out_sz = out_sz;
+    }
+    __syncthreads();
+    if (Z.status != ST_OK) { if (lane == 0) { a.status[i] = Z.status; a.out_size[i] = 0; } return; }
+    const u32 order = I->order, end = in_size;
+
+    if (order == 0) {
+        if (lane == 0) {
+            i32 st = ST_OK;
+            const u32 cp = x8_get_table(src, 9, end, Z.Fsym, Z.listed, &Z.total, false, nullptr, st);
+            u32 n = 0;
+            if (st == ST_OK) {
+                for (u32 j = 0; j < 256; j++) if (Z.listed[j]) S.alpha[n++] = (u8)j;
+                S.alpha[n++] = 0;                                                // the flagged extra symbol
+                if (cp + 16 > end) st = ST_TRUNCATED;                            // :313
+            }
+            Z.status = st; Z.pos = cp; Z.n = n;
+        }
+        __syncthreads();
+        if (Z.status == ST_OK) {
+            const u32 n = Z.n;
+            for (u32 j = lane; j < n; j += WAVE) ((u16 *)img)[j] = (u16)(S.alpha[j] | (j + 1 == n ? ROW_BAD : 0u));
+            x8_build_row(Z, img + img_alpha_bytes(n), n, lane);
+        }
+    } else {
+        // pass 1 (lane 0): the alphabet = every byte listed as a context or as a symbol, byte 0 forced in (the first
+        // byte of each quarter is decoded in context 0, :843-850)
+        if (lane == 0) {
+            i32 st = ST_OK;
+            u32 cp = 9, rle_i = 0, prev = 0;
+            bool first = true;
+            u32 c = src.at(cp++);
+            do {
+                if (!first && c <= prev) { st = ST_TABLE; break; }
+                first = false; prev = c;
+                S.present[c] = 1;
+                u32 dummy;
+                cp = x8_get_table(src, cp, end, nullptr, nullptr, &dummy, true, S.present, st);
+                if (st != ST_OK) break;
+                const u32 nx = src.at(cp);
+                if (!rle_i && c + 1 == nx) { c = src.at(cp++); rle_i = src.at(cp++); }
+                else if (rle_i) { rle_i--; c++; if (c > 255) { st = ST_TABLE; break; } }
+                else c = src.at(cp++);
+            } while (c);
+            u32 n = 0;
+            if (st == ST_OK) {
+                S.present[0] = 1;
+                for (u32 j = 0; j < 256; j++) if (S.present[j]) { S.idx_of[j] = (u8)n; S.alpha[n++] = (u8)j; }
+                S.alpha[n++] = 0;
+                if (cp + 16 > end) st = ST_TRUNCATED;                            // :826
+            }
+            Z.status = st; Z.pos = cp; Z.n = n;
+        }
+        __syncthreads();
+        if (Z.status == ST_OK) {
+            const u32 n = Z.n, stride = img_row_bytes(n);
+            u8 *rows0 = img + img_alpha_bytes(n);
+            // every context starts without a table; the flagged symbol has none either
+            for (u32 j = lane; j < n; j += WAVE) ((u16 *)img)[j] = (u16)(S.alpha[j] | ROW_EMPTY | (j + 1 == n ? ROW_BAD : 0u));
+            for (u32 r = 0; r < n; r++) {                                        // rows of contexts without a table: all-sentinel
+                u16 *w = (u16 *)(rows0 + (u64)r * stride);
+                for (u32 t = lane; t < stride / 2; t += WAVE) w[t] = t == (img_leaf_off(img_levels(n)) / 2) ? (u16)0 : (u16)0x7fffu;
+            }
+            __syncthreads();
+            // pass 2: the tables, context by context
+            u32 cp = 9, rle_i = 0;
+            u32 c = 0;
+            if (lane == 0) { Z.pos = cp + 1; Z.go = 1; }
+            c = src.at(cp);
+            for (;;) {
+                for (u32 j = lane; j < 256; j += WAVE) { Z.Fsym[j] = 0; Z.listed[j] = 0; }
+                __syncthreads();
+                if (lane == 0) {
+                    i32 st = ST_OK;
+                    const u32 np = x8_get_table(src, Z.pos, end, Z.Fsym, Z.listed, &Z.total, true, nullptr, st);
+                    Z.status = st; Z.pos = np;
+                }
+                __syncthreads();
+                if (Z.status != ST_OK) break;
+                const u32 ci = S.idx_of[c];
+                x8_build_row(Z, rows0 + (u64)ci * stride, n, lane);
+                if (lane == 0) ((u16 *)img)[ci] &= (u16)~ROW_EMPTY;
+                // next context (same grammar as the symbols; order was checked in pass 1)
+                cp = Z.pos;
+                const u32 nx = src.at(cp);
+                if (!rle_i && c + 1 == nx) { c = src.at(cp); rle_i = src.at(cp + 1); cp += 2; }
+                else if (rle_i) { rle_i--; c++; }
+                else { c = src.at(cp); cp += 1; }
+                if (lane == 0) Z.pos = cp;
+                __syncthreads();
+                if (!c) break;
+            }
+        }
+    }
+    __syncthreads();
+    if (Z.status != ST_OK) { if (lane == 0) { a.status[i] = Z.status; a.out_size[i] = 0; } return; }
+    if (lane == 0) {
+        u32 p = Z.pos;
+        i32 st = ST_OK;
+        for (u32 k = 0; k < 4; k++, p += 4) {
+            const u32 r = (u32)src.at(p) | ((u32)src.at(p + 1) << 8) | ((u32)src.at(p + 2) << 16) | ((u32)src.at(p + 3) << 24);
+            I->R[k] = r;
+            if (r < X8_LOW) st = ST_STATE;                                        // :316-319, :829-832
+        }
+        I->bytes = (u64)(in + p); I->bytes_len = end - p;
+        I->out = (u64)(a.out + a.out_off[i]);
+        I->image = (u64)img; I->nsym = Z.n;
+        a.status[i] = st;
+        a.out_size[i] = st == ST_OK ? I->out_sz : 0;
+        __threadfence();
+        I->active = st == ST_OK && I->out_sz != 0;
+    }
+}
+
+// The 4x8 chain loop (rANS_static.c:323-372, :857-916): the lookups of chain_decode, byte renormalisation.
+template <int ORDER, int LV>
+__device__ __forceinline__ u32 chain_decode8(GImg img, u32 nsym, gcu8 *bytes, u32 bytes_len, gu8 *out, u32 out_sz, u32 x,
+                                             bool active, u32 lane)
+{
+    const u32 k = lane & 3;
+    const u32 rows = img_alpha_bytes(nsym), roww = img_row_bytes(nsym);
+    const u32 below = (1u << k) - 1u;
+    u32 count, pos;
+    if (ORDER == 0) { count = (out_sz + 3 - k) >> 2; pos = k; }
+    else { const u32 q = out_sz >> 2; count = q + (k == 3 ? out_sz - 4 * q : 0); pos = k * q; }
+    if (!active) count = 0;
+    u32 row = rows, cursor = 0, bad = 0, t = 0;
+    if (ORDER == 1 && count) bad = img.ld16(0) & ROW_EMPTY;
+    while (wave_any(t < count)) {
+        const bool live = t < count;
+        if (live) {
+            const u32 s = lookup_step<LV>(img, row, X8_BITS, 4095u, x);
+            const u32 al = img.ld16(2 * s);
+            bad |= al & ROW_BAD;
+            if (ORDER == 0) { out[pos] = (u8)al; pos += 4; }
+            else {
+                row = rows + s * roww;
+                if (t + 1 < count) bad |= al & ROW_EMPTY;
+                out[pos] = (u8)al; pos += 1;
+            }
+        }
+        // a chain takes one byte if x < 2^23 and a second one if x < 2^15 (x << 8 | byte < 2^23 whatever the byte
+        // is); chains are served in the order 0..3, and nothing is read past the end (rANS_byte.h:541-551)
+        const bool w1 = live && x < X8_LOW, w2 = live && x < (1u << 15);
+        const u32 m1 = quad_ballot(w1, lane), m2 = quad_ballot(w2, lane);
+        const u32 at = cursor + __popc(m1 & below) + __popc(m2 & below);
+        const u32 want = (w1 ? 1u : 0u) + (w2 ? 1u : 0u);
+        const u32 room = at < bytes_len ? bytes_len - at : 0u;
+        const u32 take = want < room ? want : room;
+        if (take) {
+            x = (x << 8) | bytes[at];
+            if (take > 1) x = (x << 8) | bytes[at + 1];
+        }
+        cursor += __popc(m1) + __popc(m2);
+        t++;
+    }
+    return bad;
+}
+
+__global__ __launch_bounds__(WAVE) void k8_dec_chain(const X8Item *items, BatchArgs a, int base, int nitems)
+{
+    const u32 lane = threadIdx.x;
+    const int slot = (int)blockIdx.x * 16 + (int)(lane >> 2);
+    const bool mine = slot < nitems;
+    const X8Item *I = &items[mine ? slot : 0];
+    const bool active = mine && I->active;
+    if (!wave_any(active)) return;
+    const u32 nsym = active ? I->nsym : 1u, order = active ? I->order : 2u;
+    const u32 lv = img_levels(nsym);
+    GImg im{(gcu8 *)I->image};
+    gcu8 *bytes = (gcu8 *)I->bytes;
+    gu8 *out = (gu8 *)I->out;
+    const u32 blen = I->bytes_len, osz = I->out_sz, x0 = I->R[lane & 3];
+    u32 bad = 0;
+#define X8_RUN(O, L) bad |= chain_decode8<O, L>(im, nsym, bytes, blen, out, osz, x0, active && order == O && lv == L, lane)
+    X8_RUN(0, 2); X8_RUN(0, 3); X8_RUN(0, 4);
+    X8_RUN(1, 2); X8_RUN(1, 3); X8_RUN(1, 4);
+#undef X8_RUN
+    if (active && bad) {
+        a.status[base + slot] = (bad & ROW_BAD) ? ST_TABLE : ST_CONTEXT;
+        a.out_size[base + slot] = 0;
+    }
+}
+
+extern "C" size_t r4x8_dec_ws_bytes(size_t nblk) { return align_up_sz(nblk * sizeof(X8Item), 256) + nblk * (size_t)IMG8_SLOT; }
+extern "C" void r4x8_launch_decode(const BatchArgs *a, u8 *ws, int base, int nblk, hipStream_t s)
+{
+    X8Item *items = (X8Item *)ws;
+    u8 *images = ws + align_up_sz((size_t)nblk * sizeof(X8Item), 256);
+    hipLaunchKernelGGL(k8_dec_front, dim3(nblk), dim3(WAVE), 0, s, *a, items, images, base);
+    hipLaunchKernelGGL(k8_dec_chain, dim3((nblk + 15) / 16), dim3(WAVE), 0, s, (const X8Item *)items, *a, base, nblk);
 }

@@ -1981,3 +1981,327 @@ extern "C" void r4x16_launch_enc_finish(const BatchArgs *a, const EncWs *ws, int
     hipLaunchKernelGGL(k_enc_finish, dim3(nblk), dim3(FINISH_THREADS), 0, s, *a, *ws, base);
 }
 extern "C" u32 r4x16_compress_bound(u32 size, int order) { return compress_bound(size, order); }
+
+// =============================================================================================
+// rANS 4x8 encode (CRAM 3.0's codec: htscodecs/rANS_static.c:85-224, :409-615, rANS_byte.h).  SURVEY.md 8f-4.
+//   k8_enc_front  : 256 threads per block: histograms (the 4x16 front end's passes: hist8 / present8 + hist1_4 with
+//                   the three quarter starts, utils.h:80-202), normalisation to 4095 (order 0: 64-bit fixed point;
+//                   order 1: double precision, one context row per thread, evaluation order of the reference),
+//                   the table in the 4x8 grammar, the u16 cumulative image of the 4x16 encoder.
+//   k8_enc_chain  : a quad per block; the general-form chain loop with BYTE renormalisation: a chain emits
+//                   (x >= x_max) + (x >> 8 >= x_max) bytes, low byte first, on the quad's descending pointer,
+//                   chains served in the order 3, 2, 1, 0 (rANS_byte.h:320-402).
+//   k8_enc_finish : header (order, sizes), table, payload into the caller's slot.
+// Plain first version (tables through L2, byte stores); in_size == 0 is refused (the reference divides by zero).
+// =============================================================================================
+#define X8_LOW_E (1u << 23)
+__host__ __device__ static inline u32 compress_bound8(u32 size) { return (u32)((int)(1.05 * size) + 257 * 257 * 3 + 9); }   // :87
+extern "C" u32 r4x8_compress_bound(u32 size) { return compress_bound8(size); }
+
+// symbols j with F[j] != 0 (byte order = compact order) in the 4x8 table grammar (:143-169, :497-531); `F` is
+// indexed by compact symbol, `alpha` maps to bytes.  cp == nullptr: only the length.
+__device__ u32 x8_put_table(u8 *cp, const u32 *F, u32 fstride, const u8 *alpha, u32 ns)
+{
+    u32 len = 0, rle = 0;
+    for (u32 c = 0; c < ns; c++) {
+        const u32 f = F[c * fstride];
+        if (!f) continue;
+        if (rle) rle--;
+        else {
+            const u32 j = alpha[c];
+            if (cp) cp[len] = (u8)j;
+            len++;
+            if (c && F[(c - 1) * fstride] && alpha[c - 1] + 1u == j) {
+                u32 r = c + 1;
+                while (r < ns && F[r * fstride] && alpha[r] == j + (r - c)) r++;
+                rle = r - (c + 1);
+                if (cp) cp[len] = (u8)rle;
+                len++;
+            }
+        }
+        if (f < 128) { if (cp) cp[len] = (u8)f; len++; }
+        else { if (cp) { cp[len] = (u8)(128 | (f >> 8)); cp[len + 1] = (u8)(f & 0xff); } len += 2; }
+    }
+    if (cp) cp[len] = 0;
+    return len + 1;
+}
+
+__global__ __launch_bounds__(FRONT_THREADS) void k8_enc_front(BatchArgs a, EncWs ws, int base)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 dyn[];
+    __shared__ EncShared S;
+    __shared__ struct { i32 status; u32 order, ns, tab_len; } H;
+    const u32 tid = threadIdx.x;
+    const u32 b = blockIdx.x;
+    const int i = base + (int)b;
+    EncItem *I0 = &ws.items[b];
+    const u8 *data = a.in + a.in_off[i];
+    const u32 n = a.in_size[i];
+    int order = a.d_order ? a.d_order[i] : a.order;
+    u8 *img = ws.images + (u64)b * ENC_IMG_BYTES;
+    u8 *tab = ws.tab + (u64)b * TAB_BYTES;
+    u8 *scratch_end = ws.scratch + (u64)b * ws.scratch_stride + ws.scratch_stride;
+
+    if (tid == 0) {
+        I0->active = 0; I0->pay_len = 0; I0->blk = b; I0->packed = 0;
+        i32 st = ST_OK;
+        if (n == 0) st = ST_EMPTY;
+        else if (a.out_cap[i] < compress_bound8(n)) st = ST_CAPACITY;
+        else if ((u64)compress_bound8(n) + 64u > ws.scratch_stride) st = ST_UNSUPPORTED;   // block larger than the call announced
+        H.status = st;
+        H.order = (order && n >= 4) ? 1u : 0u;                                  // :438
+        ws.desc[b].status = st;
+    }
+    __syncthreads();
+    if (H.status != ST_OK) return;
+
+    if (H.order == 0) {
+        wg_hist8(data, n, S.F, (u32 *)dyn, tid);
+        if (tid == 0) {
+            // normalise to 4095 (:106-133): the largest symbol absorbs the difference; one harder retry
+            u64 tr = ((u64)4096 << 31) / n + (1u << 30) / n;
+            for (;;) {
+                int fsum = 0, m = 0, M = 0;
+                for (int j = 0; j < 256; j++) {
+                    int f = (int)S.F[j];
+                    if (!f) continue;
+                    if (m < f) { m = f; M = j; }
+                    f = (int)(((u64)f * tr) >> 31);
+                    if (f == 0) f = 1;
+                    S.F[j] = (u32)f;
+                    fsum += f;
+                }
+                fsum++;
+                if (fsum < 4096) { S.F[M] += (u32)(4096 - fsum); break; }
+                if (fsum - 4096 > (int)S.F[M] / 2) { tr = 2104533975u; continue; }
+                S.F[M] -= (u32)(fsum - 4096);
+                break;
+            }
+            for (u32 j = 0; j < 256; j++) S.alpha[j] = (u8)j;
+            H.tab_len = x8_put_table(tab, S.F, 1, S.alpha, 256);
+        }
+        __syncthreads();
+        img[tid] = (u8)tid;                                                      // identity index, one row of 257
+        if (tid == 0) {
+            u16 *cum = (u16 *)(img + ENC_IMG_IDX);
+            u32 x = 0;
+            for (u32 j = 0; j < 256; j++) { cum[j] = (u16)x; x += S.F[j]; }
+            cum[256] = (u16)x;
+        }
+        H.ns = 256;
+    } else {
+        wg_present8(data, n, S.F, S.pmask, tid);
+        if (tid == 0) {
+            u32 ns = 0;
+            for (u32 j = 0; j < 256; j++) {
+                S.present[j] = (S.F[j] != 0) || j == 0;
+                if (S.present[j]) { S.idx_of[j] = (u8)ns; S.alpha[ns] = (u8)j; ns++; }
+            }
+            S.nsym = ns;
+        }
+        __syncthreads();
+        const u32 ns = S.nsym;
+        const bool f_in_lds = ns <= FRONT_LDS_NSYM;
+        u32 *Fg = ws.F + (u64)b * 65536u;
+        u32 *Fp = f_in_lds ? (u32 *)dyn : Fg;
+        for (u32 j = tid; j < ns * ns; j += FRONT_THREADS) Fp[j] = 0;
+        __syncthreads();
+        wg_hist1(data, n, Fp, ns, 1u, S.idx_of, tid);
+        // one context row per thread: totals, normalisation in double precision (:470-495), serialised length
+        u32 T = 0;
+        if (tid < ns) {
+            u32 *F = Fp + tid * ns;
+            for (u32 j = 0; j < ns; j++) T += F[j];
+            if (T) {
+                double p = (double)4096 / (double)(int)T;
+                for (;;) {
+                    int t2 = 0, m = 0, M = 0;
+                    for (u32 j = 0; j < ns; j++) {
+                        int f = (int)F[j];
+                        if (!f) continue;
+                        if (m < f) { m = f; M = (int)j; }
+                        f = (int)((double)f * p);
+                        if (f == 0) f = 1;
+                        F[j] = (u32)f;
+                        t2 += f;
+                    }
+                    t2++;
+                    if (t2 < 4096) { F[M] += (u32)(4096 - t2); break; }
+                    if (t2 - 4096 >= (int)F[M] / 2) { p = .98; continue; }
+                    F[M] -= (u32)(t2 - 4096);
+                    break;
+                }
+            }
+            S.T[tid] = T;
+        }
+        __syncthreads();
+        if (tid < ns) {
+            u32 len = 0;
+            if (T) {
+                // the context byte with the table grammar's run-length shortcut over the contexts that occur (:497-510)
+                u32 pos = 0;
+                for (u32 r = tid; r > 0 && S.T[r - 1] && S.alpha[r - 1] + 1u == S.alpha[r]; r--) pos++;
+                len = (pos == 0 ? 1u : pos == 1 ? 2u : 0u) + x8_put_table(nullptr, Fp + tid * ns, 1, S.alpha, ns);
+            }
+            S.rowlen[tid] = len;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            u32 off = 0;
+            for (u32 r = 0; r < ns; r++) { const u32 l = S.rowlen[r]; S.rowlen[r] = off; off += l; }
+            tab[off] = 0;                                                        // closes the context list (:534)
+            H.tab_len = off + 1;
+        }
+        __syncthreads();
+        if (tid < ns && T) {
+            u8 *cp = tab + S.rowlen[tid];
+            u32 pos = 0;
+            for (u32 r = tid; r > 0 && S.T[r - 1] && S.alpha[r - 1] + 1u == S.alpha[r]; r--) pos++;
+            if (pos == 0) *cp++ = S.alpha[tid];
+            else if (pos == 1) {
+                u32 r = tid + 1;
+                while (r < ns && S.T[r] && S.alpha[r] == S.alpha[tid] + (r - tid)) r++;
+                *cp++ = S.alpha[tid];
+                *cp++ = (u8)(r - (tid + 1));
+            }
+            x8_put_table(cp, Fp + tid * ns, 1, S.alpha, ns);
+        }
+        // image: byte -> compact index, u16 cumulative rows
+        img[tid] = S.present[tid] ? S.idx_of[tid] : (u8)0;
+        if (tid < ns) {
+            u16 *cum = (u16 *)(img + ENC_IMG_IDX) + tid * (ns + 1);
+            u32 x = 0;
+            for (u32 j = 0; j < ns; j++) { cum[j] = (u16)x; x += Fp[tid * ns + j]; }
+            cum[ns] = (u16)x;
+        }
+        H.ns = ns;
+    }
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        ws.desc[b].tab_len = H.tab_len;
+        I0->data = (u64)data; I0->n = n; I0->image = (u64)img; I0->bits = 12; I0->order = H.order;
+        I0->ns = H.ns; I0->img_bytes = 0;
+        I0->scratch_end = (u64)scratch_end;
+        __threadfence();
+        I0->active = 1;
+    }
+}
+
+// One quad per block.  The step schedule is chain_encode's (both codecs walk a block the same way); what differs
+// is the renormalisation: zero, one or two BYTES per chain and step.
+template <int ORDER>
+__device__ __forceinline__ u32 chain_encode8(gcu8 *data, u32 n, gcu8 *image, u32 ns, gcu32 *rcptab, gu8 *scratch_end,
+                                             u32 room, bool active, u32 lane)
+{
+    const u32 k = lane & 3;
+    GAS const u16 *cum = (GAS const u16 *)(image + ENC_IMG_IDX);
+    const u32 rs = ns + 1;
+    u32 x = X8_LOW_E;
+    u32 written = 0;                 // bytes emitted by the quad so far
+    u32 nsteps, first, p;
+    const u32 q = n >> 2;
+    if (ORDER == 0) {
+        const u32 gtop = n ? (n - 1) >> 2 : 0;
+        nsteps = n ? gtop + 1 : 0;
+        first = (4 * gtop + k < n) ? 0 : 1;
+        p = 4 * (gtop - (first ? 1 : 0)) + k;
+    } else {
+        const u32 tail = n - 4 * q;
+        nsteps = tail + q;
+        first = (k == 3) ? 0 : tail;
+        p = (k == 3) ? n - 1 : k * q + q - 1;
+    }
+    if (!active) { nsteps = 0; first = 0; }
+    u32 cur = 0;
+    if (nsteps > first) cur = image[data[p]];
+    for (u32 s = 0; wave_any(s < nsteps); s++) {
+        const bool live = s >= first && s < nsteps;
+        bool e1 = false, e2 = false;
+        u32 rcp = 0, pk = 0, nextc = 0;
+        if (live) {
+            u32 row = 0;
+            if (ORDER == 0) { if (p >= 4) nextc = image[data[p - 4]]; }
+            else if (s != nsteps - 1) { nextc = image[data[p - 1]]; row = nextc; }
+            const u32 c0 = cum[row * rs + cur], c1 = cum[row * rs + cur + 1];
+            const u32 f = c1 - c0;
+            pk = c0 | (f << 16);
+            rcp = enc_rcp(rcptab, f);
+            const u32 x_max = f << 19;                                           // rANS_byte.h:217 (f = 4096: 2^31)
+            e1 = x >= x_max;
+            e2 = (x >> 8) >= x_max;
+        }
+        const u32 m1 = quad_ballot(e1, lane), m2 = quad_ballot(e2, lane);
+        if (e1) {
+            const u32 at = written + __popc(m1 >> (k + 1)) + __popc(m2 >> (k + 1));
+            if (at + 2 <= room) {                                                // (never false for data the bound covers)
+                scratch_end[-(long)(at + 1)] = (u8)x;
+                if (e2) scratch_end[-(long)(at + 2)] = (u8)(x >> 8);
+            }
+            x >>= e2 ? 16 : 8;
+        }
+        written += __popc(m1) + __popc(m2);
+        if (live) {
+            x = enc_advance(x, rcp, pk, 12);
+            cur = nextc;
+            p -= (ORDER == 0) ? 4 : 1;
+        }
+    }
+    // RansEncFlush x4 in the order 3,2,1,0 (:199-202): state 0 ends up lowest in memory
+    if (active && written + 16 <= room) {
+        gu8 *dst = scratch_end - written - 16 + 4 * k;
+        dst[0] = (u8)x; dst[1] = (u8)(x >> 8); dst[2] = (u8)(x >> 16); dst[3] = (u8)(x >> 24);
+    }
+    return active ? written + 16 : 0;
+}
+
+__global__ __launch_bounds__(WAVE) void k8_enc_chain(EncItem *items, const u32 *rcptab_, int nitems, u32 room)
+{
+    const u32 lane = threadIdx.x;
+    const int slot = (int)blockIdx.x * 16 + (int)(lane >> 2);
+    const bool mine = slot < nitems;
+    EncItem *I = &items[mine ? slot : 0];
+    const bool active = mine && I->active;
+    if (!wave_any(active)) return;
+    gcu32 *rcptab = to_global(rcptab_);
+    gcu8 *data = (gcu8 *)I->data, *im = (gcu8 *)I->image;
+    gu8 *send = (gu8 *)I->scratch_end;
+    const u32 n = I->n, ns = I->ns, order = active ? I->order : 2u;
+    u32 pay = chain_encode8<1>(data, n, im, ns, rcptab, send, room, order == 1, lane);
+    pay |= chain_encode8<0>(data, n, im, ns, rcptab, send, room, order == 0, lane);
+    if (active && (lane & 3) == 0) I->pay_len = pay;
+}
+
+__global__ __launch_bounds__(FINISH_THREADS) void k8_enc_finish(BatchArgs a, EncWs ws, int base, u32 room)
+{
+    const u32 tid = threadIdx.x;
+    const u32 b = blockIdx.x;
+    const int i = base + (int)b;
+    const EncItem *I0 = &ws.items[b];
+    const i32 st = ws.desc[b].status;
+    if (st != ST_OK || !I0->active || I0->pay_len > room) {
+        if (tid == 0) { a.status[i] = st != ST_OK ? st : ST_CAPACITY; a.out_size[i] = 0; }
+        return;
+    }
+    u8 *out = a.out + a.out_off[i];
+    const u32 tab_len = ws.desc[b].tab_len, pay = I0->pay_len, total = 9 + tab_len + pay;
+    if (tid == 0) {                                                              // :204-214, :593-605
+        const u32 csz = total - 9, n = I0->n;
+        out[0] = (u8)I0->order;
+        out[1] = (u8)csz; out[2] = (u8)(csz >> 8); out[3] = (u8)(csz >> 16); out[4] = (u8)(csz >> 24);
+        out[5] = (u8)n; out[6] = (u8)(n >> 8); out[7] = (u8)(n >> 16); out[8] = (u8)(n >> 24);
+    }
+    group_copy<FINISH_THREADS>(out + 9, ws.tab + (u64)b * TAB_BYTES, tab_len, tid);
+    group_copy<FINISH_THREADS>(out + 9 + tab_len, (const u8 *)I0->scratch_end - pay, pay, tid);
+    if (tid == 0) { a.status[i] = ST_OK; a.out_size[i] = total; }
+}
+
+extern "C" void r4x8_launch_encode(const BatchArgs *a, const EncWs *ws, int base, int nblk, hipStream_t s)
+{
+    if (r4x16_first_on_device(8u))
+        (void)hipFuncSetAttribute((const void *)k8_enc_front, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_DYN_LDS);
+    const u32 room = (u32)(ws->scratch_stride > 0xffffffffull ? 0xffffffffu : ws->scratch_stride);
+    hipLaunchKernelGGL(k8_enc_front, dim3(nblk), dim3(FRONT_THREADS), FRONT_DYN_LDS, s, *a, *ws, base);
+    hipLaunchKernelGGL(k8_enc_chain, dim3((nblk + 15) / 16), dim3(WAVE), 0, s, ws->items, ws->rcptab, nblk, room);
+    hipLaunchKernelGGL(k8_enc_finish, dim3(nblk), dim3(FINISH_THREADS), 0, s, *a, *ws, base, room);
+}

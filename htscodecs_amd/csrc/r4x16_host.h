@@ -16,6 +16,7 @@
 #include <algorithm>
 
 #include "../../include/rans4x16_hip.h"
+#include "../../include/rans4x8_hip.h"
 #include "r4x16_dev.h"
 
 extern "C" {

@@ -48,6 +48,19 @@ SIGNATURES = {
                                                    C.c_void_p, C.c_void_p, C.c_void_p]),
     "rans4x16_hip_uncompress_batch_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                      C.c_void_p, C.c_void_p]),
+    # include/rans4x8_hip.h
+    "rans_compress": (C.c_void_p, [_u8p, C.c_uint, C.POINTER(C.c_uint), C.c_int]),
+    "rans_uncompress": (C.c_void_p, [_u8p, C.c_uint, C.POINTER(C.c_uint)]),
+    "rans4x8_hip_compress_bound": (C.c_uint, [C.c_uint]),
+    "rans4x8_hip_compress_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rans4x8_hip_uncompress_batch": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p]),
+    "rans4x8_hip_compress_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "rans4x8_hip_uncompress_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 

@@ -13,9 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "rans4x16_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"\b(rans4x16_hip_\w+|rans_\w+_4x16)\s*\(", text)
+    names = []
+    for hdr in ("rans4x16_hip.h", "rans4x8_hip.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names += re.findall(r"\b(rans4x16_hip_\w+|rans4x8_hip_\w+|rans_\w+_4x16|rans_compress|rans_uncompress)\s*\(", text)
     return sorted(set(names))
 
 
@@ -32,7 +34,16 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(L, name), f"{name} declared in include/rans4x16_hip.h but not exported"
         assert name in hlib.SIGNATURES, f"{name} has no ctypes signature in htscodecs_amd/lib.py"
     for name in hlib.SIGNATURES:
-        assert name in declared, f"{name} bound in lib.py but not declared in the header"
+        assert name in declared, f"{name} bound in lib.py but not declared in a header"
+
+
+def test_exports_are_exactly_the_headers_symbols():
+    """-fvisibility=hidden + exports.map: the dynamic symbol table holds the C ABI and nothing else (it
+    used to export launchers and mangled C++)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", hlib.LIB_PATH], check=True, stdout=subprocess.PIPE, text=True).stdout
+    exported = sorted(l.split()[-1] for l in out.splitlines() if l.strip())
+    assert exported == _declared_symbols()
 
 
 def test_reference_symbols_present():
