@@ -380,6 +380,123 @@ static rans4x16_hip_ctx *thread_ctx()
     return h.c;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The combiner behind the single-block entry points.  A CRAM reader / writer calls rans_compress_to_4x16 or
+// rans_uncompress_to_4x16 once per block from a pool of host threads.  One block is four chains: a GPU
+// call for it costs its chain latency (25-50 ms for 1 MiB) whatever else the card does, and thirty-two threads each
+// driving their own copies and launches mostly wait for the runtime's locks (measured: 278 ms per call).  So calls
+// that arrive together are served together: a caller queues its block and sleeps; a worker thread takes everything
+// queued for its direction (after a short gathering window once the first request is in), runs ONE host batch on
+// its own context and wakes each caller with its own result.  Two workers per direction, so that the next batch is
+// gathered and copied in while the previous one computes.
+//   R4X16_COMBINE=0           calls go straight to a per-thread context, as before
+//   R4X16_COMBINE_WINDOW_US   gathering window (default 200)      R4X16_COMBINE_MAX  blocks per batch (default 256)
+// ---------------------------------------------------------------------------------------------
+#include <condition_variable>
+#include <deque>
+#include <memory>
+struct CombReq {
+    const unsigned char *in; unsigned int in_size;
+    unsigned char *out; unsigned int cap;
+    int order;
+    unsigned int result = 0;
+    int rc = -1;                               // 0 ok, 1 block failed, -1 batch failed
+    bool done = false;
+};
+struct Combiner {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<CombReq *> q[2];                // [0] encode, [1] decode
+    int device = 0;
+    bool started = false, stop = false;
+    long window_us = 200, max_batch = 256;
+
+    void worker(int dir)
+    {
+        if (hipSetDevice(device) != hipSuccess) return;
+        rans4x16_hip_ctx *c = rans4x16_hip_create(device);
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_work.wait(lk, [&] { return stop || !q[dir].empty(); });
+            if (stop) break;
+            if ((long)q[dir].size() < max_batch && window_us > 0) {
+                // more callers may be a few microseconds behind: give them the window
+                cv_work.wait_for(lk, std::chrono::microseconds(window_us), [&] { return stop || (long)q[dir].size() >= max_batch; });
+                if (stop) break;
+            }
+            std::vector<CombReq *> batch;
+            while (!q[dir].empty() && (long)batch.size() < max_batch) { batch.push_back(q[dir].front()); q[dir].pop_front(); }
+            lk.unlock();
+            const int n = (int)batch.size();
+            std::vector<const unsigned char *> in(n);
+            std::vector<unsigned char *> out(n);
+            std::vector<unsigned int> isz(n), osz(n);
+            std::vector<int> ord(n), st(n, 0);
+            for (int i = 0; i < n; i++) { in[i] = batch[i]->in; out[i] = batch[i]->out; isz[i] = batch[i]->in_size; osz[i] = batch[i]->cap; ord[i] = batch[i]->order; }
+            const int rc = c ? r4x16_run_host_batch(c, n, dir == 1, in.data(), isz.data(), out.data(), osz.data(), dir == 0 ? ord.data() : nullptr, st.data()) : -1;
+            if (c) r4x16_trim(c, (size_t)4 << 30);
+            lk.lock();
+            for (int i = 0; i < n; i++) {
+                batch[i]->rc = rc < 0 ? -1 : (st[i] != 0 ? 1 : 0);
+                batch[i]->result = rc < 0 ? 0u : osz[i];
+                batch[i]->done = true;
+            }
+            cv_done.notify_all();
+        }
+        lk.unlock();
+        rans4x16_hip_destroy(c);
+    }
+    int submit(CombReq &r, int dir)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        if (!started) {
+            started = true;
+            const char *w = getenv("R4X16_COMBINE_WINDOW_US"), *m = getenv("R4X16_COMBINE_MAX");
+            if (w && *w) window_us = atol(w);
+            if (m && *m && atol(m) > 0) max_batch = atol(m);
+            // (detached, and the combiner itself is never destroyed: tearing GPU contexts down from static destructors
+            //  at process exit races the runtime's own shutdown)
+            for (int d = 0; d < 2; d++) for (int k = 0; k < 2; k++) std::thread([this, d] { worker(d); }).detach();
+        }
+        q[dir].push_back(&r);
+        cv_work.notify_all();
+        cv_done.wait(lk, [&] { return r.done; });
+        return r.rc;
+    }
+};
+// one combiner per device (a caller's current device decides, as it did for its per-thread context)
+static Combiner *combiner_for_current_device()
+{
+    static const bool enabled = !(getenv("R4X16_COMBINE") && atoi(getenv("R4X16_COMBINE")) == 0);
+    if (!enabled) return nullptr;
+    int ndev = 0, dev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    static std::mutex mu;
+    static Combiner *per_dev[64];
+    std::lock_guard<std::mutex> g(mu);
+    if (!per_dev[dev]) { per_dev[dev] = new Combiner(); per_dev[dev]->device = dev; }
+    return per_dev[dev];
+}
+// one block through the combiner (or, with R4X16_COMBINE=0, through this thread's own context); 0 = ok
+static int single_block(bool decode, const unsigned char *in, unsigned int in_size, unsigned char *out, unsigned int *out_size, int order)
+{
+    if (Combiner *cb = combiner_for_current_device()) {
+        CombReq r;
+        r.in = in; r.in_size = in_size; r.out = out; r.cap = *out_size; r.order = order;
+        const int rc = cb->submit(r, decode ? 1 : 0);
+        *out_size = r.result;
+        return rc;
+    }
+    rans4x16_hip_ctx *c = thread_ctx();
+    if (!c) return -1;
+    const unsigned char *ins[1] = { in };
+    unsigned char *outs[1] = { out };
+    unsigned int isz[1] = { in_size };
+    int ord[1] = { order };
+    const int rc = r4x16_run_host_batch(c, 1, decode, ins, isz, outs, out_size, decode ? nullptr : ord, nullptr);
+    r4x16_trim(c, SINGLE_CALL_KEEP);
+    return rc;
+}
 extern "C" unsigned int rans_compress_bound_4x16(unsigned int size, int order)
 {
     return r4x16_compress_bound(size, order);
@@ -388,20 +505,13 @@ extern "C" unsigned int rans_compress_bound_4x16(unsigned int size, int order)
 extern "C" unsigned char *rans_compress_to_4x16(unsigned char *in, unsigned int in_size,
                                                 unsigned char *out, unsigned int *out_size, int order)
 {
-    rans4x16_hip_ctx *c = thread_ctx();
-    if (!c || !out_size) return nullptr;
+    if (!out_size) return nullptr;
     unsigned char *mine = nullptr;
     if (!out) {
         *out_size = rans_compress_bound_4x16(in_size, order);
         if (!(out = mine = (unsigned char *)malloc(*out_size))) return nullptr;
     }
-    const unsigned char *ins[1] = { in };
-    unsigned char *outs[1] = { out };
-    unsigned int isz[1] = { in_size };
-    int ord[1] = { order };
-    const int rc = r4x16_run_host_batch(c, 1, false, ins, isz, outs, out_size, ord, nullptr);
-    r4x16_trim(c, SINGLE_CALL_KEEP);
-    if (rc != 0) { free(mine); return nullptr; }
+    if (single_block(false, in, in_size, out, out_size, order) != 0) { free(mine); return nullptr; }
     return out;
 }
 
@@ -427,8 +537,7 @@ static int peek_size(const unsigned char *in, unsigned int in_size, unsigned int
 extern "C" unsigned char *rans_uncompress_to_4x16(unsigned char *in, unsigned int in_size,
                                                   unsigned char *out, unsigned int *out_size)
 {
-    rans4x16_hip_ctx *c = thread_ctx();
-    if (!c || !out_size || in_size == 0) return nullptr;
+    if (!out_size || in_size == 0) return nullptr;
     unsigned char *mine = nullptr;
     if (!out) {
         unsigned int usz;
@@ -437,12 +546,7 @@ extern "C" unsigned char *rans_uncompress_to_4x16(unsigned char *in, unsigned in
         if (!(out = mine = (unsigned char *)malloc(usz ? usz : 1))) return nullptr;
         *out_size = usz;
     }
-    const unsigned char *ins[1] = { in };
-    unsigned char *outs[1] = { out };
-    unsigned int isz[1] = { in_size };
-    const int rc = r4x16_run_host_batch(c, 1, true, ins, isz, outs, out_size, nullptr, nullptr);
-    r4x16_trim(c, SINGLE_CALL_KEEP);
-    if (rc != 0) { free(mine); return nullptr; }
+    if (single_block(true, in, in_size, out, out_size, 0) != 0) { free(mine); return nullptr; }
     return out;
 }
 

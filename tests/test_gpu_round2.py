@@ -228,3 +228,33 @@ def test_bench_launches_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["blocks_per_gpu"] == 600
     assert out["value"] > 0 and out["roofline"]["achieved"] > 0
+
+
+def test_single_block_calls_from_a_thread_pool_are_combined(H, oracle):
+    """The literal drop-in case: 24 host threads each calling rans_compress_to_4x16 /
+    rans_uncompress_to_4x16 block by block.  Calls that arrive together are served by one device batch
+    (r4x16_api.hip: Combiner); every caller must get its own, reference-identical result - mixed sizes, orders,
+    stripe blocks, and one caller whose stream is damaged."""
+    from concurrent.futures import ThreadPoolExecutor
+    rs = np.random.RandomState(2424)
+    names = ["q4", "q8", "q40+dir", "qvar"]
+    jobs = []
+    for t in range(24):
+        blocks = [datagen.tile(names[(t + k) % 4], int(rs.choice([100, 5000, 65536, 300000])), t * 7 + k).tobytes() for k in range(5)]
+        orders = [int(rs.choice([0, 1, 65, 193, 9])) for _ in blocks]
+        jobs.append((blocks, orders))
+
+    def work(job):
+        blocks, orders = job
+        for d, o in zip(blocks, orders):
+            c = H.rans_compress_4x16(d, o)
+            if c != oracle.compress(d, o):
+                return False
+            if H.rans_uncompress_4x16(c) != d:
+                return False
+            if H.rans_uncompress_4x16(c[:max(1, len(c) // 2)], len(d)) != oracle.uncompress(c[:max(1, len(c) // 2)], capacity=len(d), out_size_hint=len(d)):
+                return False
+        return True
+
+    with ThreadPoolExecutor(24) as ex:
+        assert all(ex.map(work, jobs))
