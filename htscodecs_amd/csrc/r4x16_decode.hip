@@ -1192,20 +1192,24 @@ __device__ bool rle_expand(const u8 *lit, u32 lit_len, const u8 *runs, u32 run_l
         // rle.c:165, :173: every literal needs room, a run needs room for all of it
         const bool bad = valid && (oi >= cap || (runval && oi + runval >= cap));
         if (__ballot(bad)) { err = true; break; }
-        B.pfx[lane] = (u32)excl;
-        B.lb[lane] = (u8)bval;
-        const u32 nvalid = (u32)__popcll(__ballot(valid));
-        __syncthreads();
-        u8 *o = out + outp;
-        for (u32 k = lane; k < (u32)total; k += WAVE) {
-            u32 lo = 0, hi = nvalid - 1;                   // largest j with pfx[j] <= k
-            while (lo < hi) {
-                const u32 mid = (lo + hi + 1) >> 1;
-                if (B.pfx[mid] <= k) lo = mid; else hi = mid - 1;
-            }
-            o[k] = B.lb[lo];
+        // Every lane writes its own literal and, when its run is short (nearly all are: quality data has runs of a few
+        // bytes), the run behind it; the few long runs are then filled by the whole wave, one after the other.
+        // (The first version balanced every output byte over the lanes by a binary search over the trip's prefix
+        //  sums: six dependent LDS reads per byte, ~85 % of this kernel on q4 with X_PACK|X_RLE.)
+        u8 *o = out + outp + excl;
+        const u32 rv = valid ? runval : 0u;
+        if (valid) o[0] = (u8)bval;
+        if (rv && rv <= 24u)
+            for (u32 k = 1; k <= rv; k++) o[k] = (u8)bval;
+        u64 longm = __ballot(rv > 24u);
+        while (longm) {
+            const int src = __ffsll((unsigned long long)longm) - 1;
+            longm &= longm - 1;
+            const u64 at = __shfl(excl, src);
+            const u32 len = (u32)__shfl((int)rv, src), bv = (u32)__shfl((int)bval, src);
+            u8 *ro = out + outp + at + 1;
+            for (u32 k = lane; k < len; k += WAVE) ro[k] = (u8)bv;
         }
-        __syncthreads();
         outp += total;
     }
     produced = (u32)outp;
@@ -1223,6 +1227,39 @@ __device__ bool unpack(const u8 *data, u32 len, u8 *out, u32 out_len, u32 per, B
     }
     if ((out_len + per - 1) / per > len) return false;
     const u32 width = 8 / per, mask = (1u << width) - 1u;
+    if (per == 4 || per == 8) {
+        // <= 4 symbols: the map fits one register and v_perm_b32 is the look-up: a packed byte's four 2-bit codes are
+        // spread into the four selector bytes by one multiply and one mask (b * 0x41041 = b | b << 6 | b << 12 | b << 18).
+        // Sixteen (per == 4) or thirty-two output bytes per lane and trip from one packed dword.
+        const u32 m4 = (u32)B.map[0] | ((u32)B.map[1] << 8) | ((u32)B.map[2] << 16) | ((u32)B.map[3] << 24);
+        const u32 in_per = 4u, out_per = in_per * per;                       // bytes in / out per lane and trip
+        const u32 trips = out_len / out_per;
+        for (u32 t = lane; t < trips; t += WAVE) {
+            const u32 w = *(const u32_unaligned *)(data + 4ull * t);
+            u8 *o = out + (u64)out_per * t;
+            if (per == 4) {
+                u32x4 v;
+                v.x = __builtin_amdgcn_perm(m4, m4, __umul24(w & 0xffu, 0x41041u) & 0x03030303u);
+                v.y = __builtin_amdgcn_perm(m4, m4, __umul24((w >> 8) & 0xffu, 0x41041u) & 0x03030303u);
+                v.z = __builtin_amdgcn_perm(m4, m4, __umul24((w >> 16) & 0xffu, 0x41041u) & 0x03030303u);
+                v.w = __builtin_amdgcn_perm(m4, m4, __umul24(w >> 24, 0x41041u) & 0x03030303u);
+                *(u32x4_unaligned *)o = v;
+            } else {
+                // eight 1-bit codes per byte: two selector dwords per packed byte (b * 0x204081 spreads bits 0..3 to bytes)
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++) {
+                    const u32 b = (w >> (8 * bb)) & 0xffu;
+                    u32x2 v;
+                    v.x = __builtin_amdgcn_perm(m4, m4, __umul24(b & 15u, 0x204081u) & 0x01010101u);
+                    v.y = __builtin_amdgcn_perm(m4, m4, __umul24(b >> 4, 0x204081u) & 0x01010101u);
+                    *(u32x2_unaligned *)(o + 8 * bb) = v;
+                }
+            }
+        }
+        for (u32 i = trips * out_per + lane; i < out_len; i += WAVE)
+            out[i] = B.map[(data[i / per] >> ((i % per) * width)) & mask];
+        return true;
+    }
     const u32 ndw = out_len >> 2;
     for (u32 w = lane; w < ndw; w += WAVE) {
         u32 v = 0;

@@ -1317,7 +1317,9 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
         if (n == 0) flags &= ~(u32)X_PACK;
         else {
             u8 *pbuf = ws.packed + (u64)b * ws.xf_stride;
-            wg_hist8(data, n, S.F, (u32 *)dyn, tid);
+            // hts_pack only asks WHICH bytes occur (pack.c:62-75): the presence pass, plain byte stores, instead of the
+            // counting histogram, whose LDS atomics all but serialise on the two to sixteen symbols PACK is made for
+            wg_present8(data, n, S.F, S.pmask, tid);
             wg_pack(data, n, D->hdr + hl, pbuf, S, tid);
             if (S.pk_meta_len == 1 && S.pk_n != 256) flags &= ~(u32)X_PACK;    // > 16 symbols (:1249); 256 wraps to 0 and stays
             else {
