@@ -1228,8 +1228,8 @@ __device__ bool unpack(const u8 *data, u32 len, u8 *out, u32 out_len, u32 per, B
     if ((out_len + per - 1) / per > len) return false;
     const u32 width = 8 / per, mask = (1u << width) - 1u;
     if (per == 4 || per == 8) {
-        // <= 4 symbols: the map fits one register and v_perm_b32 is the look-up: a packed byte's four 2-bit codes are
-        // spread into the four selector bytes by one multiply and one mask (b * 0x41041 = b | b << 6 | b << 12 | b << 18).
+        // <= 4 symbols: the map fits one register and v_perm_b32 is the look-up, its selector the packed byte's codes
+        // spread one per byte.
         // Sixteen (per == 4) or thirty-two output bytes per lane and trip from one packed dword.
         const u32 m4 = (u32)B.map[0] | ((u32)B.map[1] << 8) | ((u32)B.map[2] << 16) | ((u32)B.map[3] << 24);
         const u32 in_per = 4u, out_per = in_per * per;                       // bytes in / out per lane and trip
@@ -1238,11 +1238,14 @@ __device__ bool unpack(const u8 *data, u32 len, u8 *out, u32 out_len, u32 per, B
             const u32 w = *(const u32_unaligned *)(data + 4ull * t);
             u8 *o = out + (u64)out_per * t;
             if (per == 4) {
+                // byte b -> selector bytes (b & 3, b >> 2 & 3, b >> 4 & 3, b >> 6): nibbles to bits 0 and 16, then pairs
+                // to every byte (two shift-ors and two masks; the shifted copies never overlap)
+                auto sel4 = [](u32 b) -> u32 { const u32 x = (b | (b << 12)) & 0x000f000fu; return (x | (x << 6)) & 0x03030303u; };
                 u32x4 v;
-                v.x = __builtin_amdgcn_perm(m4, m4, __umul24(w & 0xffu, 0x41041u) & 0x03030303u);
-                v.y = __builtin_amdgcn_perm(m4, m4, __umul24((w >> 8) & 0xffu, 0x41041u) & 0x03030303u);
-                v.z = __builtin_amdgcn_perm(m4, m4, __umul24((w >> 16) & 0xffu, 0x41041u) & 0x03030303u);
-                v.w = __builtin_amdgcn_perm(m4, m4, __umul24(w >> 24, 0x41041u) & 0x03030303u);
+                v.x = __builtin_amdgcn_perm(m4, m4, sel4(w & 0xffu));
+                v.y = __builtin_amdgcn_perm(m4, m4, sel4((w >> 8) & 0xffu));
+                v.z = __builtin_amdgcn_perm(m4, m4, sel4((w >> 16) & 0xffu));
+                v.w = __builtin_amdgcn_perm(m4, m4, sel4(w >> 24));
                 *(u32x4_unaligned *)o = v;
             } else {
                 // eight 1-bit codes per byte: two selector dwords per packed byte (b * 0x204081 spreads bits 0..3 to bytes)
