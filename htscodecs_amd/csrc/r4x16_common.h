@@ -114,12 +114,17 @@ static inline __host__ __device__ u32 img_bytes(u32 n, u32 rows) { return img_al
 //       dword 1 + i  : L[3i], L[3i + 1], L[3i + 2]       (group g is dwords 1 + 4g .. 1 + 4g + 4)
 //   G = ceil(n / 12) groups, 4G + 2 dwords (4G + 1 unless n = 12G): 68 bytes for 46 symbols against 108 of the u16 rows.
 // ---------------------------------------------------------------------------------------------
-#define PK_MAX_NSYM 48u
-#define PK_FIRST_SHIFT 10
-static inline __host__ __device__ u32 pk_groups(u32 n) { return n <= 12 ? 1u : n <= 24 ? 2u : n <= 36 ? 3u : 4u; }
+#define PK_MAX_NSYM 48u                                  // one root dword: up to four groups of twelve
+#define PKW_MAX_NSYM 96u                                 // "wide" packed rows: up to eight groups, 16-byte root
+#define PK_FIRST_SHIFT 9                                 // `first` in bits 9..15 of the alpha word
+static inline __host__ __device__ u32 pk_groups(u32 n) { return (n + 11u) / 12u; }
+// Wide rows (49..96 symbols: what X_PACK makes of a four- or six-letter quality alphabet): the same leaf, and a
+// root of eight u16 separators L[12 k] + 1 (0x7fff beyond the last group) counted with the u16 rows' compare-free
+// count_le: two 8-byte reads instead of one dword.  80 symbols: 128-byte rows against 224 of the 3-read u16 rows.
+static inline __host__ __device__ u32 pk_root_bytes(u32 n) { return n > PK_MAX_NSYM ? 16u : 4u; }
 // (the last dword, L[12G ..], can only be selected when the alphabet fills its last group: left out otherwise, and
 //  that read runs into the next row's root or the word ring - as with the u16 rows' last dword)
-static inline __host__ __device__ u32 pk_row_bytes(u32 n) { return 8u + 16u * pk_groups(n) - (n % 12u ? 4u : 0u); }
+static inline __host__ __device__ u32 pk_row_bytes(u32 n) { return pk_root_bytes(n) + 4u + 16u * pk_groups(n) - (n % 12u ? 4u : 0u); }
 static inline __host__ __device__ u32 pk_img_bytes(u32 n) { return img_alpha_bytes(n) + n * pk_row_bytes(n); }
 
 #define IMG_O0_BYTES  1344u                       // 256 symbols, one row
@@ -142,7 +147,7 @@ struct DecItem {
     u32 packed;      // 1: packed 10-bit rows (level 1), 0: u16 rows of img_levels(nsym) levels
     u32 pad;
 };
-static inline __host__ __device__ u32 item_levels(u32 nsym, u32 packed) { return packed ? 1u : img_levels(nsym); }
+static inline __host__ __device__ u32 item_levels(u32 nsym, u32 packed) { return packed ? (nsym > PK_MAX_NSYM ? 5u : 1u) : img_levels(nsym); }
 
 // Per-block record of the decode pipeline.
 struct DecDesc {
@@ -233,7 +238,7 @@ struct EncDesc {
 #define DEC_IMG_SLOT   (IMG_MAX_BYTES + 2u * IMG_O0_BYTES)   // payload image, nested-table image, RLE-meta image
 #define TAB_BYTES      198656u                          // >= 1 + 257*257*3 (assert at rANS_static4x16pr.c:784)
 
-#define CLS_MAX  32u
+#define CLS_MAX  48u
 #define CLS_NONE 0xffffffffu
 struct DecWs {
     DecDesc *desc;     // [nblk]

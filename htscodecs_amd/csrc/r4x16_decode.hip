@@ -129,17 +129,27 @@ __device__ __forceinline__ u32 lookup_step(const IMG &img, u32 row, u32 look, u3
 // 21: adding GM = guards - (m | m << 11 | m << 22) leaves guard bit i set exactly when field i >= m (a field plus
 // 1024 minus m stays inside its eleven bits), so two "field < m" tests cost one add, one and, one popcount.
 // Returns the compact symbol index; x becomes freq * (x >> 10) + m - start.
-__device__ __forceinline__ u32 lookup_step_pk(u32 row, u32 root, u32 first, u32 &x)
+// WIDE: 49..96 symbols, root = eight u16 separators L[12 k] + 1 (r4x16_common.h), counted like the u16 rows' roots.
+template <bool WIDE>
+__device__ __forceinline__ u32 lookup_step_pk(u32 row, u32x2 rootv, u32x2 rootw, u32 first, u32 &x)
 {
     const LImg img0{0u};
     const u32 GB = 0x00200400u;
     const u32 m = x & 1023u;
     const u32 GM = GB - __umul24(m, 0x400801u);
-    // group of twelve: #{L[12], L[24], L[36]} below m
-    const u32 gneg = __popc((root + GM) & GB);                // 2 - #{L[12], L[24] < m}
-    const bool r3 = root < (m << 22);                         // L[36] < m: the top field needs no guard
-    const u32 g = (r3 ? 3u : 2u) - gneg;
-    const u32 ga = row + 4u + 16u * g;
+    u32 g, ga;
+    if (WIDE) {
+        const u32 mm = __umul24(m, 0x10001u) + 0x80008000u;
+        g = count_le(mm, rootv) + count_le(mm, rootw);        // #{k : L[12 k] < m}
+        ga = row + 16u + 16u * g;
+    } else {
+        // group of twelve: #{L[12], L[24], L[36]} below m
+        const u32 root = rootv.x;
+        const u32 gneg = __popc((root + GM) & GB);            // 2 - #{L[12], L[24] < m}
+        const bool r3 = root < (m << 22);                     // L[36] < m: the top field needs no guard
+        g = (r3 ? 3u : 2u) - gneg;
+        ga = row + 4u + 16u * g;
+    }
     const u32 D0 = img0.ld32(ga), D1 = img0.ld32(ga + 4), D2 = img0.ld32(ga + 8), D3 = img0.ld32(ga + 12),
               D4 = img0.ld32(ga + 16);
     // dword of three: the low fields of D1, D2, D3 are L[12g + 3], L[12g + 6], L[12g + 9]
@@ -256,7 +266,8 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     const LImg img0{0u};                                   // row reads: `row` is an absolute LDS address
     const u32 k = lane & 3;
     const u32 mask = (1u << look) - 1;
-    const u32 rows = lds_addr(img_lds) + img_alpha_bytes(nsym), roww = LV == 1 ? pk_row_bytes(nsym) : img_row_bytes(nsym);
+    constexpr bool PKD = LV == 1 || LV == 5, WIDE = LV == 5;       // packed rows (r4x16_common.h), with the 16-byte root
+    const u32 rows = lds_addr(img_lds) + img_alpha_bytes(nsym), roww = PKD ? pk_row_bytes(nsym) : img_row_bytes(nsym);
     const u32 nwords = words_len >> 1;
     const u32 below = (1u << k) - 1u;                      // quad lanes below this one
     u32 count;
@@ -301,11 +312,12 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     // root separators of `row`, read as soon as the row is known (one step ahead of their use,
     // so that this LDS round trip runs beside the renormalisation instead of after it)
     u32x2 root = LV == 1 ? u32x2{img0.ld32(row), 0u} : img0.ld64(row);
+    u32x2 root2 = WIDE ? img0.ld64(row + 8) : u32x2{0u, 0u};
     u32 acc = 0;                                          // order-1: the last (up to) 4 decoded bytes
     u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;                   // order-1: completed dwords not yet stored (a3 newest)
     u32 hdr = 0, hdr_even = 0;                            // order-1: alpha[] word of the symbol decoded last step
     if (ORDER == 1 && count) bad = img.ld16(0);
-    if (LV == 1) hdr = img.ld16(0);                       // packed rows: bits 10.. of the context's alpha word = its `first`
+    if (PKD) hdr = img.ld16(0);                           // packed rows: bits 9.. of the context's alpha word = its `first`
 
     // Four steps per trip: one loop test, one store and one ring check per trip.  A trip in which
     // every stream of the wave is still running on all four chains and has at least 16 words left
@@ -331,14 +343,19 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             RootSpec spec;
             spec.rows = rows; spec.roww = roww;
             const bool speculate = ORDER == 1 && LV == 2;
-            u32 s, rown1 = 0, rootn1 = 0;
-            if (LV == 1) {
-                s = lookup_step_pk(row, root.x, hdr >> PK_FIRST_SHIFT, xn);
+            u32 s, rown1 = 0;
+            u32x2 rootn1 = {0u, 0u}, rootn2 = {0u, 0u};
+            if (PKD) {
+                s = lookup_step_pk<WIDE>(row, root, root2, hdr >> PK_FIRST_SHIFT, xn);
                 // the next row's root: requested as soon as the symbol is known, used at the top of the next step
                 asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(rown1) : "v"(s), "v"(roww), "v"(rows));   // (the compiler's own choice is a 64-bit multiply-add)
-                rootn1 = *(LAS const volatile u32 *)(unsigned long)rown1;
+                if (WIDE) {
+                    rootn1 = *(LAS const volatile u32x2_a4 *)(unsigned long)rown1;
+                    rootn2 = *(LAS const volatile u32x2_a4 *)(unsigned long)(rown1 + 8u);
+                } else
+                    rootn1.x = *(LAS const volatile u32 *)(unsigned long)rown1;
             } else {
-                s = lookup_step<(LV == 1 ? 2 : LV)>(img0, row, look, mask, xn, LV == 2 ? &root : nullptr, speculate ? &spec : nullptr);
+                s = lookup_step<(PKD ? 2 : LV)>(img0, row, look, mask, xn, LV == 2 ? &root : nullptr, speculate ? &spec : nullptr);
             }
             const u32 hn = img.ld16(2 * s);               // byte value | ROW_EMPTY of the new context
             u32 byte0 = 0;
@@ -365,9 +382,14 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
                     }
                 }
                 hdr = live ? hn : hdr;
-                if (LV == 1) {
+                if (PKD) {
                     row = live ? rown1 : row;
-                    root.x = live ? rootn1 : root.x;
+                    root.x = live ? rootn1.x : root.x;
+                    if (WIDE) {
+                        root.y = live ? rootn1.y : root.y;
+                        root2.x = live ? rootn2.x : root2.x;
+                        root2.y = live ? rootn2.y : root2.y;
+                    }
                 } else if (speculate) {
                     const u32 rown = spec.rowE + (spec.up ? roww : 0u);
                     const u32x2 rootn = {spec.up ? spec.rb.x : spec.ra.x, spec.up ? spec.rb.y : spec.ra.y};
@@ -584,11 +606,17 @@ __device__ void write_row_pk(u8 *rowp, const FrontShared &S, u32 n, bool empty, 
         const u32 idx = first + j;
         return idx <= n ? (u32)S.cum[idx] - 1u : 1023u;       // cum[first + 1 ..] >= 1: `first` has a frequency
     };
-    const u32 ndw = pk_row_bytes(n) / 4u;
+    const u32 ndw = pk_row_bytes(n) / 4u, rdw = pk_root_bytes(n) / 4u;
     if (lane < ndw) {
         u32 v;
-        if (lane == 0) v = L(12) | (L(24) << 11) | (L(36) << 22);
-        else { const u32 i = 3u * (lane - 1u); v = L(i) | (L(i + 1) << 11) | (L(i + 2) << 22); }
+        if (lane < rdw) {
+            if (rdw == 1) v = L(12) | (L(24) << 11) | (L(36) << 22);
+            else {
+                // wide root: u16 separators L[12 k] + 1 for k = 2 lane + 1, 2 lane + 2; beyond the last group: never <= m
+                auto sep = [&](u32 k) -> u32 { return (!empty && first + 12u * k <= n) ? L(12u * k) + 1u : 0x7fffu; };
+                v = sep(2u * lane + 1u) | (sep(2u * lane + 2u) << 16);
+            }
+        } else { const u32 i = 3u * (lane - rdw); v = L(i) | (L(i + 1) << 11) | (L(i + 2) << 22); }
         ((u32 *)rowp)[lane] = v;
     }
 }
@@ -899,7 +927,7 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
 
     const u32 nsym = S.nsym;
     // 10-bit tables of quality-sized alphabets take the packed rows (smaller images: more streams per CU)
-    const bool packed = bits == 10 && nsym >= PK_MIN_NSYM && nsym <= PK_MAX_NSYM;
+    const bool packed = bits == 10 && nsym >= PK_MIN_NSYM && nsym <= PKW_MAX_NSYM;
     const u32 stride = packed ? pk_row_bytes(nsym) : img_row_bytes(nsym);
     u8 *rows0 = img + img_alpha_bytes(nsym);
 
@@ -1105,12 +1133,12 @@ __global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDes
         u8 *ring = lds + (u64)quad * lds_per_item + (lds_per_item - RING_BYTES);
         // order-0 and order-1 streams may share a wave: run the two loops back to back
         bad = chain_decode_lds<1, LV>(im, nsym, ring, words, words_len, out, out_sz, x0, look, active && order == 1, lane);
-        if (LV != 1)                                          // packed rows exist for order-1 streams only
-            bad |= chain_decode_lds<0, (LV == 1 ? 2 : LV)>(im, nsym, ring, words, words_len, out, out_sz, x0, look, active && order == 0, lane);
+        if (LV != 1 && LV != 5)                               // packed rows exist for order-1 streams only
+            bad |= chain_decode_lds<0, ((LV == 1 || LV == 5) ? 2 : LV)>(im, nsym, ring, words, words_len, out, out_sz, x0, look, active && order == 0, lane);
     } else {
         GImg im{(gcu8 *)I->image};                            // (never level 1: packed images always fit a class)
-        bad = chain_decode<1, (LV == 1 ? 2 : LV)>(im, nsym, words, words_len, out, out_sz, x0, look, active && order == 1, lane);
-        bad |= chain_decode<0, (LV == 1 ? 2 : LV)>(im, nsym, words, words_len, out, out_sz, x0, look, active && order == 0, lane);
+        bad = chain_decode<1, ((LV == 1 || LV == 5) ? 2 : LV)>(im, nsym, words, words_len, out, out_sz, x0, look, active && order == 1, lane);
+        bad |= chain_decode<0, ((LV == 1 || LV == 5) ? 2 : LV)>(im, nsym, words, words_len, out, out_sz, x0, look, active && order == 0, lane);
     }
     if (active && bad) desc[I->blk].status = ST_CONTEXT;
     __syncthreads();                                       // LDS is reused by the next share
@@ -1349,6 +1377,8 @@ static const struct { u32 bytes; int qpw; int lv; } DEC_CLASSES[] = {
     // packed rows (level 1): 13..36 symbols in rows of up to 56 bytes, 37..48 of up to 72 (46 symbols: 68-byte rows,
     // 3,496 bytes with alphabet and ring: 3 x 15 streams per CU)
     {1424, 16, 1}, {2448, 16, 1}, {3344, 16, 1}, {3496, 15, 1}, {3856, 13, 1},
+    // wide packed rows (level 5): 49..96 symbols, rows of 84..148 bytes; three workgroups per CU
+    {5520, 9, 5}, {7184, 7, 5}, {8912, 6, 5}, {10640, 5, 5}, {13200, 4, 5}, {14736, 3, 5},
     {656, 16, 2}, {1296, 16, 2}, {2576, 16, 2}, {3856, 16, 2}, {5008, 16, 2}, {5360, 10, 2}, {5392, 15, 2}, {6416, 12, 2},
     // 51..150 symbols, 3 reads: one-row order-0 images, then order-1 images of 9..55 KB (one stream per wave,
     // as many waves per CU as LDS granules allow)
@@ -1418,7 +1448,7 @@ __global__ __launch_bounds__(256) void k_dec_classify(const DecItem *items, int 
         u32 c = CLS_NONE;
         if (I->active) {
             const u32 need = I->img_bytes + RING_BYTES, lv = item_levels(I->nsym, I->packed);
-            c = tab.n + (lv < 2u ? 0u : lv - 2u);               // catch-all of this depth (level 1 always fits a class)
+            c = tab.n + ((lv < 2u || lv > 4u) ? 0u : lv - 2u);  // catch-all of this depth (packed levels 1 and 5 always fit a class)
             for (u32 k = 0; k < tab.n; k++)
                 if (tab.lv[k] == lv && need <= tab.bytes[k]) { c = k; break; }   // classes of a depth ascend
             atomicAdd(&local[c], 1u);
@@ -1474,6 +1504,7 @@ extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t 
     }
     if (r4x16_first_on_device(1u)) {
         lds_limit((const void *)k_dec_chain<true, 1>, 163840);
+        lds_limit((const void *)k_dec_chain<true, 5>, 163840);
         lds_limit((const void *)k_dec_chain<true, 2>, 163840);
         lds_limit((const void *)k_dec_chain<true, 3>, 163840);
         lds_limit((const void *)k_dec_chain<true, 4>, 163840);
@@ -1488,7 +1519,7 @@ extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t 
         const size_t ldsb = (size_t)qpw * c.bytes;
         const int grid = r4x16_resident_grid(ldsb, 1, (nitems + qpw - 1) / qpw);
         void (*kern)(const DecItem *, DecDesc *, const u32 *, const u32 *, int, u32) =
-            c.lv == 1 ? k_dec_chain<true, 1> : c.lv == 2 ? k_dec_chain<true, 2> : c.lv == 3 ? k_dec_chain<true, 3> : k_dec_chain<true, 4>;
+            c.lv == 1 ? k_dec_chain<true, 1> : c.lv == 5 ? k_dec_chain<true, 5> : c.lv == 2 ? k_dec_chain<true, 2> : c.lv == 3 ? k_dec_chain<true, 3> : k_dec_chain<true, 4>;
         hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), ldsb, s, ws->items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci), qpw, c.bytes);
         ci++;
     }
@@ -1502,7 +1533,7 @@ extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t 
 extern "C" int r4x16_dec_residency(u32 nsym, int order, u32 bits, int *streams_per_wave, int *waves_per_cu)
 {
     if (nsym == 0 || nsym > 256) return -1;
-    const bool packed = order == 1 && bits == 10 && nsym >= PK_MIN_NSYM && nsym <= PK_MAX_NSYM;
+    const bool packed = order == 1 && bits == 10 && nsym >= PK_MIN_NSYM && nsym <= PKW_MAX_NSYM;
     const u32 lv = item_levels(nsym, packed ? 1u : 0u);
     const u32 need = (packed ? pk_img_bytes(nsym) : img_bytes(nsym, order ? nsym : 1u)) + RING_BYTES;
     for (const auto &c : DEC_CLASSES) {
