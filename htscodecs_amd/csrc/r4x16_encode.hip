@@ -1024,9 +1024,7 @@ __device__ void wg_pack(const u8 *data, u32 n, u8 *meta, u8 *out, EncShared &S, 
 }
 
 // rle_encode with automatic symbol choice, rle.c:48-138.  S.F holds the byte histogram.  The repeat
-// counts are taken by all threads; the back-to-front split is one wave's work (its bookkeeping is
-// serial from trip to trip) but it reads the input from LDS tiles that all threads stage, the next
-// tile travelling from HBM while the current one is swept.  `tiles`: 2 x (RLE_TILE + 32) bytes of LDS.
+// counts and the split are taken by all threads, each on its own chunk of the input.  `tiles`: 5 KB of LDS.
 // Results: S.rl_nsyms, S.rl_lits, S.rl_runs (bytes); symbols in S.alpha[0..nsyms).  Ends on a workgroup barrier.
 #define RLE_TILE 16384u
 __device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, EncShared &S, u8 *tiles, u32 tid)
@@ -1068,160 +1066,71 @@ __device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, 
     }
     __syncthreads();
 
-    // tiles from the top: tile covers data[tb, tt); LDS keeps the 16-byte phase of global memory and
-    // starts one byte early (the predecessor of the tile's first byte)
-    const u32 per_thread = (RLE_TILE + 32) / 16 / FRONT_THREADS + 1;     // 16-byte chunks per thread (5)
-    u32x4 stage[per_thread];
-    auto tile_bounds = [&](u32 k, u32 &tb, u32 &tt) { tt = n - k * RLE_TILE; tb = tt > RLE_TILE ? tt - RLE_TILE : 0; };
-    auto tile_fetch = [&](u32 k) {                        // global -> registers
-        u32 tb, tt; tile_bounds(k, tb, tt);
-        const u64 lo = (u64)(data + tb) - (tb ? 1 : 0);
-        const u64 a0 = lo & ~15ull, a1 = ((u64)(data + tt) + 15) & ~15ull;
-        const u32 chunks = (u32)((a1 - a0) >> 4);
+    // The split itself: every thread owns one contiguous chunk of the input and walks it twice.
+    //   walk A: literals in the chunk, the position of its first literal, the varint bytes of the runs that END inside
+    //           the chunk, and the run left open at its end (the chunk's last literal, if that is an RLE symbol);
+    //   between: the next literal after each chunk (a suffix minimum over the chunks' first literals) closes the open
+    //           runs, and exclusive sums over the chunks place every chunk's literals and run bytes;
+    //   walk B: the same walk, now writing.
+    // A byte is a literal unless it repeats an RLE symbol (rle.c:121-133); an RLE-symbol literal is followed, in the run
+    // stream, by varint(number of repeats behind it).  (The first version swept 16 KB LDS tiles from the top with five
+    // workgroup barriers per tile: 1.2 ms per 256 KiB, 69 % of k_enc_front on q4 with X_PACK|X_RLE; this form: see DESIGN 6.)
+    u32 *cF = (u32 *)tiles, *cL = cF + 256, *cV = cL + 256, *cP = cV + 256, *cN = cP + 256;   // first / literals / run bytes / open run / next literal
+    const u32 NONE = 0xffffffffu;
+    const u32 csz = ((n + FRONT_THREADS - 1) / FRONT_THREADS + 15u) & ~15u;            // chunk bytes, a multiple of 16
+    const u32 c0 = tid * csz < n ? tid * csz : n, c1 = c0 + csz < n ? c0 + csz : n;
+    // one walk; EMIT = false: count, EMIT = true: write at (lp, vp).  `open` = position of the RLE-symbol literal whose run is running.
+    auto walk = [&](auto emitc, u32 &nlit, u32 &first, u32 &vbytes, u32 &open, u8 *lp, u8 *vp) {
+        constexpr bool EMIT = decltype(emitc)::value;
+        u32 prev = c0 ? data[c0 - 1] : 256u;
+        for (u32 p0 = c0; p0 < c1; p0 += 16) {
+            const u32 cnt = c1 - p0 < 16 ? c1 - p0 : 16;
+            u32 w[4] = {0, 0, 0, 0};
+            if (cnt == 16) { const u32x4 v = *(const u32x4_unaligned *)(data + p0); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+            else for (u32 c = 0; c < cnt; c++) w[c >> 2] |= (u32)data[p0 + c] << (8 * (c & 3));
 #pragma unroll
-        for (u32 c = 0; c < per_thread; c++) {
-            const u32 ci = tid + c * FRONT_THREADS;
-            u32x4 v = {0, 0, 0, 0};
-            if (ci < chunks) v = *(const u32x4 *)(a0 + 16ull * ci);       // aligned; stays inside the 16-byte
-            stage[c] = v;                                                 // granules the block touches
+            for (int c = 0; c < 16; c++) {
+                const u32 cur = (w[c >> 2] >> (8 * (c & 3))) & 0xff;
+                if (c < (int)cnt) {
+                    const bool lit = cur != prev || !S.present[cur];
+                    if (lit) {
+                        const u32 at = p0 + (u32)c;
+                        if (open != NONE) {                                   // the run behind `open` ends here
+                            const u32 run = at - open - 1;
+                            if (EMIT) vp += var_put(vp, run); else vbytes += var_len(run);
+                        }
+                        open = S.present[cur] ? at : NONE;
+                        if (first == NONE) first = at;
+                        if (EMIT) *lp++ = (u8)cur; else nlit++;
+                    }
+                    prev = cur;
+                }
+            }
         }
+        if (EMIT && open != NONE) var_put(vp, cN[tid] - open - 1);            // the run that leaves the chunk
     };
-    auto tile_store = [&](u8 *buf) {                      // registers -> LDS
-#pragma unroll
-        for (u32 c = 0; c < per_thread; c++) {
-            const u32 ci = tid + c * FRONT_THREADS;
-            if (ci < (RLE_TILE + 32) / 16) *(u32x4 *)(buf + 16 * ci) = stage[c];
-        }
-    };
-    const u32 ntiles = (n + RLE_TILE - 1) / RLE_TILE;
-    u8 *bufs[2] = {tiles, tiles + RLE_TILE + 32};
-    tile_fetch(0);
-    tile_store(bufs[0]);
+    u32 nlit = 0, first = NONE, vbytes = 0, open = NONE;
+    walk(std::false_type{}, nlit, first, vbytes, open, nullptr, nullptr);
+    cF[tid] = first; cL[tid] = nlit; cV[tid] = vbytes; cP[tid] = open;
     __syncthreads();
-
-    // Per tile, 64-byte groups from the top (group 0 = the highest addresses), all four waves:
-    //   1. literal mask of every group (a byte is a literal unless it repeats an RLE symbol);
-    //   2. for every group the position of the nearest literal above it (one wave, a scan over the masks);
-    //   3. run lengths and varint sizes -> literals and run bytes per group;
-    //   4. prefix sums of those (one wave) -> where each group's output goes;
-    //   5. the literals and the run varints are written, every group at its final place.
-    // Only the three running values (next literal above, literals so far, run bytes so far) pass from
-    // tile to tile.  Steps 3 and 5 evaluate a group twice; that is cheaper than parking 16 KB of run lengths.
-    u8 *aux = tiles + 2 * (RLE_TILE + 32);
-    u64 *Lm = (u64 *)aux;                                 // [256] literal masks
-    u32 *NL = (u32 *)(aux + 2048);                        // [256] nearest literal above the group
-    u32 *GL = (u32 *)(aux + 3072), *GV = (u32 *)(aux + 4096);   // [256] literals / run bytes of the group
-    u32 *OL = (u32 *)(aux + 5120), *OV = (u32 *)(aux + 6144);   // [256] the same, summed over the groups above
-    u32 *car = (u32 *)(aux + 7168);                       // [3] next_lit, tile literals, tile run bytes
-    const u32 wv = tid >> 6;
-    u32 next_lit = n, nl = 0, nrb = 0;
-    for (u32 k = 0; k < ntiles; k++) {
-        if (k + 1 < ntiles) tile_fetch(k + 1);
-        u32 tb, tt; tile_bounds(k, tb, tt);
-        const u64 lo = (u64)(data + tb) - (tb ? 1 : 0);
-        // LDS address of data[i]: buf + (address of data[i] - a0)
-        LAS const u8 *img = (LAS const u8 *)bufs[k & 1] + (u32)(lo & 15ull) - tb + (tb ? 1 : 0);
-        const u32 G = (tt - tb + WAVE - 1) / WAVE;
-        auto group_base = [&](u32 j) -> u32 { const u32 top = tt - WAVE * j; return top - tb > WAVE ? top - WAVE : tb; };
-        auto group_cnt = [&](u32 j) -> u32 { const u32 top = tt - WAVE * j; return top - group_base(j); };
-        // (1)
-        for (u32 j = wv; j < G; j += FRONT_THREADS / WAVE) {
-            const u32 base = group_base(j), cnt = group_cnt(j);
-            const u32 i = base + lane;
-            const bool valid = lane < cnt;
-            const u32 cur = valid ? img[i] : 0u;
-            const u32 prev = (valid && i > 0) ? img[i - 1] : 256u;
-            const bool isl = valid && !(S.present[cur] && cur == prev);
-            const u64 L = __ballot(isl);
-            if (lane == 0) Lm[j] = L;
+    if (tid == 0) {
+        u32 nx = n;                                                            // next literal after the chunk
+        for (int t = FRONT_THREADS - 1; t >= 0; t--) { cN[t] = nx; if (cF[t] != NONE) nx = cF[t]; }
+        u32 al = 0, av = 0;
+        for (u32 t = 0; t < FRONT_THREADS; t++) {
+            const u32 v = cV[t] + (cP[t] != NONE ? var_len(cN[t] - cP[t] - 1) : 0u);
+            const u32 l = cL[t];
+            cL[t] = al; cV[t] = av;                                            // exclusive sums
+            al += l; av += v;
         }
-        __syncthreads();
-        // (2) lane l owns groups 4l .. 4l+3; "nearest literal above" runs down the groups
-        if (tid < WAVE) {
-            const u32 NONE = 0xffffffffu;
-            u32 low[4], last = NONE;
-#pragma unroll
-            for (u32 c = 0; c < 4; c++) {
-                const u32 j = 4 * lane + c;
-                const u64 L = j < G ? Lm[j] : 0ull;
-                low[c] = L ? group_base(j) + (u32)__ffsll((unsigned long long)L) - 1 : NONE;
-                if (low[c] != NONE) last = low[c];
-            }
-            // exclusive scan over lanes of "the last literal position seen so far"
-            u32 incl = last;
-#pragma unroll
-            for (int dd = 1; dd < WAVE; dd <<= 1) {
-                const u32 t2 = __shfl_up(incl, dd);
-                if (lane >= (u32)dd && incl == NONE) incl = t2;
-            }
-            u32 run = __shfl_up(incl, 1);
-            if (lane == 0) run = NONE;
-            if (run == NONE) run = next_lit;
-#pragma unroll
-            for (u32 c = 0; c < 4; c++) {
-                const u32 j = 4 * lane + c;
-                if (j < G) NL[j] = run;
-                if (low[c] != NONE) run = low[c];
-            }
-            const u32 fin = __shfl(incl, WAVE - 1);
-            if (lane == 0) car[0] = fin == NONE ? next_lit : fin;
-        }
-        __syncthreads();
-        // (3) and (5)
-        auto eval_group = [&](u32 j, bool write, u32 ol, u32 ov) {
-            const u32 base = group_base(j), cnt = group_cnt(j);
-            const u32 i = base + lane;
-            const bool valid = lane < cnt;
-            const u32 cur = valid ? img[i] : 0u;
-            const u64 L = Lm[j];
-            const bool isl = (L >> lane) & 1ull;
-            const u64 above = lane == WAVE - 1 ? 0ull : (L >> (lane + 1));
-            const u32 nxt = above ? i + (u32)__ffsll((unsigned long long)above) : NL[j];
-            const bool isr = isl && S.present[cur];
-            const u32 run = nxt - i - 1;
-            const u32 vl = isr ? var_len(run) : 0u;
-            u32 suf = vl, tot = 0;
-#pragma unroll
-            for (u32 kk = 1; kk <= 5; kk++) {
-                const u64 mk = __ballot(vl >= kk);
-                suf += lane == WAVE - 1 ? 0u : (u32)__popcll(mk >> (lane + 1));
-                tot += (u32)__popcll(mk);
-            }
-            if (!write) {
-                if (lane == 0) { GL[j] = (u32)__popcll(L); GV[j] = tot; }
-            } else {
-                if (isl) lits_end[-(long)(nl + ol + (u32)__popcll(above) + 1)] = (u8)cur;
-                if (isr) var_put(runs_end - (nrb + ov + suf), run);
-            }
-        };
-        for (u32 j = wv; j < G; j += FRONT_THREADS / WAVE) eval_group(j, false, 0, 0);
-        __syncthreads();
-        // (4) exclusive sums down the groups
-        if (tid < WAVE) {
-            u32 l4[4], v4[4], sl = 0, sv = 0;
-#pragma unroll
-            for (u32 c = 0; c < 4; c++) {
-                const u32 j = 4 * lane + c;
-                l4[c] = j < G ? GL[j] : 0u; v4[c] = j < G ? GV[j] : 0u;
-                sl += l4[c]; sv += v4[c];
-            }
-            const u32 il = wave_incl_scan(sl, lane), iv = wave_incl_scan(sv, lane);
-            u32 el = il - sl, ev = iv - sv;
-#pragma unroll
-            for (u32 c = 0; c < 4; c++) {
-                const u32 j = 4 * lane + c;
-                if (j < G) { OL[j] = el; OV[j] = ev; }
-                el += l4[c]; ev += v4[c];
-            }
-            if (lane == WAVE - 1) { car[1] = il; car[2] = iv; }
-        }
-        __syncthreads();
-        for (u32 j = wv; j < G; j += FRONT_THREADS / WAVE) eval_group(j, true, OL[j], OV[j]);
-        next_lit = car[0]; nl += car[1]; nrb += car[2];
-        if (k + 1 < ntiles) tile_store(bufs[(k + 1) & 1]);
-        __syncthreads();
+        S.rl_lits = al; S.rl_runs = av;
     }
-    if (tid == 0) { S.rl_lits = nl; S.rl_runs = nrb; }
+    __syncthreads();
+    {
+        const u32 nl_all = S.rl_lits, nv_all = S.rl_runs;
+        u32 d0 = 0, d1 = NONE, d2 = 0, op = NONE;
+        walk(std::true_type{}, d0, d1, d2, op, lits_end - nl_all + cL[tid], runs_end - nv_all + cV[tid]);
+    }
     __threadfence();
     __syncthreads();
 }
@@ -1242,6 +1151,23 @@ __device__ __forceinline__ double approx_log(double a)            // fast_log :6
     return (double)(bits - 4606921278410026770LL) * 1.539095918623324e-16;
 }
 
+// Phase timing of k_enc_front for variant builds (-DR4X16_PROF_FRONT; tools/front_phases.py): cycles of thread 0 between
+// stamps, summed over the blocks.  Not compiled into the product.
+#ifdef R4X16_PROF_FRONT
+__device__ unsigned long long g_front_prof[16];
+#define PROF_INIT unsigned long long prof_t = tid == 0 ? (unsigned long long)wall_clock64() : 0ull
+#define PROF(k) do { if (tid == 0) { const unsigned long long n_ = (unsigned long long)wall_clock64(); atomicAdd(&g_front_prof[k], n_ - prof_t); prof_t = n_; } } while (0)
+extern "C" __attribute__((visibility("default"))) int rans4x16_hip_debug_front_prof(unsigned long long *out16, int reset)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_front_prof), sizeof(g_front_prof)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_front_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define PROF_INIT
+#define PROF(k)
+#endif
+
 __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs ws, int base)
 {
     extern __shared__ __attribute__((aligned(16))) u8 dyn[];
@@ -1256,6 +1182,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
     const bool w0 = tid < WAVE;
     const u32 b = blockIdx.x;
     const int i = base + (int)b;
+    PROF_INIT;
     EncDesc *D = &ws.desc[b];
     EncItem *I0 = &ws.items[b], *I1 = &ws.items[gridDim.x + b];   // payload items first, meta items after
     const u8 *in = a.in + a.in_off[i];
@@ -1319,8 +1246,11 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
             u8 *pbuf = ws.packed + (u64)b * ws.xf_stride;
             // hts_pack only asks WHICH bytes occur (pack.c:62-75): the presence pass, plain byte stores, instead of the
             // counting histogram, whose LDS atomics all but serialise on the two to sixteen symbols PACK is made for
+            PROF(0);
             wg_present8(data, n, S.F, S.pmask, tid);
+            PROF(1);
             wg_pack(data, n, D->hdr + hl, pbuf, S, tid);
+            PROF(2);
             if (S.pk_meta_len == 1 && S.pk_n != 256) flags &= ~(u32)X_PACK;    // > 16 symbols (:1249); 256 wraps to 0 and stays
             else {
                 if (S.pk_n <= 16) data = pbuf;
@@ -1340,8 +1270,11 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
         else {
             u8 *lits_end = ws.lits + (u64)b * ws.xf_stride + ws.xf_stride;
             u8 *meta_end = ws.meta + (u64)b * (ws.xf_stride + 768) + (ws.xf_stride + 768);
+            PROF(3);
             wg_hist8(data, n, S.F, (u32 *)dyn, tid);
+            PROF(4);
             wg_rle_split(data, n, lits_end, meta_end, S, dyn, tid);
+            PROF(5);
             const u32 nsy = S.rl_nsyms, nlits = S.rl_lits, nruns = S.rl_runs;
             const u32 mlen = nruns + nsy + 1;                              // :1282-1285
             if ((double)((u64)nlits + mlen) >= .99 * (double)n) {          // :1287
@@ -1393,12 +1326,14 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
 
     data = (const u8 *)H.data;
     n = H.dlen;
+    PROF(6);
 
     // pass 1 over the block, all waves: byte histogram (hist8, utils.h:80-102) for order 0, presence only
     // (present8, :108-131) for order 1
     if (H.order == 0) wg_hist8(data, n, S.F, (u32 *)dyn, tid);
     else              wg_present8(data, n, S.F, S.pmask, tid);
 
+    PROF(7);
     EncStat *ST = &ws.stat[b];
     ST->F0[tid] = S.F[tid];                                               // FRONT_THREADS == 256
     if (H.order == 0) {
@@ -1425,12 +1360,15 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
     else          { for (u32 j = tid; j < ns * ns; j += FRONT_THREADS) Fg[j] = 0; }
     __syncthreads();
     // pass 2 over the block: order-1 pair histogram, all waves
+    PROF(8);
     if (f_in_lds) wg_hist1(data, n, (u32 *)dyn, ns, copies, S.idx_of, tid);
     else          wg_hist1(data, n, Fg, ns, 1u, S.idx_of, tid);
+    PROF(9);
     // hand over to k_enc_tables: alphabet maps and the pair counters (compact, ns*ns)
     ST->present[tid] = S.present[tid]; ST->idx_of[tid] = S.idx_of[tid]; ST->alpha[tid] = S.alpha[tid];
     if (f_in_lds) for (u32 j = tid; j < ns * ns; j += FRONT_THREADS) Fg[j] = ((u32 *)dyn)[j];
     if (tid == 0) { ST->run = 1; ST->order = 1; ST->ns = ns; }
+    PROF(10);
 }
 
 // ---------------------------------------------------------------------------------------------
