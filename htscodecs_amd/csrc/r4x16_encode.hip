@@ -1083,11 +1083,24 @@ __device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, 
     auto walk = [&](auto emitc, u32 &nlit, u32 &first, u32 &vbytes, u32 &open, u8 *lp, u8 *vp) {
         constexpr bool EMIT = decltype(emitc)::value;
         u32 prev = c0 ? data[c0 - 1] : 256u;
+        // a thread's pieces are consecutive, so their loads are dependent round trips to memory unless the next one
+        // is requested before this one is looked at
+        auto piece = [&](u32 p0) -> u32x4 {
+            u32x4 v = {0, 0, 0, 0};
+            if (p0 + 16 <= c1) v = *(const u32x4_unaligned *)(data + p0);
+            else if (p0 < c1) {
+                u32 w[4] = {0, 0, 0, 0};
+                for (u32 c = 0; c < c1 - p0; c++) w[c >> 2] |= (u32)data[p0 + c] << (8 * (c & 3));
+                v = u32x4{w[0], w[1], w[2], w[3]};
+            }
+            return v;
+        };
+        u32x4 ahead = piece(c0);
         for (u32 p0 = c0; p0 < c1; p0 += 16) {
             const u32 cnt = c1 - p0 < 16 ? c1 - p0 : 16;
-            u32 w[4] = {0, 0, 0, 0};
-            if (cnt == 16) { const u32x4 v = *(const u32x4_unaligned *)(data + p0); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
-            else for (u32 c = 0; c < cnt; c++) w[c >> 2] |= (u32)data[p0 + c] << (8 * (c & 3));
+            const u32x4 v = ahead;
+            ahead = piece(p0 + 16);
+            const u32 w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int c = 0; c < 16; c++) {
                 const u32 cur = (w[c >> 2] >> (8 * (c & 3))) & 0xff;
