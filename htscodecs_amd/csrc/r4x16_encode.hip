@@ -835,7 +835,7 @@ __device__ __forceinline__ void wg_hist8(const u8 *data, u32 n, u32 *Fout, u32 *
     const u32 full = n >> 4;
     auto ld = [&](u32 pi) -> u32x4 {
         u32x4 v = {0, 0, 0, 0};
-        if (pi < full) v = *(const u32x4_unaligned *)(data + 16ull * pi);
+        if (pi < full) v = *(GAS const u32x4_unaligned *)(to_global(data) + 16ull * pi);
         return v;
     };
     auto count = [&](u32x4 w, u32 pi) {
@@ -878,7 +878,7 @@ __device__ __forceinline__ void wg_present8(const u8 *data, u32 n, u32 *F, u8 *f
     const u32 full = n >> 4;
     auto ld = [&](u32 pi) -> u32x4 {
         u32x4 v = {0, 0, 0, 0};
-        if (pi < full) v = *(const u32x4_unaligned *)(data + 16ull * pi);
+        if (pi < full) v = *(GAS const u32x4_unaligned *)(to_global(data) + 16ull * pi);
         return v;
     };
     auto mark = [&](u32x4 w, u32 pi) {
@@ -920,7 +920,7 @@ __device__ __forceinline__ void wg_hist1(const u8 *data, u32 n, FP Fp0, u32 ns, 
     struct Piece { u32x4 w; u32 before; };
     auto ld = [&](u32 pi) -> Piece {
         Piece p = {{0, 0, 0, 0}, 0};
-        if (pi < full) { p.w = *(const u32x4_unaligned *)(data + 16ull * pi); p.before = pi ? data[16ull * pi - 1] : 0u; }
+        if (pi < full) { p.w = *(GAS const u32x4_unaligned *)(to_global(data) + 16ull * pi); p.before = pi ? to_global(data)[16ull * pi - 1] : 0u; }
         return p;
     };
     auto count = [&](const Piece &p, u32 pi) {
@@ -994,8 +994,14 @@ __device__ void wg_pack(const u8 *data, u32 n, u8 *meta, u8 *out, EncShared &S, 
     const u32 per = ns > 4 ? 2 : ns > 2 ? 4 : 8;
     const u32 width = 8 / per;
     const u32 pieces = n >> 4;
+    // (global-address-space accesses: a FLAT load or store also counts on the LDS counter, and every idx_of look-up
+    //  below would wait for it; the next piece is requested before this one is packed)
+    gu8 *gout = to_global(out);
+    auto piece = [&](u32 pi) -> u32x4 { u32x4 v = {0, 0, 0, 0}; if (pi < pieces) v = *(GAS const u32x4_unaligned *)(to_global(data) + 16ull * pi); return v; };
+    u32x4 ahead = piece(tid);
     for (u32 pi = tid; pi < pieces; pi += FRONT_THREADS) {
-        const u32x4 v = *(const u32x4_unaligned *)(data + 16ull * pi);
+        const u32x4 v = ahead;
+        ahead = piece(pi + FRONT_THREADS);
         const u32 w[4] = {v.x, v.y, v.z, v.w};
         u64 acc = 0;                                      // 16 symbols of `width` bits, first in the low bits
 #pragma unroll
@@ -1005,10 +1011,10 @@ __device__ void wg_pack(const u8 *data, u32 n, u8 *meta, u8 *out, EncShared &S, 
             const u64 four = (u64)(i0 | (i1 << width) | (i2 << (2 * width)) | (i3 << (3 * width)));
             acc |= four << (4 * width * c);
         }
-        u8 *o = out + (u64)pi * (16 / per);
-        if (per == 2)      *(u64_unaligned *)o = acc;
-        else if (per == 4) *(u32_unaligned *)o = (u32)acc;
-        else               *(u16_unaligned *)o = (u16)acc;
+        gu8 *o = gout + (u64)pi * (16 / per);
+        if (per == 2)      *(GAS u64_unaligned *)o = acc;
+        else if (per == 4) *(GAS u32_unaligned *)o = (u32)acc;
+        else               *(GAS u16_unaligned *)o = (u16)acc;
     }
     if (tid == 0) {                                       // the last n % 16 bytes
         const u32 nout = S.pk_len;
@@ -1023,6 +1029,32 @@ __device__ void wg_pack(const u8 *data, u32 n, u8 *meta, u8 *out, EncShared &S, 
     __syncthreads();
 }
 
+// Phase timing of k_enc_front for variant builds (-DR4X16_PROF_FRONT; tools/front_phases.py): cycles of thread 0 between
+// stamps, summed over the blocks.  Not compiled into the product.
+#ifdef R4X16_PROF_FRONT
+__device__ unsigned long long g_front_prof[16];
+#define PROF_INIT unsigned long long prof_t = tid == 0 ? (unsigned long long)wall_clock64() : 0ull
+#define PROF(k) do { if (tid == 0) { const unsigned long long n_ = (unsigned long long)wall_clock64(); atomicAdd(&g_front_prof[k], n_ - prof_t); prof_t = n_; } } while (0)
+extern "C" __attribute__((visibility("default"))) int rans4x16_hip_debug_front_prof(unsigned long long *out16, int reset)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_front_prof), sizeof(g_front_prof)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_front_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define PROF_INIT
+#define PROF(k)
+#endif
+
+// var_put_u32 (varint.h:85-104) through a global-address-space pointer (see wg_pack on FLAT accesses)
+__device__ __forceinline__ u32 var_put_g(gu8 *cp, u32 v)
+{
+    u32 groups = 1;
+    for (u32 t = v >> 7; t; t >>= 7) groups++;
+    for (u32 g = groups; g-- > 0; ) *cp++ = (u8)(((v >> (7 * g)) & 0x7f) | (g ? 0x80 : 0));
+    return groups;
+}
+
 // rle_encode with automatic symbol choice, rle.c:48-138.  S.F holds the byte histogram.  The repeat
 // counts and the split are taken by all threads, each on its own chunk of the input.  `tiles`: 5 KB of LDS.
 // Results: S.rl_nsyms, S.rl_lits, S.rl_runs (bytes); symbols in S.alpha[0..nsyms).  Ends on a workgroup barrier.
@@ -1030,6 +1062,7 @@ __device__ void wg_pack(const u8 *data, u32 n, u8 *meta, u8 *out, EncShared &S, 
 __device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, EncShared &S, u8 *tiles, u32 tid)
 {
     const u32 lane = tid & (WAVE - 1);
+    PROF_INIT;
     u32 *rep = S.T;                                      // repeats per symbol
     rep[tid] = 0;                                        // FRONT_THREADS == 256
     __syncthreads();
@@ -1039,7 +1072,7 @@ __device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, 
             const u32 off = pi * 16;
             const u32 cnt = n - off < 16 ? n - off : 16;
             u32 w[4] = {0, 0, 0, 0};
-            if (cnt == 16) { const u32x4 v = *(const u32x4_unaligned *)(data + off); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
+            if (cnt == 16) { const u32x4 v = *(GAS const u32x4_unaligned *)(to_global(data) + off); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
             else for (u32 c = 0; c < cnt; c++) w[c >> 2] |= (u32)data[off + c] << (8 * (c & 3));
             u32 prev = off ? data[off - 1] : 256u;
             u32 run = 0;                                  // repeats of `prev` not yet added
@@ -1055,6 +1088,7 @@ __device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, 
         }
     }
     __syncthreads();
+    PROF(11);
     if (tid == 0) {
         u32 ns = 0;
         for (u32 j = 0; j < 256; j++) {
@@ -1080,17 +1114,17 @@ __device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, 
     const u32 csz = ((n + FRONT_THREADS - 1) / FRONT_THREADS + 15u) & ~15u;            // chunk bytes, a multiple of 16
     const u32 c0 = tid * csz < n ? tid * csz : n, c1 = c0 + csz < n ? c0 + csz : n;
     // one walk; EMIT = false: count, EMIT = true: write at (lp, vp).  `open` = position of the RLE-symbol literal whose run is running.
-    auto walk = [&](auto emitc, u32 &nlit, u32 &first, u32 &vbytes, u32 &open, u8 *lp, u8 *vp) {
+    auto walk = [&](auto emitc, u32 &nlit, u32 &first, u32 &vbytes, u32 &open, gu8 *lp, gu8 *vp) {
         constexpr bool EMIT = decltype(emitc)::value;
-        u32 prev = c0 ? data[c0 - 1] : 256u;
+        u32 prev = c0 ? to_global(data)[c0 - 1] : 256u;
         // a thread's pieces are consecutive, so their loads are dependent round trips to memory unless the next one
         // is requested before this one is looked at
         auto piece = [&](u32 p0) -> u32x4 {
             u32x4 v = {0, 0, 0, 0};
-            if (p0 + 16 <= c1) v = *(const u32x4_unaligned *)(data + p0);
+            if (p0 + 16 <= c1) v = *(GAS const u32x4_unaligned *)(to_global(data) + p0);
             else if (p0 < c1) {
                 u32 w[4] = {0, 0, 0, 0};
-                for (u32 c = 0; c < c1 - p0; c++) w[c >> 2] |= (u32)data[p0 + c] << (8 * (c & 3));
+                for (u32 c = 0; c < c1 - p0; c++) w[c >> 2] |= (u32)to_global(data)[p0 + c] << (8 * (c & 3));
                 v = u32x4{w[0], w[1], w[2], w[3]};
             }
             return v;
@@ -1110,7 +1144,7 @@ __device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, 
                         const u32 at = p0 + (u32)c;
                         if (open != NONE) {                                   // the run behind `open` ends here
                             const u32 run = at - open - 1;
-                            if (EMIT) vp += var_put(vp, run); else vbytes += var_len(run);
+                            if (EMIT) vp += var_put_g(vp, run); else vbytes += var_len(run);
                         }
                         open = S.present[cur] ? at : NONE;
                         if (first == NONE) first = at;
@@ -1120,12 +1154,14 @@ __device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, 
                 }
             }
         }
-        if (EMIT && open != NONE) var_put(vp, cN[tid] - open - 1);            // the run that leaves the chunk
+        if (EMIT && open != NONE) var_put_g(vp, cN[tid] - open - 1);          // the run that leaves the chunk
     };
     u32 nlit = 0, first = NONE, vbytes = 0, open = NONE;
-    walk(std::false_type{}, nlit, first, vbytes, open, nullptr, nullptr);
+    PROF(12);
+    walk(std::false_type{}, nlit, first, vbytes, open, (gu8 *)nullptr, (gu8 *)nullptr);
     cF[tid] = first; cL[tid] = nlit; cV[tid] = vbytes; cP[tid] = open;
     __syncthreads();
+    PROF(13);
     if (tid == 0) {
         u32 nx = n;                                                            // next literal after the chunk
         for (int t = FRONT_THREADS - 1; t >= 0; t--) { cN[t] = nx; if (cF[t] != NONE) nx = cF[t]; }
@@ -1142,10 +1178,12 @@ __device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, 
     {
         const u32 nl_all = S.rl_lits, nv_all = S.rl_runs;
         u32 d0 = 0, d1 = NONE, d2 = 0, op = NONE;
-        walk(std::true_type{}, d0, d1, d2, op, lits_end - nl_all + cL[tid], runs_end - nv_all + cV[tid]);
+        PROF(14);
+        walk(std::true_type{}, d0, d1, d2, op, to_global(lits_end) - nl_all + cL[tid], to_global(runs_end) - nv_all + cV[tid]);
     }
     __threadfence();
     __syncthreads();
+    PROF(15);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1163,23 +1201,6 @@ __device__ __forceinline__ double approx_log(double a)            // fast_log :6
     const long long bits = __double_as_longlong(a);
     return (double)(bits - 4606921278410026770LL) * 1.539095918623324e-16;
 }
-
-// Phase timing of k_enc_front for variant builds (-DR4X16_PROF_FRONT; tools/front_phases.py): cycles of thread 0 between
-// stamps, summed over the blocks.  Not compiled into the product.
-#ifdef R4X16_PROF_FRONT
-__device__ unsigned long long g_front_prof[16];
-#define PROF_INIT unsigned long long prof_t = tid == 0 ? (unsigned long long)wall_clock64() : 0ull
-#define PROF(k) do { if (tid == 0) { const unsigned long long n_ = (unsigned long long)wall_clock64(); atomicAdd(&g_front_prof[k], n_ - prof_t); prof_t = n_; } } while (0)
-extern "C" __attribute__((visibility("default"))) int rans4x16_hip_debug_front_prof(unsigned long long *out16, int reset)
-{
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_front_prof), sizeof(g_front_prof)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_front_prof), z, sizeof(z)) != hipSuccess) return -1; }
-    return 0;
-}
-#else
-#define PROF_INIT
-#define PROF(k)
-#endif
 
 __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs ws, int base)
 {

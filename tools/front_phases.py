@@ -19,3 +19,5 @@ calls = 2 * nblk            # warm step + timed step
 print(r)
 for k, nm in enumerate(names):
     print(f"{nm:28s} {buf[k] / calls / 100.0:9.1f} us per block  {100.0 * buf[k] / max(tot, 1):5.1f} %")   # wall_clock64: 100 MHz
+for k, nm in zip(range(11, 16), ["rle: repeat counts", "rle: symbol choice", "rle: walk A", "rle: scans", "rle: walk B"]):
+    print(f"  {nm:26s} {buf[k] / calls / 100.0:9.1f} us per block")
