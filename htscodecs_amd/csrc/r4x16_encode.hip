@@ -1046,6 +1046,40 @@ extern "C" __attribute__((visibility("default"))) int rans4x16_hip_debug_front_p
 #define PROF(k)
 #endif
 
+// A thread's private byte stream to global memory, sixteen bytes per store.  (In the chunked RLE split every lane writes
+// its own region: byte stores would be sixty-four one-byte transactions per instruction, 0.46 ms per 256 KiB block.)
+struct ByteOut {
+    gu8 *p;
+    u32x4 acc;           // the last (up to) sixteen bytes, the newest in the top byte
+    u32 cnt;
+    __device__ __forceinline__ void put(u32 b)
+    {
+        acc.x = __builtin_amdgcn_alignbit(acc.y, acc.x, 8);
+        acc.y = __builtin_amdgcn_alignbit(acc.z, acc.y, 8);
+        acc.z = __builtin_amdgcn_alignbit(acc.w, acc.z, 8);
+        acc.w = (acc.w >> 8) | (b << 24);
+        if (++cnt == 16) { *(GAS u32x4_unaligned *)p = acc; p += 16; cnt = 0; }
+    }
+    __device__ __forceinline__ void flush()
+    {
+        for (u32 k = cnt; k < 16; k++) {         // bring the oldest byte down to byte 0
+            acc.x = __builtin_amdgcn_alignbit(acc.y, acc.x, 8);
+            acc.y = __builtin_amdgcn_alignbit(acc.z, acc.y, 8);
+            acc.z = __builtin_amdgcn_alignbit(acc.w, acc.z, 8);
+            acc.w >>= 8;
+        }
+        const u32 w[4] = {acc.x, acc.y, acc.z, acc.w};
+        for (u32 k = 0; k < cnt; k++) p[k] = (u8)(k < 4 ? w[0] >> (8 * k) : k < 8 ? w[1] >> (8 * (k - 4)) : k < 12 ? w[2] >> (8 * (k - 8)) : w[3] >> (8 * (k - 12)));
+        p += cnt; cnt = 0;
+    }
+    __device__ __forceinline__ void put_var(u32 v)          // var_put_u32, varint.h:85-104
+    {
+        u32 groups = 1;
+        for (u32 t = v >> 7; t; t >>= 7) groups++;
+        for (u32 g = groups; g-- > 0; ) put(((v >> (7 * g)) & 0x7f) | (g ? 0x80u : 0u));
+    }
+};
+
 // var_put_u32 (varint.h:85-104) through a global-address-space pointer (see wg_pack on FLAT accesses)
 __device__ __forceinline__ u32 var_put_g(gu8 *cp, u32 v)
 {
@@ -1116,6 +1150,7 @@ __device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, 
     // one walk; EMIT = false: count, EMIT = true: write at (lp, vp).  `open` = position of the RLE-symbol literal whose run is running.
     auto walk = [&](auto emitc, u32 &nlit, u32 &first, u32 &vbytes, u32 &open, gu8 *lp, gu8 *vp) {
         constexpr bool EMIT = decltype(emitc)::value;
+        ByteOut lo{lp, {0, 0, 0, 0}, 0}, vo{vp, {0, 0, 0, 0}, 0};
         u32 prev = c0 ? to_global(data)[c0 - 1] : 256u;
         // a thread's pieces are consecutive, so their loads are dependent round trips to memory unless the next one
         // is requested before this one is looked at
@@ -1144,17 +1179,20 @@ __device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, 
                         const u32 at = p0 + (u32)c;
                         if (open != NONE) {                                   // the run behind `open` ends here
                             const u32 run = at - open - 1;
-                            if (EMIT) vp += var_put_g(vp, run); else vbytes += var_len(run);
+                            if (EMIT) vo.put_var(run); else vbytes += var_len(run);
                         }
                         open = S.present[cur] ? at : NONE;
                         if (first == NONE) first = at;
-                        if (EMIT) *lp++ = (u8)cur; else nlit++;
+                        if (EMIT) lo.put(cur); else nlit++;
                     }
                     prev = cur;
                 }
             }
         }
-        if (EMIT && open != NONE) var_put_g(vp, cN[tid] - open - 1);          // the run that leaves the chunk
+        if (EMIT) {
+            if (open != NONE) vo.put_var(cN[tid] - open - 1);                 // the run that leaves the chunk
+            lo.flush(); vo.flush();
+        }
     };
     u32 nlit = 0, first = NONE, vbytes = 0, open = NONE;
     PROF(12);
