@@ -1102,13 +1102,25 @@ __device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, 
     __syncthreads();
     {
         const u32 pieces = (n + 15) >> 4;
+        // (a thread's next piece and the byte before it are requested before this piece is counted)
+        struct Pc { u32x4 v; u32 before; };
+        auto piece = [&](u32 pi) -> Pc {
+            Pc r = {{0, 0, 0, 0}, 256u};
+            const u32 off = pi * 16;
+            if (pi >= pieces) return r;
+            if (n - off >= 16) r.v = *(GAS const u32x4_unaligned *)(to_global(data) + off);
+            else { u32 w[4] = {0, 0, 0, 0}; for (u32 c = 0; c < n - off; c++) w[c >> 2] |= (u32)to_global(data)[off + c] << (8 * (c & 3)); r.v = u32x4{w[0], w[1], w[2], w[3]}; }
+            if (off) r.before = to_global(data)[off - 1];
+            return r;
+        };
+        Pc ahead = piece(tid);
         for (u32 pi = tid; pi < pieces; pi += FRONT_THREADS) {
             const u32 off = pi * 16;
             const u32 cnt = n - off < 16 ? n - off : 16;
-            u32 w[4] = {0, 0, 0, 0};
-            if (cnt == 16) { const u32x4 v = *(GAS const u32x4_unaligned *)(to_global(data) + off); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; }
-            else for (u32 c = 0; c < cnt; c++) w[c >> 2] |= (u32)data[off + c] << (8 * (c & 3));
-            u32 prev = off ? data[off - 1] : 256u;
+            const Pc cur_p = ahead;
+            ahead = piece(pi + FRONT_THREADS);
+            const u32 w[4] = {cur_p.v.x, cur_p.v.y, cur_p.v.z, cur_p.v.w};
+            u32 prev = cur_p.before;
             u32 run = 0;                                  // repeats of `prev` not yet added
 #pragma unroll
             for (int c = 0; c < 16; c++) {
@@ -1401,44 +1413,64 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
     PROF(6);
 
     // pass 1 over the block, all waves: byte histogram (hist8, utils.h:80-102) for order 0, presence only
-    // (present8, :108-131) for order 1
+    // (present8, :108-131) for order 1.  Order-1 blocks of 256 KiB and more look at their first 64 KiB only: the pair
+    // counters get one extra "any other byte" symbol, and only if that one is ever hit (never, on quality data: a
+    // block's alphabet is complete within its first few thousand bytes) is the exact two-pass route taken.  One read
+    // of the input instead of two (the front end fetched 2.0 x the batch).
+    const u32 SAMPLE = 65536u;
+    const bool sampled = H.order == 1 && n >= 4u * SAMPLE;
     if (H.order == 0) wg_hist8(data, n, S.F, (u32 *)dyn, tid);
-    else              wg_present8(data, n, S.F, S.pmask, tid);
+    else              wg_present8(data, sampled ? SAMPLE : n, S.F, S.pmask, tid);
 
     PROF(7);
     EncStat *ST = &ws.stat[b];
-    ST->F0[tid] = S.F[tid];                                               // FRONT_THREADS == 256
     if (H.order == 0) {
+        ST->F0[tid] = S.F[tid];                                           // FRONT_THREADS == 256
         if (tid == 0) { ST->run = 1; ST->order = 0; ST->ns = 0; }
         return;
     }
 
     // ---- order-1 (:694-780) ---------------------------------------------------------------------
-    // compact alphabet F0 from the byte histogram (0 forced in, :731)
-    if (tid == 0) {
-        u32 ns = 0;
-        for (u32 j = 0; j < 256; j++) {
-            S.present[j] = (S.F[j] != 0) || j == 0;
-            if (S.present[j]) { S.idx_of[j] = (u8)ns; S.alpha[ns] = (u8)j; ns++; }
-        }
-        S.nsym = ns;
-    }
-    __syncthreads();
-    const u32 ns = S.nsym;
-    const bool f_in_lds = ns <= FRONT_LDS_NSYM;
     u32 *Fg = ws.F + (u64)b * 65536u;
-    const u32 copies = !f_in_lds ? 1u : (16u * hist1_copy_stride(ns, 4) <= FRONT_DYN_LDS ? 4u : (8u * hist1_copy_stride(ns, 2) <= FRONT_DYN_LDS ? 2u : 1u));
-    if (f_in_lds) { for (u32 j = tid; j < copies * hist1_copy_stride(ns, copies); j += FRONT_THREADS) ((u32 *)dyn)[j] = 0; }
-    else          { for (u32 j = tid; j < ns * ns; j += FRONT_THREADS) Fg[j] = 0; }
-    __syncthreads();
-    // pass 2 over the block: order-1 pair histogram, all waves
-    PROF(8);
-    if (f_in_lds) wg_hist1(data, n, (u32 *)dyn, ns, copies, S.idx_of, tid);
-    else          wg_hist1(data, n, Fg, ns, 1u, S.idx_of, tid);
-    PROF(9);
+    u32 ns = 0, nsx = 0;
+    bool f_in_lds = false;
+    for (u32 attempt = sampled ? 0u : 1u; attempt < 2u; attempt++) {
+        const bool prov = attempt == 0;                                   // provisional alphabet + overflow symbol
+        if (attempt == 1 && sampled) wg_present8(data, n, S.F, S.pmask, tid);
+        // compact alphabet F0 from the presence flags (0 forced in, :731); absent bytes map to the overflow symbol
+        if (tid == 0) {
+            u32 k = 0;
+            for (u32 j = 0; j < 256; j++) {
+                S.present[j] = (S.F[j] != 0) || j == 0;
+                if (S.present[j]) { S.idx_of[j] = (u8)k; S.alpha[k] = (u8)j; k++; }
+            }
+            if (prov) for (u32 j = 0; j < 256; j++) if (!S.present[j]) S.idx_of[j] = (u8)(k < 255 ? k : 255);
+            S.nsym = k;
+        }
+        __syncthreads();
+        ns = S.nsym;
+        nsx = prov ? ns + 1 : ns;                                         // row / column count of the counters
+        f_in_lds = nsx <= FRONT_LDS_NSYM;
+        if (prov && !f_in_lds) continue;                                  // large alphabets: straight to the exact route
+        const u32 copies = !f_in_lds ? 1u : (16u * hist1_copy_stride(nsx, 4) <= FRONT_DYN_LDS ? 4u : (8u * hist1_copy_stride(nsx, 2) <= FRONT_DYN_LDS ? 2u : 1u));
+        if (f_in_lds) { for (u32 j = tid; j < copies * hist1_copy_stride(nsx, copies); j += FRONT_THREADS) ((u32 *)dyn)[j] = 0; }
+        else          { for (u32 j = tid; j < nsx * nsx; j += FRONT_THREADS) Fg[j] = 0; }
+        __syncthreads();
+        // pass 2 over the block: order-1 pair histogram, all waves
+        PROF(8);
+        if (f_in_lds) wg_hist1(data, n, (u32 *)dyn, nsx, copies, S.idx_of, tid);
+        else          wg_hist1(data, n, Fg, nsx, 1u, S.idx_of, tid);
+        PROF(9);
+        if (!prov) break;
+        // any pair with the overflow symbol (row ns or column ns of the (ns + 1)^2 counters)?
+        bool hit = false;
+        for (u32 j = tid; j <= ns; j += FRONT_THREADS) hit |= ((u32 *)dyn)[ns * nsx + j] != 0 || ((u32 *)dyn)[j * nsx + ns] != 0;
+        if (!__syncthreads_or(hit)) break;
+    }
+    ST->F0[tid] = S.F[tid];
     // hand over to k_enc_tables: alphabet maps and the pair counters (compact, ns*ns)
     ST->present[tid] = S.present[tid]; ST->idx_of[tid] = S.idx_of[tid]; ST->alpha[tid] = S.alpha[tid];
-    if (f_in_lds) for (u32 j = tid; j < ns * ns; j += FRONT_THREADS) Fg[j] = ((u32 *)dyn)[j];
+    if (f_in_lds) for (u32 j = tid; j < ns * ns; j += FRONT_THREADS) Fg[j] = ((u32 *)dyn)[(j / ns) * nsx + j % ns];   // (nsx = ns + 1 on the sampled route)
     if (tid == 0) { ST->run = 1; ST->order = 1; ST->ns = ns; }
     PROF(10);
 }

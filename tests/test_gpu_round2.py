@@ -258,3 +258,27 @@ def test_single_block_calls_from_a_thread_pool_are_combined(H, oracle):
 
     with ThreadPoolExecutor(24) as ex:
         assert all(ex.map(work, jobs))
+
+
+def test_alphabet_that_grows_after_the_first_64_kib(H, oracle):
+    """k_enc_front sizes the pair counters of large order-1 blocks from the alphabet of their first 64 KiB plus one
+    overflow symbol and falls back to the exact two-pass route when that symbol is ever hit: blocks whose later
+    bytes bring new symbols (at the very end, in the middle, as a quarter start, as the last byte) must still be
+    reference-identical; so must blocks where nothing new appears."""
+    rs = np.random.RandomState(6464)
+    n = 600000
+    base = datagen.tile("q40+dir", n, 3)
+    cases = []
+    a = base.copy(); cases.append(a)                                      # nothing new
+    a = base.copy(); a[-1] = 200; cases.append(a)                         # new symbol as the last byte
+    a = base.copy(); a[300000:300050] = 7; cases.append(a)                # new symbol in the middle
+    a = base.copy(); a[2 * (n >> 2)] = 250; cases.append(a)               # new symbol exactly at a quarter start
+    a = base.copy(); a[70000:] = rs.randint(0, 256, size=n - 70000).astype(np.uint8); cases.append(a)   # everything new
+    a = base.copy(); a[65536] = 1; cases.append(a)                        # first byte after the sample
+    a = np.concatenate([datagen.tile("q4", 100000, 1), datagen.tile("q40+dir", n - 100000, 2)]); cases.append(a)
+    datas = [c.tobytes() for c in cases]
+    for order in (1, 193, 65):
+        enc, st = H.compress_batch(datas, [order] * len(datas))
+        assert all(s == 0 for s in st)
+        for k, (d, e) in enumerate(zip(datas, enc)):
+            assert e == oracle.compress(d, order), (k, order)
