@@ -1462,6 +1462,8 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
         f_in_lds = nsx <= FRONT_LDS_NSYM;
         if (prov && !f_in_lds) continue;                                  // large alphabets: straight to the exact route
         // (eight copies instead of four measured the same: the pass is bound by the number of LDS instructions, not by their conflicts)
+        // (measured and not kept: eight copies instead of four - the same; arithmetic compact indices for contiguous
+        //  alphabets instead of the 17 LDS look-ups per 16 bytes - 20 % slower: the pass is bound by its LDS atomics and its issue slots alike)
         const u32 copies = !f_in_lds ? 1u : (16u * hist1_copy_stride(nsx, 4) <= FRONT_DYN_LDS ? 4u : (8u * hist1_copy_stride(nsx, 2) <= FRONT_DYN_LDS ? 2u : 1u));
         if (f_in_lds) { for (u32 j = tid; j < copies * hist1_copy_stride(nsx, copies); j += FRONT_THREADS) ((u32 *)dyn)[j] = 0; }
         else          { for (u32 j = tid; j < nsx * nsx; j += FRONT_THREADS) Fg[j] = 0; }
