@@ -910,18 +910,9 @@ __device__ __forceinline__ void wg_present8(const u8 *data, u32 n, u32 *F, u8 *f
 // counters of one copy: ns*ns, padded so that the copies start eight LDS banks apart
 __device__ __forceinline__ u32 hist1_copy_stride(u32 ns, u32 copies) { return copies > 1 ? ((ns * ns + 31u) & ~31u) + 8u : ns * ns; }
 
-// AFFINE: the alphabet is byte 0 plus one contiguous range [lo, lo + span): the compact index is arithmetic
-// (b - lo + 1, byte 0 -> 0, anything else -> `ovf`) instead of an LDS look-up per byte.  The pass is bound by its LDS
-// instructions (17 look-ups + 16 atomics per 16 bytes); quality alphabets are such ranges.
-struct AffineMap { u32 lo, span, ovf; };
-template <bool AFFINE, class FP>
-__device__ __forceinline__ void wg_hist1(const u8 *data, u32 n, FP Fp0, u32 ns, u32 copies, const u8 *idx_of, u32 tid, AffineMap am = {0, 0, 0})
+template <class FP>
+__device__ __forceinline__ void wg_hist1(const u8 *data, u32 n, FP Fp0, u32 ns, u32 copies, const u8 *idx_of, u32 tid)
 {
-    auto cidx = [&](u32 b) -> u32 {
-        if (!AFFINE) return idx_of[b];
-        const u32 t = b - am.lo;
-        return t < am.span ? t + 1u : (b == 0u ? 0u : am.ovf);
-    };
     const u32 cs = hist1_copy_stride(ns, copies);
     FP Fp = Fp0 + (tid & (copies - 1)) * cs;
     // 16-byte pieces with the byte before them, four in flight per thread (see wg_hist8)
@@ -938,10 +929,10 @@ __device__ __forceinline__ void wg_hist1(const u8 *data, u32 n, FP Fp0, u32 ns, 
         u32 ci[16];                                  // compact indices of this thread's bytes
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            ci[4 * c] = cidx(ww[c] & 0xff); ci[4 * c + 1] = cidx((ww[c] >> 8) & 0xff);
-            ci[4 * c + 2] = cidx((ww[c] >> 16) & 0xff); ci[4 * c + 3] = cidx(ww[c] >> 24);
+            ci[4 * c] = idx_of[ww[c] & 0xff]; ci[4 * c + 1] = idx_of[(ww[c] >> 8) & 0xff];
+            ci[4 * c + 2] = idx_of[(ww[c] >> 16) & 0xff]; ci[4 * c + 3] = idx_of[ww[c] >> 24];
         }
-        u32 prev = pi ? cidx(p.before) : 0u;       // the first byte of the block is seen in context 0
+        u32 prev = pi ? idx_of[p.before] : 0u;       // the first byte of the block is seen in context 0
 #pragma unroll
         for (int c = 0; c < 16; c++) {
             atomicAdd(&Fp[prev * ns + ci[c]], 1u);
@@ -957,16 +948,16 @@ __device__ __forceinline__ void wg_hist1(const u8 *data, u32 n, FP Fp0, u32 ns, 
         count(q3, pi + 3 * T); q3 = ld(pi + 7 * T);
     }
     if (tid == 0) {                                  // the last n % 16 bytes
-        u32 prev = full ? cidx(data[16 * full - 1]) : 0u;
+        u32 prev = full ? idx_of[data[16 * full - 1]] : 0u;
         for (u32 i = 16 * full; i < n; i++) {
-            const u32 cur = cidx(data[i]);
+            const u32 cur = idx_of[data[i]];
             atomicAdd(&Fp[(i ? prev : 0u) * ns + cur], 1u);
             prev = cur;
         }
     }
     __syncthreads();
     // the three quarter starts are coded in context 0 (rANS_static4x16pr.c:720-723)
-    if (tid >= 1 && tid < 4) atomicAdd(&Fp0[cidx(data[tid * (n >> 2)])], 1u);
+    if (tid >= 1 && tid < 4) atomicAdd(&Fp0[idx_of[data[tid * (n >> 2)]]], 1u);
     __syncthreads();
     if (copies > 1) {
         for (u32 j = tid; j < ns * ns; j += FRONT_THREADS) {
@@ -1461,22 +1452,14 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
         nsx = prov ? ns + 1 : ns;                                         // row / column count of the counters
         f_in_lds = nsx <= FRONT_LDS_NSYM;
         if (prov && !f_in_lds) continue;                                  // large alphabets: straight to the exact route
-        // (eight copies instead of four measured the same: the pass is bound by the number of LDS instructions, not by their conflicts)
-        // (measured and not kept: eight copies instead of four - the same; arithmetic compact indices for contiguous
-        //  alphabets instead of the 17 LDS look-ups per 16 bytes - 20 % slower: the pass is bound by its LDS atomics and its issue slots alike)
         const u32 copies = !f_in_lds ? 1u : (16u * hist1_copy_stride(nsx, 4) <= FRONT_DYN_LDS ? 4u : (8u * hist1_copy_stride(nsx, 2) <= FRONT_DYN_LDS ? 2u : 1u));
         if (f_in_lds) { for (u32 j = tid; j < copies * hist1_copy_stride(nsx, copies); j += FRONT_THREADS) ((u32 *)dyn)[j] = 0; }
         else          { for (u32 j = tid; j < nsx * nsx; j += FRONT_THREADS) Fg[j] = 0; }
         __syncthreads();
         // pass 2 over the block: order-1 pair histogram, all waves
         PROF(8);
-        // (contiguous alphabet: arithmetic indices; the range test is on the alphabet just built)
-        const u32 lo = ns > 1 ? S.alpha[1] : 0u, hi = ns > 1 ? S.alpha[ns - 1] : 0u;
-        const bool affine = f_in_lds && ns > 1 && hi - lo + 1u == ns - 1u;
-        const AffineMap am = {lo, ns - 1u, prov ? ns : 0u};
-        if (affine)        wg_hist1<true>(data, n, (u32 *)dyn, nsx, copies, S.idx_of, tid, am);
-        else if (f_in_lds) wg_hist1<false>(data, n, (u32 *)dyn, nsx, copies, S.idx_of, tid);
-        else               wg_hist1<false>(data, n, Fg, nsx, 1u, S.idx_of, tid);
+        if (f_in_lds) wg_hist1(data, n, (u32 *)dyn, nsx, copies, S.idx_of, tid);
+        else          wg_hist1(data, n, Fg, nsx, 1u, S.idx_of, tid);
         PROF(9);
         if (!prov) break;
         // any pair with the overflow symbol (row ns or column ns of the (ns + 1)^2 counters)?
@@ -2167,7 +2150,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void k8_enc_front(BatchArgs a, EncWs
         u32 *Fp = f_in_lds ? (u32 *)dyn : Fg;
         for (u32 j = tid; j < ns * ns; j += FRONT_THREADS) Fp[j] = 0;
         __syncthreads();
-        wg_hist1<false>(data, n, Fp, ns, 1u, S.idx_of, tid);
+        wg_hist1(data, n, Fp, ns, 1u, S.idx_of, tid);
         // one context row per thread: totals, normalisation in double precision (:470-495), serialised length
         u32 T = 0;
         if (tid < ns) {
