@@ -1041,9 +1041,20 @@ extern "C" __attribute__((visibility("default"))) int rans4x16_hip_debug_front_p
     if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_front_prof), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
+__device__ unsigned long long g_tables_prof[16];
+#define TPROF_INIT unsigned long long tprof_t = lane == 0 ? (unsigned long long)wall_clock64() : 0ull
+#define TPROF(k) do { if (lane == 0) { const unsigned long long n_ = (unsigned long long)wall_clock64(); atomicAdd(&g_tables_prof[k], n_ - tprof_t); tprof_t = n_; } } while (0)
+extern "C" __attribute__((visibility("default"))) int rans4x16_hip_debug_tables_prof(unsigned long long *out16, int reset)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_tables_prof), sizeof(g_tables_prof)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_tables_prof), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
 #else
 #define PROF_INIT
 #define PROF(k)
+#define TPROF_INIT
+#define TPROF(k)
 #endif
 
 // A thread's private byte stream to global memory, sixteen bytes per store.  (In the chunked RLE split every lane writes
@@ -1520,6 +1531,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
         return;
     }
 
+    TPROF_INIT;
     const u32 ns = ST->ns;
     for (u32 j = lane; j < 256; j += WAVE) { S.present[j] = ST->present[j]; S.idx_of[j] = ST->idx_of[j]; S.alpha[j] = ST->alpha[j]; }
     if (lane == 0) S.nsym = ns;
@@ -1536,6 +1548,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
     }
     wsync();
 
+    TPROF(0);
     // ---- compute_shift (:629-691): row by row; terms in parallel, sums in reference order ------
     if (lane == 0) H.max_tot = 0;
     wsync();
@@ -1591,6 +1604,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
     }
     const u32 bits = (e10 / e12 < 1.01 || H.max_tot <= 1024) ? 10u : 12u;          // :685
 
+    TPROF(1);
     // ---- per-context normalisation (:740-752), one context row per lane ---------------------------
     for (u32 rb = 0; rb < ns; rb += WAVE) {
         const u32 r = rb + lane;
@@ -1613,6 +1627,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
     wsync();
     if (H.status != ST_OK) { if (lane == 0) D->status = H.status; return; }
 
+    TPROF(2);
     // ---- serialise: alphabet, then rows at their prefix offsets -----------------------------------
     if (lane == 0) {
         u32 off = put_alphabet(tabraw, S.present);                    // :732
@@ -1623,56 +1638,61 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
     for (u32 rb = 0; rb < ns; rb += WAVE) {
         const u32 r = rb + lane;
         if (r < ns) {
-            u8 *cp = tabraw + S.rowlen[r];
+            // (a lane's row goes out in 16-byte pieces: byte stores, one per lane and instruction to forty-odd different
+            //  lines, were 100 us of this kernel per block)
+            ByteOut bo{to_global(tabraw) + S.rowlen[r], {0, 0, 0, 0}, 0};
             u32 zeros = 0;
             for (u32 j = 0; j < ns; j++) {
                 const u32 f = Fp[r * ns + j];
                 if (f) {
-                    if (zeros) { *cp++ = 0; *cp++ = (u8)(zeros - 1); zeros = 0; }
-                    cp += var_put(cp, f);
+                    if (zeros) { bo.put(0); bo.put(zeros - 1); zeros = 0; }
+                    bo.put_var(f);
                 } else zeros++;
             }
-            if (zeros) { *cp++ = 0; *cp++ = (u8)(zeros - 1); }
+            if (zeros) { bo.put(0); bo.put(zeros - 1); }
+            bo.flush();
         }
     }
     const u32 tlen = S.tab_len;
 
+    TPROF(3);
     // ---- encoder image: scale each row up to 1<<bits (:756) and build entries (:759-762) -----------
     for (u32 j = lane; j < 256; j += WAVE) img[j] = S.present[j] ? S.idx_of[j] : (u8)0;
     u16 *cumimg = (u16 *)(img + ENC_IMG_IDX);            // cum[r][0..ns]
     const bool packed = bits == 10 && ns >= ENC_PK_MIN_NS && ns <= ENC_PK_MAX_NS;
     const u32 W = enc_pk_row_dwords(ns);
-    for (u32 r = 0; r < ns; r++) {
+    // one context row per lane, serial over its ns entries (a row per wave with a scan per 64 entries and two
+    // barriers per packed row took 98 us per block for 46 rows)
+    for (u32 rb = 0; rb < ns; rb += WAVE) {
+        const u32 r = rb + lane;
+        if (r >= ns) continue;
         u32 sh = 0;
         const u32 tgt = (u32)S.S[r];
         if (tgt != 0 && tgt != (1u << bits)) { u32 sz = tgt; while (sz < (1u << bits)) { sz *= 2; sh++; } }
-        u32 carry = 0;
-        for (u32 jb = 0; jb < ns; jb += WAVE) {
-            const u32 j = jb + lane;
-            const u32 f = (j < ns) ? (Fp[r * ns + j] << sh) : 0u;
-            const u32 incl = wave_incl_scan(f, lane);
-            if (j < ns) { if (packed) S.F[j] = carry + incl - f; else cumimg[r * (ns + 1) + j] = (u16)(carry + incl - f); }
-            carry += __shfl(incl, WAVE - 1);
-        }
-        if (!packed) { if (lane == 0) cumimg[r * (ns + 1) + ns] = (u16)carry; continue; }
-        // packed row (r4x16_common.h): entry j at bit 11 j; lane d gathers the entries that touch dword d
-        if (lane == 0) S.F[ns] = carry;
-        wsync();
-        if (lane < W) {
-            u32 word = 0;
-            for (u32 j = (32u * lane) / 11u; j <= ns && 11u * j < 32u * lane + 32u; j++) {
-                const u32 e = S.F[j];
-                const int at = (int)(11u * j) - (int)(32u * lane);
-                word |= at >= 0 ? e << at : e >> -at;
+        u32 x = 0;
+        if (!packed) {
+            u16 *row = cumimg + r * (ns + 1);
+            for (u32 j = 0; j < ns; j++) { row[j] = (u16)x; x += Fp[r * ns + j] << sh; }
+            row[ns] = (u16)x;
+        } else {
+            // packed row (r4x16_common.h): entry j at bit 11 j of the row's bit stream
+            u32 *row = (u32 *)(img + ENC_IMG_IDX) + r * W;
+            u64 acc = 0;                                  // bits not yet written, `have` of them
+            u32 have = 0, wi = 0;
+            for (u32 j = 0; j <= ns; j++) {
+                acc |= (u64)x << have;
+                have += 11;
+                if (have >= 32) { row[wi++] = (u32)acc; acc >>= 32; have -= 32; }
+                if (j < ns) x += Fp[r * ns + j] << sh;
             }
-            ((u32 *)(img + ENC_IMG_IDX))[r * W + lane] = word;
+            if (wi < W) row[wi] = (u32)acc;
         }
-        wsync();
     }
     if (packed && lane == 0) ((u32 *)(img + ENC_IMG_IDX))[ns * W] = 0;      // the pair window's second dword past the last row
     __threadfence();
     wsync();
 
+    TPROF(4);
     // ---- table into the stream, nested order-0 if it pays (:766-780) ------------------------------
     u32 final_len = 0;
     bool nested = false;
@@ -1728,6 +1748,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
             final_len = hl + nlen;
         }
     }
+    TPROF(5);
     if (!nested) {
         if (lane == 0) tab[0] = (u8)(bits << 4);
         wave_copy(tab + 1, tabraw, tlen, lane);

@@ -21,3 +21,9 @@ for k, nm in enumerate(names):
     print(f"{nm:28s} {buf[k] / calls / 100.0:9.1f} us per block  {100.0 * buf[k] / max(tot, 1):5.1f} %")   # wall_clock64: 100 MHz
 for k, nm in zip(range(11, 16), ["rle: repeat counts", "rle: symbol choice", "rle: walk A", "rle: scans", "rle: walk B"]):
     print(f"  {nm:26s} {buf[k] / calls / 100.0:9.1f} us per block")
+
+fn2 = C.CDLL(_lib.LIB_PATH).rans4x16_hip_debug_tables_prof
+assert fn2(buf, 0) == 0
+print("k_enc_tables (order-1 path), us per block:")
+for k, nm in enumerate(["load counters, totals", "compute_shift", "normalise rows", "serialise table", "encoder image", "nested table coding"]):
+    print(f"  {nm:26s} {buf[k] / calls / 100.0:9.1f}")
