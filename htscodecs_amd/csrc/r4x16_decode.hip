@@ -152,19 +152,23 @@ __device__ __forceinline__ u32 lookup_step_pk(u32 row, u32x2 rootv, u32x2 rootw,
     }
     const u32 D0 = img0.ld32(ga), D1 = img0.ld32(ga + 4), D2 = img0.ld32(ga + 8), D3 = img0.ld32(ga + 12),
               D4 = img0.ld32(ga + 16);
-    // dword of three: the low fields of D1, D2, D3 are L[12g + 3], L[12g + 6], L[12g + 9]
-    const bool s0 = (D1 & 1023u) < m, s1 = (D2 & 1023u) < m, s2 = (D3 & 1023u) < m;
+    // dword of three.  A leaf dword holds L[3i + 1], L[3i + 2] in its guarded low fields and L[3i] in its TOP field, so
+    // the pivots L[12g + 3], L[12g + 6], L[12g + 9] are tested without extraction: top field < m  <=>  dword < m << 22.
+    const u32 m22 = m << 22;
+    const bool s0 = D1 < m22, s1 = D2 < m22, s2 = D3 < m22;
     u32 D = D0, Dn = D1;
     if (s0) { D = D1; Dn = D2; }
     if (s1) { D = D2; Dn = D3; }
     if (s2) { D = D3; Dn = D4; }
     const u32 q = (u32)s0 + (u32)s1 + (u32)s2;
-    // fields 1, 2 of D and field 0 of Dn, in the same guarded layout
-    const u32 Fu = (D >> 11) + (Dn << 22);
-    const u32 rneg = __popc((Fu + GM) & GB);                  // 2 - r,  r = #{fields 1, 2 of D below m}
+    // inside the dword: the two low fields against m by their guard bits
+    const u32 rneg = __popc((D + GM) & GB);                   // 2 - r,  r = #{L[3q + 1], L[3q + 2] below m}
     const u32 r11 = 22u - 11u * rneg;
-    const u32 prev = __builtin_amdgcn_ubfe(D, r11, 10);       // L[c]: end of the symbol before (1023 stands for -1)
-    const u32 cur = __builtin_amdgcn_ubfe(Fu, r11, 10);       // L[c + 1]: end of this symbol
+    // the candidates in stride-11 order: P = L[3q], L[3q + 1], L[3q + 2];  C = L[3q + 1], L[3q + 2], L[3q + 3]
+    const u32 P = (D << 11) | (D >> 22);
+    const u32 Cc = (D & 0x003fffffu) | (Dn & 0xffc00000u);    // (one v_bfi_b32)
+    const u32 prev = __builtin_amdgcn_ubfe(P, r11, 10);       // L[c]: end of the symbol before (1023 stands for -1)
+    const u32 cur = __builtin_amdgcn_ubfe(Cc, r11, 10);       // L[c + 1]: end of this symbol
     const u32 np = ~prev;
     const u32 fm1 = (cur + np) & 1023u;                       // freq - 1
     const u32 off = (m + np) & 1023u;                         // m - start
@@ -616,7 +620,7 @@ __device__ void write_row_pk(u8 *rowp, const FrontShared &S, u32 n, bool empty, 
                 auto sep = [&](u32 k) -> u32 { return (!empty && first + 12u * k <= n) ? L(12u * k) + 1u : 0x7fffu; };
                 v = sep(2u * lane + 1u) | (sep(2u * lane + 2u) << 16);
             }
-        } else { const u32 i = 3u * (lane - rdw); v = L(i) | (L(i + 1) << 11) | (L(i + 2) << 22); }
+        } else { const u32 i = 3u * (lane - rdw); v = L(i + 1) | (L(i + 2) << 11) | (L(i) << 22); }     // L[3i] on top: see lookup_step_pk
         ((u32 *)rowp)[lane] = v;
     }
 }
