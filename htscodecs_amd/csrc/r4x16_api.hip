@@ -61,10 +61,19 @@ extern "C" void rans4x16_hip_destroy(rans4x16_hip_ctx *c)
         for (auto &t : c->timed[w]) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     if (c->ws_done) (void)hipEventDestroy(c->ws_done);
     if (c->ws) (void)hipFree(c->ws);
+    if (c->xs) (void)hipFree(c->xs);
     if (c->stage) (void)hipFree(c->stage);
     if (c->logtab) (void)hipFree(c->logtab);
     if (c->rcptab) (void)hipFree(c->rcptab);
     delete c;
+}
+
+extern "C" int rans4x16_hip_set_dev_stripe_planes(rans4x16_hip_ctx *c, int planes, unsigned int max_block_size)
+{
+    if (!c || planes < 0 || planes > 255) return -1;
+    c->dev_stripe_planes = planes;
+    c->dev_stripe_out = max_block_size;
+    return 0;
 }
 
 extern "C" const char *rans4x16_hip_last_error(const rans4x16_hip_ctx *c) { return c ? c->err.c_str() : "no context"; }
@@ -210,6 +219,13 @@ extern "C" int rans4x16_hip_compress_dev(rans4x16_hip_ctx *c, int n,
     if (n == 0) return 0;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
+    if (!d_order && (order & X_STRIPE)) {                 // one order for all blocks: N and the candidate methods are host knowledge
+        BatchArgs sa;
+        sa.in = d_in; sa.in_off = d_in_off; sa.in_size = d_in_size;
+        sa.out = d_out; sa.out_off = d_out_off; sa.out_cap = d_out_cap; sa.out_size = d_out_size;
+        sa.status = d_status; sa.d_order = nullptr; sa.order = order; sa.n = n;
+        return r4x16_stripe_compress_dev(c, n, sa, order, max_in_size, s);
+    }
 
     // backward-write area per block: the order-1 bound of the largest block (covers the nested
     // table coder and the RLE meta stream as well)
@@ -282,9 +298,15 @@ extern "C" int rans4x16_hip_uncompress_dev(rans4x16_hip_ctx *c, int n,
         return -1;
     }
     if (n == 0) return 0;
-    (void)max_in_size;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
+    if (c->dev_stripe_planes > 0 && !c->in_stripe) {
+        BatchArgs sa;
+        sa.in = d_in; sa.in_off = d_in_off; sa.in_size = d_in_size;
+        sa.out = d_out; sa.out_off = d_out_off; sa.out_cap = d_out_cap; sa.out_size = d_out_size;
+        sa.status = d_status; sa.d_order = nullptr; sa.order = 0; sa.n = n;
+        return r4x16_stripe_uncompress_dev(c, n, sa, max_in_size, max_out_cap, c->dev_stripe_out, s);
+    }
 
     // PACK / RLE staging: one buffer of the output size, and room for the decoded run-length meta
     // (rANS_static4x16pr.c:1273: at most in_size + 257 bytes)

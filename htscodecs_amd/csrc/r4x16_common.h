@@ -27,6 +27,21 @@ typedef int32_t  i32;
 #define RANS_LOW (1u << 15)   // rANS_word.h:63
 #define O0_BITS  12           // rANS_static4x16pr.c:81
 
+// rans_compress_bound_4x16, rANS_static4x16pr.c:360-372: same expression, same evaluation order, in double
+static inline __host__ __device__ u32 r4x16_bound_hd(u32 size, int order)
+{
+    int N = order >> 8;
+    if (!N) N = 4;
+    order &= 0xff;
+    double d = (order == 0 ? 1.05 * size + 257 * 3 + 4
+                           : 1.05 * size + 257 * 257 * 3 + 4 + 257 * 3 + 4)
+             + ((order & X_PACK) ? 1 : 0)
+             + ((order & X_RLE) ? 1 + 257 * 3 + 4 : 0) + 20
+             + ((order & X_STRIPE) ? 1 + 5 * N : 0);
+    int sz = (int)d;
+    return (u32)(sz + (sz & 1) + 2);
+}
+
 // status codes mirror include/rans4x16_hip.h
 #define ST_OK 0
 #define ST_CAPACITY 1

@@ -20,19 +20,8 @@
 // ---------------------------------------------------------------------------------------------
 // rANS_static4x16pr.c:360-372, same expression, same evaluation order, in double.
 // ---------------------------------------------------------------------------------------------
-__host__ __device__ static inline u32 compress_bound(u32 size, int order)
-{
-    int N = order >> 8;
-    if (!N) N = 4;
-    order &= 0xff;
-    double d = (order == 0 ? 1.05 * size + 257 * 3 + 4
-                           : 1.05 * size + 257 * 257 * 3 + 4 + 257 * 3 + 4)
-             + ((order & X_PACK) ? 1 : 0)
-             + ((order & X_RLE) ? 1 + 257 * 3 + 4 : 0) + 20
-             + ((order & X_STRIPE) ? 1 + 5 * N : 0);
-    int sz = (int)d;
-    return (u32)(sz + (sz & 1) + 2);
-}
+// (the expression itself lives in r4x16_common.h: the stripe kernels need it too)
+__host__ __device__ static inline u32 compress_bound(u32 size, int order) { return r4x16_bound_hd(size, order); }
 
 // ---------------------------------------------------------------------------------------------
 // normalise_freq, rANS_static4x16pr.c:116-163, over `cnt` counters F[0..cnt) (zero = absent).

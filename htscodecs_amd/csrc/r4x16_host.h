@@ -36,6 +36,9 @@ struct HostPipe;
 void r4x16_pipe_destroy(HostPipe *);
 int r4x16_ensure_stage(rans4x16_hip_ctx *c, size_t bytes);
 void r4x16_trim(rans4x16_hip_ctx *c, size_t keep);
+int r4x16_stripe_compress_dev(rans4x16_hip_ctx *c, int n, const BatchArgs &a, int order, uint32_t max_in_size, hipStream_t s);
+int r4x16_stripe_uncompress_dev(rans4x16_hip_ctx *c, int n, const BatchArgs &a, uint32_t max_in_size, uint32_t max_out_cap,
+                                uint32_t max_stripe_out, hipStream_t s);
 int r4x16_run_host_batch(rans4x16_hip_ctx *c, int n, bool decode,
                           const unsigned char *const *in, const unsigned int *in_size,
                           unsigned char *const *out, unsigned int *out_size, const int *order, int *status);
@@ -55,6 +58,13 @@ struct rans4x16_hip_ctx {
     int timing = 0;
     std::vector<TimedLaunch> timed[2];
     size_t max_ws = (size_t)96 << 30;       // ceiling for one chunk of blocks (plan_chunk also looks at free memory)
+    // X_STRIPE in the device-resident calls (r4x16_stripe.hip): the arena of the internal items, and how many planes a
+    // device-resident decode batch reserves per block (0: stripe blocks report UNSUPPORTED there)
+    u8 *xs = nullptr;
+    size_t xs_bytes = 0;
+    int dev_stripe_planes = 0;
+    unsigned int dev_stripe_out = 0;        // largest uncompressed stripe block such a batch may hold
+    bool in_stripe = false;
     // calls on different streams are ordered on the one workspace through this event
     hipEvent_t ws_done = nullptr;
     hipStream_t ws_stream = nullptr;

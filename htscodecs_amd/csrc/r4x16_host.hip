@@ -38,6 +38,7 @@ void r4x16_trim(rans4x16_hip_ctx *c, size_t keep)
     (void)hipDeviceSynchronize();
     if (c->stage) { (void)hipFree(c->stage); c->stage = nullptr; c->stage_bytes = 0; }
     if (c->ws) { (void)hipFree(c->ws); c->ws = nullptr; c->ws_bytes = 0; }
+    if (c->xs) { (void)hipFree(c->xs); c->xs = nullptr; c->xs_bytes = 0; }
     c->ws_busy = false;
 }
 

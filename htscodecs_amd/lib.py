@@ -36,6 +36,7 @@ SIGNATURES = {
     "rans4x16_hip_timing": (None, [C.c_void_p, C.c_int]),
     "rans4x16_hip_timing_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]),
     "rans4x16_hip_version": (C.c_char_p, []),
+    "rans4x16_hip_set_dev_stripe_planes": (C.c_int, [C.c_void_p, C.c_int, C.c_uint]),
     "rans4x16_hip_device_clock_khz": (C.c_int, [C.c_void_p]),
     "rans4x16_hip_residency": (C.c_int, [C.c_void_p, C.c_int, C.c_uint, C.c_int, C.c_uint, C.POINTER(C.c_int),
                                         C.POINTER(C.c_int), C.POINTER(C.c_int)]),

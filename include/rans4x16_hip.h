@@ -112,7 +112,11 @@ int rans4x16_hip_compress_best_batch(rans4x16_hip_ctx *ctx, int n,
  * the stage buffers of X_PACK / X_RLE blocks only: it may be the largest output of THOSE blocks, 0 if the batch
  * has none (a transformed block larger than that reports UNSUPPORTED).
  * `stream` is a hipStream_t (NULL = default stream).  The call only enqueues work.
- * X_STRIPE (0x08) is handled by the host entry points, not by *_dev (status UNSUPPORTED).
+ * X_STRIPE (0x08), device-resident: encode accepts it when all blocks share one `order` (d_order == NULL): the
+ * planes, the N x K candidate encodings, the choice of the smallest per plane and the header are all produced on the
+ * device (rANS_static4x16pr.c:1154-1216); with per-block orders a stripe block reports UNSUPPORTED.  Decode accepts
+ * stripe blocks after rans4x16_hip_set_dev_stripe_planes (below); without it they report UNSUPPORTED.  The host
+ * entry points handle stripes in every case.
  * Returns 0 if enqueued, -1 on argument / allocation / launch errors. */
 int rans4x16_hip_compress_dev(rans4x16_hip_ctx *ctx, int n,
                               const unsigned char *d_in, const uint64_t *d_in_off,
@@ -128,6 +132,13 @@ int rans4x16_hip_uncompress_dev(rans4x16_hip_ctx *ctx, int n,
                                 const uint32_t *d_out_cap, uint32_t *d_out_size,
                                 int32_t *d_status, uint32_t max_in_size, uint32_t max_out_cap,
                                 void *stream);
+
+/* Device-resident decode of X_STRIPE blocks: the flag and the plane count N live in the stream, so the host cannot
+ * size the workspace per block; this sets what every block of later rans4x16_hip_uncompress_dev calls reserves:
+ * `planes` internal sub-blocks (the default N is 4) and a plane buffer of `max_block_size` bytes.  A stripe block
+ * with more planes, or larger than that, reports UNSUPPORTED; like the reference (:1379) a stripe block must be given
+ * an output capacity equal to its stored size.  planes == 0 (the default) switches it off.  Returns 0, -1 on bad arguments. */
+int rans4x16_hip_set_dev_stripe_planes(rans4x16_hip_ctx *ctx, int planes, unsigned int max_block_size);
 
 /* Bytes of device workspace the context currently holds (grows on demand, never shrinks). */
 size_t rans4x16_hip_workspace_bytes(const rans4x16_hip_ctx *ctx);

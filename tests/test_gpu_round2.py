@@ -282,3 +282,76 @@ def test_alphabet_that_grows_after_the_first_64_kib(H, oracle):
         assert all(s == 0 for s in st)
         for k, (d, e) in enumerate(zip(datas, enc)):
             assert e == oracle.compress(d, order), (k, order)
+
+
+def test_stripe_blocks_device_resident(H, oracle):
+    """X_STRIPE through rans4x16_hip_{compress,uncompress}_dev (r4x16_stripe.hip): planes, the N x K candidate
+    encodings, the per-plane arg-min and the header on the device (rANS_static4x16pr.c:1154-1216); decode with the
+    planes-per-block reservation.  The four stripe fixtures and the stripe edge shapes, bit-exact with the oracle;
+    ordinary blocks ride along in the same decode batch; blocks of <= 20 bytes drop the flag (:1151)."""
+    import torch
+    dc = H.DeviceCodec(0)
+    dev = dc.dev
+    L = H.load()
+    names = ["q4", "q8", "q40+dir", "qvar"]
+    rs = np.random.RandomState(89)
+    blocks = [datagen.base_text("q4").tobytes(), datagen.base_text("q40+dir").tobytes(), b"", b"a", b"abcdefghij" * 2, b"x" * 21,
+              datagen.tile("q8", 1000, 1).tobytes(), datagen.tile("qvar", 65537, 2).tobytes(), datagen.tile("q40+dir", 300003, 5).tobytes()]
+    blocks += [datagen.tile(names[k % 4], int(rs.randint(22, 5000)), k).tobytes() for k in range(30)]
+    n = len(blocks)
+    sizes = [len(b) for b in blocks]
+    in_off = np.cumsum([0] + [(s + 255) // 256 * 256 + 256 for s in sizes])[:-1].astype(np.int64)
+    arena = np.zeros(int(in_off[-1]) + sizes[-1] + 512, dtype=np.uint8)
+    for b, off in zip(blocks, in_off):
+        arena[off:off + len(b)] = np.frombuffer(b, dtype=np.uint8)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d_in = t(arena)
+    for order in (8, 9, 0x48, 0xc9, (2 << 8) | 9, (3 << 8) | 0xc9, (7 << 8) | 8):
+        want = [oracle.compress(b, order) for b in blocks]
+        caps = np.array([H.rans_compress_bound_4x16(s, order) for s in sizes], dtype=np.int32)
+        out_off = np.cumsum([0] + [(int(c) + 255) // 256 * 256 for c in caps])[:-1].astype(np.int64)
+        d_out = torch.zeros(int(out_off[-1]) + int(caps[-1]) + 256, dtype=torch.uint8, device=dev)
+        d_osz = torch.zeros(n, dtype=torch.int32, device=dev)
+        d_st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        dc.compress(d_in, t(in_off), t(np.array(sizes, dtype=np.int32)), d_out, t(out_off), t(caps), d_osz, d_st, order, max(sizes))
+        torch.cuda.synchronize()
+        st, osz, comp = d_st.cpu().numpy(), d_osz.cpu().numpy(), d_out.cpu().numpy()
+        assert (st == 0).all(), (order, st.tolist())
+        for i in range(n):
+            assert comp[out_off[i]:out_off[i] + osz[i]].tobytes() == want[i], (order, i, sizes[i])
+        # decode on the device: the stripe streams just made, with two ordinary streams mixed in
+        N = (order >> 8) or 4
+        assert L.rans4x16_hip_set_dev_stripe_planes(dc.ctx.h, N, max(sizes)) == 0
+        plain = [oracle.compress(blocks[6], 1), oracle.compress(blocks[8], 193)]
+        streams = want + plain
+        plains = blocks + [blocks[6], blocks[8]]
+        m = len(streams)
+        c_off = np.cumsum([0] + [(len(s) + 255) // 256 * 256 + 256 for s in streams])[:-1].astype(np.int64)
+        carena = np.zeros(int(c_off[-1]) + len(streams[-1]) + 512, dtype=np.uint8)
+        for sdata, off in zip(streams, c_off):
+            carena[off:off + len(sdata)] = np.frombuffer(sdata, dtype=np.uint8)
+        u_sizes = np.array([len(p) for p in plains], dtype=np.int32)
+        u_off = np.cumsum([0] + [(len(p) + 255) // 256 * 256 + 256 for p in plains])[:-1].astype(np.int64)
+        d_dec = torch.zeros(int(u_off[-1]) + len(plains[-1]) + 512, dtype=torch.uint8, device=dev)
+        d_dsz = torch.zeros(m, dtype=torch.int32, device=dev)
+        d_dst = torch.full((m,), -1, dtype=torch.int32, device=dev)
+        dc.uncompress(t(carena), t(c_off), t(np.array([len(s) for s in streams], dtype=np.int32)), d_dec, t(u_off), t(u_sizes),
+                      d_dsz, d_dst, max(len(s) for s in streams), max(sizes))
+        torch.cuda.synchronize()
+        dst, dsz, dec = d_dst.cpu().numpy(), d_dsz.cpu().numpy(), d_dec.cpu().numpy()
+        for i, p in enumerate(plains):
+            ref = oracle.uncompress(streams[i], capacity=len(p), out_size_hint=len(p))
+            assert ref == p
+            assert dst[i] == 0 and dsz[i] == len(p), (order, i, int(dst[i]))
+            assert dec[u_off[i]:u_off[i] + len(p)].tobytes() == p, (order, i)
+        # a stream with more planes than reserved is refused, its neighbours are not
+        assert L.rans4x16_hip_set_dev_stripe_planes(dc.ctx.h, 1, max(sizes)) == 0
+        d_dst.fill_(-1)
+        dc.uncompress(t(carena), t(c_off), t(np.array([len(s) for s in streams], dtype=np.int32)), d_dec, t(u_off), t(u_sizes),
+                      d_dsz, d_dst, max(len(s) for s in streams), max(sizes))
+        torch.cuda.synchronize()
+        dst = d_dst.cpu().numpy()
+        assert dst[-1] == 0 and dst[-2] == 0
+        if N > 1:
+            assert dst[0] == 6
+        assert L.rans4x16_hip_set_dev_stripe_planes(dc.ctx.h, 0, 0) == 0
