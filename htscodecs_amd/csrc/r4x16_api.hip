@@ -181,9 +181,8 @@ static size_t enc_ws_layout(u8 *base, size_t nblk, u64 scratch_stride, u64 xf_st
 {
     Carver cv(base);
     w->desc = cv.take<EncDesc>(nblk);
-    w->items = cv.take<EncItem>(2 * nblk);
+    w->items = cv.take<EncItem>(3 * nblk);         // payload, RLE meta, nested order-1 table
     w->images = cv.take<u8>(nblk, ENC_IMG_BYTES);
-    w->tabraw = cv.take<u8>(nblk, TAB_BYTES);
     w->tab = cv.take<u8>(nblk, TAB_BYTES);
     w->scratch = cv.take<u8>(nblk, scratch_stride);
     w->F = cv.take<u32>(nblk * 65536);
@@ -195,8 +194,8 @@ static size_t enc_ws_layout(u8 *base, size_t nblk, u64 scratch_stride, u64 xf_st
     w->scratch2 = cv.take<u8>(nblk, scratch2_stride);
     w->stat = cv.take<EncStat>(nblk);
     w->dump = cv.take<u8>(1, ENC_DUMP_BYTES);
-    w->cls = cv.take<u32>(2 * nblk);
-    w->cls_list = cv.take<u32>(2 * nblk);
+    w->cls = cv.take<u32>(3 * nblk);
+    w->cls_list = cv.take<u32>(3 * nblk);
     w->cls_count = cv.take<u32>(3 * CLS_MAX);
     w->xf_stride = xf_stride;
     w->scratch2_stride = scratch2_stride;
@@ -259,7 +258,7 @@ extern "C" int rans4x16_hip_compress_dev(rans4x16_hip_ctx *c, int n,
         r4x16_launch_enc_tables(&a, &w, (int)base, nb, s);
         TimedLaunch t;
         if (c->timing) time_begin(c, 0, s, t);
-        r4x16_launch_enc_chain(&w, 2 * nb, s);
+        r4x16_launch_enc_chain(&w, 3 * nb, s);
         if (c->timing) time_end(c, 0, s, t);
         r4x16_launch_enc_finish(&a, &w, (int)base, nb, s);
     }

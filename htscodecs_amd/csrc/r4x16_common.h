@@ -240,6 +240,9 @@ struct EncDesc {
     u32 cat;         // 1: copy `data` raw (explicit X_CAT)
     u32 tab_len;     // bytes of table (incl. order-1 header byte) staged in tab[]
     u64 tab;         // device address of the staged table bytes
+    u32 nest_on;     // 1: the order-1 table is also coded as an order-0 stream (third chain item); k_enc_finish picks
+    u32 nest_tab_len;//    the smaller form (rANS_static4x16pr.c:766-780).  Its own order-0 table: nest_tab[0..nest_tab_len)
+    u64 nest_tab;
     u32 rle_on, rle_mlen, rle_lits;   // RLE meta bookkeeping (meta raw bytes at rle_meta)
     u32 meta_tab_len;
     u64 rle_meta;
@@ -285,9 +288,8 @@ struct EncStat {
 
 struct EncWs {
     EncDesc *desc;      // [nblk]
-    EncItem *items;     // [2*nblk]  [b] = payload stream of block b, [nblk+b] = its RLE meta stream
+    EncItem *items;     // [3*nblk]  [b] = payload stream of block b, [nblk+b] = its RLE meta stream, [2*nblk+b] = its order-1 table
     u8 *images;         // [nblk][ENC_IMG_BYTES]
-    u8 *tabraw;         // [nblk][TAB_BYTES]  serialised order-1 table before nesting
     u8 *tab;            // [nblk][TAB_BYTES]  table bytes as they go into the stream
     u8 *scratch;        // [nblk][scratch_stride]  backward-written states + words
     u32 *F;             // [nblk][65536]  order-1 counters when the alphabet is too big for LDS

@@ -1256,7 +1256,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
 {
     extern __shared__ __attribute__((aligned(16))) u8 dyn[];
     __shared__ EncShared S;
-    __shared__ struct { i32 status; u32 go, order, dlen, nested_len, flags, hl, run; u64 data; double e10, e12; int max_tot; } H;
+    __shared__ struct { i32 status; u32 go, order, dlen, nested_len, flags, hl, run; u64 data; double e10, e12; int max_tot; u32 wcnt[4]; } H;
 
     // Wave 0 runs the whole front end; waves 1..3 join only for the two histogram passes over the
     // block (the bulk of the memory traffic).  Inside wave-0-only code the ordering points are
@@ -1275,7 +1275,6 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
     int order = a.d_order ? a.d_order[i] : a.order;
     u8 *img = ws.images + (u64)b * ENC_IMG_BYTES;
     u8 *tab = ws.tab + (u64)b * TAB_BYTES;
-    u8 *tabraw = ws.tabraw + (u64)b * TAB_BYTES;
     u8 *scratch = ws.scratch + (u64)b * ws.scratch_stride;
     u8 *scratch_end = scratch + ws.scratch_stride;
 
@@ -1283,9 +1282,11 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
     if (tid == 0) {
         H.run = 0;
         ws.stat[b].run = 0;
+        EncItem *I2 = &ws.items[2 * gridDim.x + b];                        // the order-1 table as an order-0 stream (k_enc_tables)
         I0->active = 0; I1->active = 0; I0->pay_len = 0; I1->pay_len = 0; I0->packed = 0; I1->packed = 0;
-        I0->blk = b; I1->blk = b;
-        D->cat = 0; D->rle_on = 0; D->tab_len = 0; D->hdr_len = 0; D->dlen = 0; D->tab = (u64)tab;
+        I2->active = 0; I2->pay_len = 0; I2->packed = 0;
+        I0->blk = b; I1->blk = b; I2->blk = b;
+        D->cat = 0; D->rle_on = 0; D->tab_len = 0; D->hdr_len = 0; D->dlen = 0; D->tab = (u64)tab; D->nest_on = 0;
         i32 st = ST_OK;
         u32 go = 0;
         H.flags = 0; H.hl = 0;
@@ -1438,14 +1439,17 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
         const bool prov = attempt == 0;                                   // provisional alphabet + overflow symbol
         if (attempt == 1 && sampled) wg_present8(data, n, S.F, S.pmask, tid);
         // compact alphabet F0 from the presence flags (0 forced in, :731); absent bytes map to the overflow symbol
-        if (tid == 0) {
-            u32 k = 0;
-            for (u32 j = 0; j < 256; j++) {
-                S.present[j] = (S.F[j] != 0) || j == 0;
-                if (S.present[j]) { S.idx_of[j] = (u8)k; S.alpha[k] = (u8)j; k++; }
-            }
-            if (prov) for (u32 j = 0; j < 256; j++) if (!S.present[j]) S.idx_of[j] = (u8)(k < 255 ? k : 255);
-            S.nsym = k;
+        {   // one byte value per thread (FRONT_THREADS == 256): rank among the present ones by ballot + wave counts
+            const bool pr = S.F[tid] != 0 || tid == 0;
+            const u64 bal = __ballot(pr);
+            if (lane == 0) H.wcnt[tid >> 6] = (u32)__popcll(bal);
+            __syncthreads();
+            u32 k = (u32)__popcll(bal & ((1ull << lane) - 1ull)), tot = 0;
+            for (u32 w = 0; w < 4; w++) { const u32 c = H.wcnt[w]; tot += c; if (w < (tid >> 6)) k += c; }
+            S.present[tid] = pr;
+            if (pr) { S.idx_of[tid] = (u8)k; S.alpha[k] = (u8)tid; }
+            else if (prov) S.idx_of[tid] = (u8)(tot < 255 ? tot : 255);
+            if (tid == 0) S.nsym = tot;
         }
         __syncthreads();
         ns = S.nsym;
@@ -1480,15 +1484,18 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
 // everything between the histograms and the chain kernel — normalisation, the 10/12-bit decision,
 // table serialisation (nested coding included) and the encoder image.
 // ---------------------------------------------------------------------------------------------
-#define TABLES_DYN_LDS 10240u          // pair counters of alphabets up to 50 symbols; later the nested coder
+#define TABLES_DYN_LDS 10240u          // pair counters of alphabets up to 50 symbols
 #define TABLES_LDS_NSYM 50u
-#define TABLES_NEST_MAX 8192u          // nested table bytes that fit next to a 1,024-byte image and 256 reciprocals
+// nested table stream: order-0 table (< 1 KB) at the bottom, payload written down from NEST_AREA.  The largest
+// serialised order-1 table is 256 rows of 256 two-byte entries and the alphabet, ~132 KB; its order-0 coding stays
+// below 1.05 x that + 16.
+#define NEST_AREA 196608u
 
 __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int base)
 {
     extern __shared__ __attribute__((aligned(16))) u8 dyn[];
     __shared__ EncShared S;
-    __shared__ struct { i32 status; u32 nested_len; double e10, e12; int max_tot; } H;
+    __shared__ struct { i32 status; double e10, e12; int max_tot; } H;
     const u32 lane = threadIdx.x;
     const u32 b = blockIdx.x;
     EncDesc *D = &ws.desc[b];
@@ -1497,7 +1504,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
     if (D->status != ST_OK || !ST->run) return;
     u8 *img = ws.images + (u64)b * ENC_IMG_BYTES;
     u8 *tab = ws.tab + (u64)b * TAB_BYTES;
-    u8 *tabraw = ws.tabraw + (u64)b * TAB_BYTES;
+    u8 *tabraw = tab + 1;                                 // the serialised order-1 table, behind its header byte
     u8 *scratch = ws.scratch + (u64)b * ws.scratch_stride;
     u8 *scratch_end = scratch + ws.scratch_stride;
     const u8 *data = (const u8 *)D->data;
@@ -1682,67 +1689,31 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
     wsync();
 
     TPROF(4);
-    // ---- table into the stream, nested order-0 if it pays (:766-780) ------------------------------
-    u32 final_len = 0;
-    bool nested = false;
+    // ---- table into the stream (:766-780) -----------------------------------------------------------
+    // A table of 1,000 bytes and more is also coded as an order-0 stream, and the shorter form goes out.  That
+    // stream is a chain item of its own (four lanes for ~3,000 steps inside this one-wave kernel were 38 % of it on
+    // 64 KiB quality blocks); k_enc_finish compares the lengths.  Its byte histogram, table and image are made here.
+    // Where it lives: the low NEST_AREA bytes of the block's backward-write area - the part of the order-1 bound
+    // that stands for the table (257*257*3) and that the payload, written down from the top, never reaches.
+    if (lane == 0) tab[0] = (u8)(bits << 4);
     if (1 + tlen > 1000) {
-        u8 *ntab = scratch;                                           // nested table bytes, staged low
-        u32 npay;
-        if (f_in_lds && tlen <= TABLES_NEST_MAX) {
-            // the counters in `dyn` are spent: reuse the space for the table bytes and the coder's
-            // one-row image, so that the 4-lane coder of this small stream never leaves the CU
-            u8 *ltab = dyn, *limg = dyn + TABLES_NEST_MAX;
-            u32 *lrcp = (u32 *)(dyn + TABLES_NEST_MAX + ENC_IMG_O0);
-            __threadfence();
-            wsync();
-            wave_copy(ltab, tabraw, tlen, lane);
-            wsync();
-            enc_o0_front(ltab, tlen, ntab, limg, S, lane);
-            __threadfence();
-            wsync();
-            {   // reciprocals of the row's 256 slots, fetched together (the 4-lane coder would fetch one per
-                // step from L2, each a dependent round trip)
-                const u16 *c = (const u16 *)(limg + ENC_IMG_IDX);
-                for (u32 j = lane; j < 256; j += WAVE) lrcp[j] = enc_rcp(to_global(ws.rcptab), (u32)c[j + 1] - (u32)c[j]);
-                wsync();
-            }
-            npay = chain_encode_o0_lds(limg, (const u8 *)ltab, tlen, O0_BITS, to_global(ws.rcptab),
-                                       to_global(scratch_end), lane < 4, lane, lrcp);
-        } else {
-            u8 *img0 = img + ENC_IMG_NESTED;
-            enc_o0_front(tabraw, tlen, ntab, img0, S, lane);
-            __threadfence();
-            wsync();
-            npay = chain_encode<0>(to_global((const u8 *)tabraw), tlen, to_global((const u8 *)img0), 256u,
-                                   O0_BITS, to_global(ws.rcptab), to_global(scratch_end), lane < 4, lane);
-        }
-        const u32 np = __shfl(npay, 0);
+        u8 *ntab = scratch;                                           // the nested stream's own order-0 table
+        u8 *img0 = img + ENC_IMG_NESTED;
         __threadfence();
         wsync();
-        const u32 nlen = S.tab_len + np;
-        if (S.status == ST_OK && nlen + 6 < 1 + tlen) {               // :772
-            nested = true;
-            u32 hl = 0;
-            if (lane == 0) {
-                tab[0] = (u8)((bits << 4) | 1);
-                hl = 1;
-                hl += var_put(tab + hl, tlen);
-                hl += var_put(tab + hl, nlen);
-                H.nested_len = hl;
-            }
-            wsync();
-            hl = H.nested_len;
-            wave_copy(tab + hl, ntab, S.tab_len, lane);
-            wave_copy(tab + hl + S.tab_len, scratch_end - np, np, lane);
-            final_len = hl + nlen;
+        enc_o0_front(tabraw, tlen, ntab, img0, S, lane);
+        if (lane == 0 && S.status == ST_OK) {
+            EncItem *I2 = &ws.items[2 * gridDim.x + b];
+            D->nest_on = 1; D->nest_tab = (u64)ntab; D->nest_tab_len = S.tab_len;
+            I2->data = (u64)tabraw; I2->n = tlen; I2->image = (u64)img0; I2->bits = O0_BITS; I2->order = 0;
+            I2->ns = 256; I2->img_bytes = ENC_IMG_IDX + 2u * 257u;
+            I2->scratch_end = (u64)(scratch + NEST_AREA);
+            __threadfence();
+            I2->active = 1;
         }
     }
     TPROF(5);
-    if (!nested) {
-        if (lane == 0) tab[0] = (u8)(bits << 4);
-        wave_copy(tab + 1, tabraw, tlen, lane);
-        final_len = 1 + tlen;
-    }
+    const u32 final_len = 1 + tlen;
     wsync();
     if (lane == 0) {
         D->tab_len = final_len;
@@ -1847,7 +1818,7 @@ __global__ __launch_bounds__(FINISH_THREADS) void k_enc_finish(BatchArgs a, EncW
     const u32 b = blockIdx.x;
     const int i = base + (int)b;
     const EncDesc *D = &ws.desc[b];
-    const EncItem *I0 = &ws.items[b], *I1 = &ws.items[gridDim.x + b];
+    const EncItem *I0 = &ws.items[b], *I1 = &ws.items[gridDim.x + b], *I2 = &ws.items[2 * gridDim.x + b];
     u8 *out = a.out + a.out_off[i];
     const i32 st = D->status;
     if (st != ST_OK) {
@@ -1887,14 +1858,38 @@ __global__ __launch_bounds__(FINISH_THREADS) void k_enc_finish(BatchArgs a, EncW
             }
         }
         const u32 pay = I0->active ? I0->pay_len : 0;
-        const u32 plen = D->tab_len + pay;
+        // order-1 table: as serialised, or as the order-0 stream the chain kernel made of it (:766-780)
+        u32 tab_len = D->tab_len;
+        const u32 tlen = tab_len - 1;
+        const u32 npay = D->nest_on ? I2->pay_len : 0;
+        const u32 nlen = D->nest_tab_len + npay;
+        const bool nested = D->nest_on && nlen + 6 < tab_len;         // :772
+        if (nested) tab_len = 1 + var_len(tlen) + var_len(nlen) + nlen;
+        const u32 plen = tab_len + pay;
         if (plen >= dlen) {                                           // :1332-1337
             flags = (flags & ~3u) | X_CAT | D->nosz;
             group_copy<FINISH_THREADS>(out + pos, (const u8 *)D->data, dlen, lane);
             pos += dlen;
         } else {
-            group_copy<FINISH_THREADS>(out + pos, (const u8 *)D->tab, D->tab_len, lane);
-            pos += D->tab_len;
+            if (nested) {
+                __syncthreads();                                      // (vbuf may still be read for the RLE header)
+                if (lane == 0) {
+                    vbuf[0] = (u8)(((const u8 *)D->tab)[0] | 1);
+                    u32 l = 1 + var_put(vbuf + 1, tlen);
+                    l += var_put(vbuf + l, nlen);
+                    vlen = l;
+                }
+                __syncthreads();
+                if (lane < vlen) out[pos + lane] = vbuf[lane];
+                pos += vlen;
+                group_copy<FINISH_THREADS>(out + pos, (const u8 *)D->nest_tab, D->nest_tab_len, lane);
+                pos += D->nest_tab_len;
+                group_copy<FINISH_THREADS>(out + pos, (const u8 *)I2->scratch_end - npay, npay, lane);
+                pos += npay;
+            } else {
+                group_copy<FINISH_THREADS>(out + pos, (const u8 *)D->tab, D->tab_len, lane);
+                pos += D->tab_len;
+            }
             group_copy<FINISH_THREADS>(out + pos, (const u8 *)I0->scratch_end - pay, pay, lane);
             pos += pay;
         }
