@@ -185,7 +185,6 @@ static size_t enc_ws_layout(u8 *base, size_t nblk, u64 scratch_stride, u64 xf_st
     w->images = cv.take<u8>(nblk, ENC_IMG_BYTES);
     w->tab = cv.take<u8>(nblk, TAB_BYTES);
     w->scratch = cv.take<u8>(nblk, scratch_stride);
-    w->F = cv.take<u32>(nblk * 65536);
     w->scratch_stride = scratch_stride;
     w->packed = cv.take<u8>(nblk, xf_stride);
     w->lits = cv.take<u8>(nblk, xf_stride);
@@ -228,7 +227,7 @@ extern "C" int rans4x16_hip_compress_dev(rans4x16_hip_ctx *c, int n,
 
     // backward-write area per block: the order-1 bound of the largest block (covers the nested
     // table coder and the RLE meta stream as well)
-    const u64 scratch_stride = align_up((size_t)r4x16_compress_bound(max_in_size, 0xc1) + 64, 256);
+    const u64 scratch_stride = align_up(std::max((size_t)r4x16_compress_bound(max_in_size, 0xc1) + 64, (size_t)ENC_F_BYTES), 256);
     // X_PACK / X_RLE staging only when some block may ask for it (per-block orders: assume yes)
     const bool xf = d_order != nullptr || (order & (X_PACK | X_RLE));
     const u64 xf_stride = xf ? align_up((size_t)max_in_size + 64, 256) : 0;
@@ -270,7 +269,8 @@ static size_t dec_ws_layout(u8 *base, size_t nblk, u64 tmp_stride, u64 meta_stri
 {
     Carver cv(base);
     w->desc = cv.take<DecDesc>(nblk);
-    w->items = cv.take<DecItem>(2 * nblk);
+    w->items = cv.take<DecItem>(3 * nblk);
+    w->resume = cv.take<DecResume>(nblk);
     w->images = cv.take<u8>(nblk, (size_t)DEC_IMG_SLOT);
     w->tbuf = cv.take<u8>(nblk, TBUF_BYTES);
     w->tmp = cv.take<u8>(nblk, tmp_stride);
@@ -601,7 +601,7 @@ extern "C" int rans4x8_hip_compress_dev(rans4x16_hip_ctx *c, int n,
     if (n == 0) return 0;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
-    const u64 scratch_stride = align_up((size_t)r4x8_compress_bound(max_in_size) + 64, 256);
+    const u64 scratch_stride = align_up(std::max((size_t)r4x8_compress_bound(max_in_size) + 64, (size_t)ENC_F_BYTES), 256);
     EncWs w;
     const size_t per_blk = enc_ws_layout(nullptr, 1, scratch_stride, 0, 0, &w) + 4096;
     size_t chunk = plan_chunk(c, (size_t)n, per_blk);

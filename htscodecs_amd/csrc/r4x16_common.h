@@ -258,9 +258,15 @@ struct EncDesc {
 
 #define CLS_MAX  48u
 #define CLS_NONE 0xffffffffu
+// An order-1 block whose table is itself an order-0 stream (rANS_static4x16pr.c:944-955): k_dec_front<0> hands that
+// stream to the chain kernel as an item of its own and leaves what k_dec_front<1> needs to carry on from the decoded
+// table bytes.
+struct DecResume { u32 pending, pay_pos, pay_len, s1_size, bits, usz, after_table, pad; };
+
 struct DecWs {
     DecDesc *desc;     // [nblk]
-    DecItem *items;    // [2*nblk]   [b] = payload stream of block b, [nblk+b] = its RLE meta stream
+    DecItem *items;    // [3*nblk]   [b] = payload stream of block b, [nblk+b] = its RLE meta stream, [2*nblk+b] = its nested table
+    DecResume *resume; // [nblk]
     u8 *images;        // [nblk][DEC_IMG_SLOT]
     u8 *tbuf;          // [nblk][TBUF_BYTES]
     u8 *tmp;           // [nblk][tmp_stride]   stage buffer for PACK / RLE
@@ -268,7 +274,7 @@ struct DecWs {
     u64 tmp_stride, meta_stride;
     // streams grouped by LDS size class on the device (k_dec_classify .. k_cls_scatter), so that every chain
     // workgroup gets a full set of streams of its class whatever the mix of blocks in the batch
-    u32 *cls;          // [2*nblk]  class of each item (CLS_NONE: nothing to run)
+    u32 *cls;          // [2*nblk]  class of each item (CLS_NONE: nothing to run)   (the nested tables' pass uses the first nblk)
     u32 *cls_list;     // [2*nblk]  item indices, grouped by class
     u32 *cls_count;    // [3][CLS_MAX]  per class: number of items, first position in cls_list, fill cursor
 };
@@ -292,7 +298,6 @@ struct EncWs {
     u8 *images;         // [nblk][ENC_IMG_BYTES]
     u8 *tab;            // [nblk][TAB_BYTES]  table bytes as they go into the stream
     u8 *scratch;        // [nblk][scratch_stride]  backward-written states + words
-    u32 *F;             // [nblk][65536]  order-1 counters when the alphabet is too big for LDS
     const double *logtab;   // [2][257]  log(1024+k), log(4096+k) from the host libm (:651-652)
     const u32 *rcptab;      // [4097]    reciprocal by frequency (rANS_word.h:252), shared by all streams
     u64 scratch_stride;
@@ -308,5 +313,6 @@ struct EncWs {
     u32 *cls, *cls_list, *cls_count;   // streams grouped by LDS size class (as in DecWs)
 };
 #define META_TAB_BYTES 1024u
+#define ENC_F_BYTES    262144u                          // 256 x 256 pair counters (bottom of a block's scratch area)
 #define ENC_DUMP_BYTES 65536u
 

@@ -682,10 +682,194 @@ __device__ __forceinline__ void o0_front(ByteSrc &src, u32 pos, u32 len, u32 out
 // ---------------------------------------------------------------------------------------------
 // k_dec_front
 // ---------------------------------------------------------------------------------------------
+// Order-1 frequency tables (:958-998) into the decoder image, then the payload item.  `tsrc` / `tend`: the table bytes -
+// the input itself, or tbuf where the table came as a nested order-0 stream.  One wave.
+__device__ void o1_tables(const u8 *in, ByteSrc &src, const u8 *tbuf, bool compressed, u32 bits, u32 tab_pos, u32 usz, u32 after_table,
+                          u32 pay_pos, u32 pay_len, u32 s1_size, u8 *img, DecDesc *D, DecItem *I0, FrontShared &S, i32 *hst, u32 lane)
+{
+    const u32 look = bits == 12 ? 12 : 10;                             // :1027, :1071
+    ByteSrc tsrc(compressed ? tbuf : in);      // tbuf was never read by this CU before the fence above
+    const u32 tend = compressed ? usz : pay_pos + pay_len;
+
+    // alphabet F0 (:958-965) and the compact alphabet F0 ∪ {0}
+    for (u32 j = lane; j < 256; j += WAVE) S.present[j] = 0;
+    __syncthreads();
+    if (lane == 0) {
+        u32 p = compressed ? 0 : tab_pos;
+        const u32 used = get_alphabet(tsrc, p, tend, S.present);
+        p += used;
+        i32 st = ST_OK;
+        if (!used || p >= tend) st = ST_TABLE;
+        u32 n = 0;
+        for (u32 j = 0; j < 256; j++)
+            if (S.present[j] || j == 0) { S.idx_of[j] = (u8)n; S.alpha[n] = (u8)j; n++; }
+        S.nsym = n;
+        S.pos = p;
+        *hst = st;
+    }
+    __syncthreads();
+    if (*hst != ST_OK) { if (lane == 0) D->status = *hst; return; }
+
+    const u32 nsym = S.nsym;
+    // 10-bit tables of quality-sized alphabets take the packed rows (smaller images: more streams per CU)
+    const bool packed = bits == 10 && nsym >= PK_MIN_NSYM && nsym <= PKW_MAX_NSYM;
+    const u32 stride = packed ? pk_row_bytes(nsym) : img_row_bytes(nsym);
+    u8 *rows0 = img + img_alpha_bytes(nsym);
+
+    // Every row lists a frequency for each member of F0 (decode_freq_d :327-358): rank them once.
+    if (lane == 0) {
+        u32 k = 0;
+        for (u32 c = 0; c < nsym; c++) S.rankof[c] = S.present[S.alpha[c]] ? (u16)k++ : (u16)0xffff;
+        S.np = k;
+    }
+    __syncthreads();
+    const u32 np = S.np;
+    // The parsing lane reads the table through a 1 KB register window (un-nested tables sit in tbuf, whose
+    // slot may be read past the table's end); a raw table inside the input keeps the plain reader.
+    WinSrc win(&tsrc);
+    const u32 wlimit = compressed ? TBUF_BYTES : 0u;
+
+    // rows, in byte order of the compact alphabet (:967-998)
+    for (u32 ci = 0; ci < nsym; ci++) {
+        {   // all lanes: clear the row's frequencies, keep the window ahead of the parse position
+            for (u32 c = lane; c < np; c += WAVE) S.Fk[c] = 0;
+            const u32 pos_now = S.pos;
+            if (wlimit && (win.wlen == 0 || pos_now < win.wbase || pos_now + 800u > win.wbase + win.wlen)) win.fill(pos_now, wlimit, lane);
+        }
+        __syncthreads();
+        u32 total = 0;
+        if (lane == 0) {
+            const u32 ctx = S.alpha[ci];
+            S.empty = 0;
+            S.go = 1;
+            if (!S.present[ctx]) {
+                S.empty = 1;                                           // byte 0 outside F0
+            } else {
+                // decode_freq_d :327-358: one value per ranked member, zero runs as (0, count - 1)
+                u32 p = S.pos, zeros = 0;
+                bool ok = p != tend;
+                // a row is at most 6 bytes per member; when that much lies inside the window and before the
+                // end of the table, no byte of the row needs a bounds check
+                if (ok && p >= win.wbase && p + 6u * np + 6u <= win.wbase + win.wlen && p + 6u * np + 6u <= tend) {
+                    for (u32 k = 0; k < np; k++) {
+                        u32 f = 0;
+                        if (zeros) zeros--;
+                        else {
+                            u32 c;
+                            do { c = win.at_inside(p++); f = (f << 7) | (c & 0x7fu); } while (c & 0x80u);   // varint.h:131-160
+                            if (f == 0) zeros = win.at_inside(p++);
+                        }
+                        S.Fk[k] = f;
+                        total += f;
+                    }
+                } else
+                for (u32 k = 0; ok && k < np && p < tend; k++) {
+                    u32 f;
+                    if (zeros) { f = 0; zeros--; }
+                    else {
+                        p += var_get(win, p, tend, &f);
+                        if (f == 0) {
+                            if (p >= tend) { ok = false; break; }
+                            zeros = win.at(p++);
+                        }
+                    }
+                    S.Fk[k] = f;
+                    total += f;
+                }
+                if (!ok || p == S.pos) { *hst = ST_TABLE; S.go = 0; }
+                else {
+                    S.pos = p;
+                    if (total == 0) S.empty = 1;                       // :977-980
+                }
+            }
+            ((u16 *)img)[ci] = (u16)(ctx | (S.empty ? ROW_EMPTY : 0u));
+        }
+        __syncthreads();
+        if (!S.go) break;
+        if (!S.empty) {
+            // cumulative starts by the whole wave (normalise_freq_shift :168-179 and the checks at :985-997):
+            // four compact symbols per lane, scaled, prefix-summed
+            total = __shfl(total, 0);
+            u32 sh = 0;
+            if (total != (1u << bits)) { u32 size = total; while (size < (1u << bits)) { size *= 2; sh++; } }
+            u32 f[4], sum = 0, lowest = 4;
+            bool bad = false;
+#pragma unroll
+            for (u32 c = 0; c < 4; c++) {
+                const u32 cc = 4 * lane + c;
+                const u32 rk = cc < nsym ? S.rankof[cc] : 0xffffu;
+                f[c] = rk != 0xffffu ? S.Fk[rk] << sh : 0u;
+                bad |= f[c] > (1u << bits);
+                sum += f[c];
+                if (f[c] && lowest == 4) lowest = c;
+            }
+            if (packed) {                                              // first symbol of the row with a frequency
+                const u64 has = __ballot(lowest != 4);
+                const int fl = has ? __ffsll((unsigned long long)has) - 1 : 0;
+                const u32 fst = (u32)__shfl((int)(4 * lane + (lowest & 3u)), fl);
+                if (lane == 0) S.first = has ? fst : 0u;
+            }
+            const bool anybad = wave_any(bad);
+            if (anybad) sum = 0;                                       // keeps the scan below from wrapping
+            const u32 incl = wave_incl_scan(sum, lane);
+            u32 x = incl - sum;
+#pragma unroll
+            for (u32 c = 0; c < 4; c++) {
+                const u32 cc = 4 * lane + c;
+                if (cc < nsym) S.cum[cc] = (u16)x;
+                x += f[c];
+            }
+            const u32 tot = __shfl(incl, WAVE - 1);
+            if (lane == 0) {
+                if (anybad || tot != (1u << bits)) { *hst = ST_TABLE; S.go = 0; }
+                S.cum[nsym] = (u16)tot;
+                S.cum[nsym + 1] = S.cum[nsym + 2] = S.cum[nsym + 3] = 0x7fffu;
+            }
+            __syncthreads();
+            if (!S.go) break;
+        }
+        if (packed) {
+            if (lane == 0 && !S.empty) ((u16 *)img)[ci] |= (u16)(S.first << PK_FIRST_SHIFT);
+            write_row_pk(rows0 + (u64)ci * stride, S, nsym, S.empty != 0, lane);
+        } else
+            write_row(rows0 + (u64)ci * stride, S, nsym, S.empty != 0, lane);
+        __syncthreads();
+    }
+    if (*hst != ST_OK) { if (lane == 0) D->status = *hst; return; }
+
+    if (lane == 0) {
+        u32 p = compressed ? after_table : S.pos;                    // :1000-1001
+        const u32 end = pay_pos + pay_len;
+        i32 st = ST_OK;
+        if (p + 16 > end) st = ST_TRUNCATED;                           // :1005
+        else {
+            for (u32 k = 0; k < 4; k++, p += 4) {
+                const u32 r = (u32)src.at(p) | ((u32)src.at(p + 1) << 8) |
+                              ((u32)src.at(p + 2) << 16) | ((u32)src.at(p + 3) << 24);
+                I0->R[k] = r;
+                if (r < RANS_LOW) st = ST_STATE;                       // :1010-1013
+            }
+        }
+        D->status = st;
+        if (st == ST_OK) {
+            I0->words = (u64)(in + p);
+            I0->words_len = end - p;
+            I0->out = D->s1; I0->out_sz = s1_size; I0->image = (u64)img;
+            I0->img_bytes = packed ? pk_img_bytes(nsym) : img_bytes(nsym, nsym); I0->nsym = nsym;
+            I0->packed = packed ? 1u : 0u;
+            I0->look = look; I0->order = 1;
+            I0->active = s1_size != 0;
+        }
+    }
+}
+
+// PHASE 0: container header, order-0 tables, order-1 tables that sit in the stream as they are; an order-1 table that is
+// itself an order-0 stream becomes a chain item (four lanes decoding ~3 KB inside this one-wave kernel were a third of
+// its time on 64 KiB quality blocks).  PHASE 1, after those items have run: the order-1 tables of their blocks.
+template <int PHASE>
 __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int base)
 {
     __shared__ FrontShared S;
-    __shared__ __attribute__((aligned(16))) u8 nimg[IMG_O0_BYTES + RING_BYTES];   // nested table stream: image + ring
     __shared__ struct {
         i32 status;
         u32 order, pay_pos, pay_len, s1_size, compressed, usz, csz, tab_pos, after_table;
@@ -706,13 +890,24 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
     u8 *tbuf = ws.tbuf + (u64)b * TBUF_BYTES;
     ByteSrc src(in);
 
+    if (PHASE == 1) {
+        const DecResume R = ws.resume[b];
+        if (!R.pending || D->status != ST_OK) return;
+        if (lane == 0) H.status = ST_OK;
+        __syncthreads();
+        o1_tables(in, src, tbuf, true, R.bits, 0u, R.usz, R.after_table, R.pay_pos, R.pay_len, R.s1_size, img, D, I0, S, &H.status, lane);
+        return;
+    }
+
     // ---- container header: flags, sizes, PACK map, RLE meta (:1435-1572) ---------------------------
     u8 *tmp = ws.tmp + (u64)b * ws.tmp_stride;
     u8 *metabuf = ws.meta + (u64)b * ws.meta_stride;
     if (lane == 0) {
-        I0->active = 0; I1->active = 0;
-        I0->blk = b; I1->blk = b;
-        I0->packed = 0; I1->packed = 0;
+        DecItem *I2 = &ws.items[2 * gridDim.x + b];
+        I0->active = 0; I1->active = 0; I2->active = 0;
+        I0->blk = b; I1->blk = b; I2->blk = b;
+        I0->packed = 0; I1->packed = 0; I2->packed = 0;
+        ws.resume[b].pending = 0;
         D->status = ST_OK; D->cat_src = 0; D->cat_len = 0; D->osz = 0; D->s1_size = 0;
         D->pack_per = 1; D->rle_meta_len = 0; D->rle_meta = 0;
         i32 st = ST_OK;
@@ -827,7 +1022,6 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
             I1->img_bytes = img_bytes(S.nsym, 1); I1->nsym = S.nsym;
             I1->look = O0_BITS; I1->order = 0;
             for (int k = 0; k < 4; k++) I1->R[k] = S.R[k];
-            __threadfence();
             I1->active = H.meta_len != 0;
         }
         __syncthreads();
@@ -848,7 +1042,6 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
                 I0->img_bytes = img_bytes(S.nsym, 1); I0->nsym = S.nsym;
                 I0->look = O0_BITS; I0->order = 0;
                 for (int k = 0; k < 4; k++) I0->R[k] = S.R[k];
-                __threadfence();
                 I0->active = s1_size != 0;
             }
         }
@@ -884,203 +1077,32 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
     if (H.status != ST_OK) { if (lane == 0) D->status = H.status; return; }
 
     const u32 bits = H.bits;
-    const u32 look = bits == 12 ? 12 : 10;                             // :1027, :1071
-    const bool compressed = H.compressed != 0;
-
-    if (compressed) {
-        // un-nest the table: an order-0 stream of usz bytes inside src[tab_pos, tab_pos+csz).  Its
-        // one-row image and word ring live in this workgroup's LDS, so the 4-lane decoder of this
-        // small stream runs at LDS latency; its output goes to tbuf (L2-resident, read back below).
-        o0_front(src, H.tab_pos, H.csz, H.usz, nimg, S, lane);
-        if (S.status != ST_OK) { if (lane == 0) D->status = S.status; return; }
-        u8 *nring = nimg + IMG_O0_BYTES;
-        if (img_levels(S.nsym) == 3)
-            chain_decode_lds<0, 3>(nimg, S.nsym, nring, to_global(in + S.words_pos), H.tab_pos + H.csz - S.words_pos,
-                                   to_global(tbuf), H.usz, S.R[lane & 3], O0_BITS, lane < 4, lane);
-        else if (img_levels(S.nsym) == 2)
-            chain_decode_lds<0, 2>(nimg, S.nsym, nring, to_global(in + S.words_pos), H.tab_pos + H.csz - S.words_pos,
-                                   to_global(tbuf), H.usz, S.R[lane & 3], O0_BITS, lane < 4, lane);
-        else
-            chain_decode_lds<0, 4>(nimg, S.nsym, nring, to_global(in + S.words_pos), H.tab_pos + H.csz - S.words_pos,
-                                   to_global(tbuf), H.usz, S.R[lane & 3], O0_BITS, lane < 4, lane);
-        __threadfence();
-        __syncthreads();
-    }
-
-    ByteSrc tsrc(compressed ? tbuf : in);      // tbuf was never read by this CU before the fence above
-    const u32 tend = compressed ? H.usz : pay_pos + pay_len;
-
-    // alphabet F0 (:958-965) and the compact alphabet F0 ∪ {0}
-    for (u32 j = lane; j < 256; j += WAVE) S.present[j] = 0;
-    __syncthreads();
-    if (lane == 0) {
-        u32 p = compressed ? 0 : H.tab_pos;
-        const u32 used = get_alphabet(tsrc, p, tend, S.present);
-        p += used;
-        i32 st = ST_OK;
-        if (!used || p >= tend) st = ST_TABLE;
-        u32 n = 0;
-        for (u32 j = 0; j < 256; j++)
-            if (S.present[j] || j == 0) { S.idx_of[j] = (u8)n; S.alpha[n] = (u8)j; n++; }
-        S.nsym = n;
-        S.pos = p;
-        H.status = st;
-    }
-    __syncthreads();
-    if (H.status != ST_OK) { if (lane == 0) D->status = H.status; return; }
-
-    const u32 nsym = S.nsym;
-    // 10-bit tables of quality-sized alphabets take the packed rows (smaller images: more streams per CU)
-    const bool packed = bits == 10 && nsym >= PK_MIN_NSYM && nsym <= PKW_MAX_NSYM;
-    const u32 stride = packed ? pk_row_bytes(nsym) : img_row_bytes(nsym);
-    u8 *rows0 = img + img_alpha_bytes(nsym);
-
-    // Every row lists a frequency for each member of F0 (decode_freq_d :327-358): rank them once.
-    if (lane == 0) {
-        u32 k = 0;
-        for (u32 c = 0; c < nsym; c++) S.rankof[c] = S.present[S.alpha[c]] ? (u16)k++ : (u16)0xffff;
-        S.np = k;
-    }
-    __syncthreads();
-    const u32 np = S.np;
-    // The parsing lane reads the table through a 1 KB register window (un-nested tables sit in tbuf, whose
-    // slot may be read past the table's end); a raw table inside the input keeps the plain reader.
-    WinSrc win(&tsrc);
-    const u32 wlimit = compressed ? TBUF_BYTES : 0u;
-
-    // rows, in byte order of the compact alphabet (:967-998)
-    for (u32 ci = 0; ci < nsym; ci++) {
-        {   // all lanes: clear the row's frequencies, keep the window ahead of the parse position
-            for (u32 c = lane; c < np; c += WAVE) S.Fk[c] = 0;
-            const u32 pos_now = S.pos;
-            if (wlimit && (win.wlen == 0 || pos_now < win.wbase || pos_now + 800u > win.wbase + win.wlen)) win.fill(pos_now, wlimit, lane);
-        }
-        __syncthreads();
-        u32 total = 0;
+    if (H.compressed) {
+        // the table is an order-0 stream of usz bytes inside src[tab_pos, tab_pos+csz): its one-row image goes next to
+        // the block's other images, its output to tbuf; k_dec_front<1> takes over from there
+        u8 *imgn = img + IMG_MAX_BYTES;
+        o0_front(src, H.tab_pos, H.csz, H.usz, imgn, S, lane);
         if (lane == 0) {
-            const u32 ctx = S.alpha[ci];
-            S.empty = 0;
-            S.go = 1;
-            if (!S.present[ctx]) {
-                S.empty = 1;                                           // byte 0 outside F0
-            } else {
-                // decode_freq_d :327-358: one value per ranked member, zero runs as (0, count - 1)
-                u32 p = S.pos, zeros = 0;
-                bool ok = p != tend;
-                // a row is at most 6 bytes per member; when that much lies inside the window and before the
-                // end of the table, no byte of the row needs a bounds check
-                if (ok && p >= win.wbase && p + 6u * np + 6u <= win.wbase + win.wlen && p + 6u * np + 6u <= tend) {
-                    for (u32 k = 0; k < np; k++) {
-                        u32 f = 0;
-                        if (zeros) zeros--;
-                        else {
-                            u32 c;
-                            do { c = win.at_inside(p++); f = (f << 7) | (c & 0x7fu); } while (c & 0x80u);   // varint.h:131-160
-                            if (f == 0) zeros = win.at_inside(p++);
-                        }
-                        S.Fk[k] = f;
-                        total += f;
-                    }
-                } else
-                for (u32 k = 0; ok && k < np && p < tend; k++) {
-                    u32 f;
-                    if (zeros) { f = 0; zeros--; }
-                    else {
-                        p += var_get(win, p, tend, &f);
-                        if (f == 0) {
-                            if (p >= tend) { ok = false; break; }
-                            zeros = win.at(p++);
-                        }
-                    }
-                    S.Fk[k] = f;
-                    total += f;
-                }
-                if (!ok || p == S.pos) { H.status = ST_TABLE; S.go = 0; }
-                else {
-                    S.pos = p;
-                    if (total == 0) S.empty = 1;                       // :977-980
-                }
+            if (S.status != ST_OK) D->status = S.status;
+            else if (H.usz == 0) D->status = ST_TABLE;                  // (an empty table: get_alphabet has nothing to read)
+            else {
+                DecItem *I2 = &ws.items[2 * gridDim.x + b];
+                I2->words = (u64)(in + S.words_pos);
+                I2->words_len = H.tab_pos + H.csz - S.words_pos;
+                I2->out = (u64)tbuf; I2->out_sz = H.usz; I2->image = (u64)imgn;
+                I2->img_bytes = img_bytes(S.nsym, 1); I2->nsym = S.nsym;
+                I2->look = O0_BITS; I2->order = 0;
+                for (int k = 0; k < 4; k++) I2->R[k] = S.R[k];
+                I2->active = 1;
+                DecResume R;
+                R.pending = 1; R.pay_pos = pay_pos; R.pay_len = pay_len; R.s1_size = s1_size; R.bits = bits;
+                R.usz = H.usz; R.after_table = H.after_table; R.pad = 0;
+                ws.resume[b] = R;
             }
-            ((u16 *)img)[ci] = (u16)(ctx | (S.empty ? ROW_EMPTY : 0u));
         }
-        __syncthreads();
-        if (!S.go) break;
-        if (!S.empty) {
-            // cumulative starts by the whole wave (normalise_freq_shift :168-179 and the checks at :985-997):
-            // four compact symbols per lane, scaled, prefix-summed
-            total = __shfl(total, 0);
-            u32 sh = 0;
-            if (total != (1u << bits)) { u32 size = total; while (size < (1u << bits)) { size *= 2; sh++; } }
-            u32 f[4], sum = 0, lowest = 4;
-            bool bad = false;
-#pragma unroll
-            for (u32 c = 0; c < 4; c++) {
-                const u32 cc = 4 * lane + c;
-                const u32 rk = cc < nsym ? S.rankof[cc] : 0xffffu;
-                f[c] = rk != 0xffffu ? S.Fk[rk] << sh : 0u;
-                bad |= f[c] > (1u << bits);
-                sum += f[c];
-                if (f[c] && lowest == 4) lowest = c;
-            }
-            if (packed) {                                              // first symbol of the row with a frequency
-                const u64 has = __ballot(lowest != 4);
-                const int fl = has ? __ffsll((unsigned long long)has) - 1 : 0;
-                const u32 fst = (u32)__shfl((int)(4 * lane + (lowest & 3u)), fl);
-                if (lane == 0) S.first = has ? fst : 0u;
-            }
-            const bool anybad = wave_any(bad);
-            if (anybad) sum = 0;                                       // keeps the scan below from wrapping
-            const u32 incl = wave_incl_scan(sum, lane);
-            u32 x = incl - sum;
-#pragma unroll
-            for (u32 c = 0; c < 4; c++) {
-                const u32 cc = 4 * lane + c;
-                if (cc < nsym) S.cum[cc] = (u16)x;
-                x += f[c];
-            }
-            const u32 tot = __shfl(incl, WAVE - 1);
-            if (lane == 0) {
-                if (anybad || tot != (1u << bits)) { H.status = ST_TABLE; S.go = 0; }
-                S.cum[nsym] = (u16)tot;
-                S.cum[nsym + 1] = S.cum[nsym + 2] = S.cum[nsym + 3] = 0x7fffu;
-            }
-            __syncthreads();
-            if (!S.go) break;
-        }
-        if (packed) {
-            if (lane == 0 && !S.empty) ((u16 *)img)[ci] |= (u16)(S.first << PK_FIRST_SHIFT);
-            write_row_pk(rows0 + (u64)ci * stride, S, nsym, S.empty != 0, lane);
-        } else
-            write_row(rows0 + (u64)ci * stride, S, nsym, S.empty != 0, lane);
-        __syncthreads();
+        return;
     }
-    if (H.status != ST_OK) { if (lane == 0) D->status = H.status; return; }
-
-    if (lane == 0) {
-        u32 p = compressed ? H.after_table : S.pos;                    // :1000-1001
-        const u32 end = pay_pos + pay_len;
-        i32 st = ST_OK;
-        if (p + 16 > end) st = ST_TRUNCATED;                           // :1005
-        else {
-            for (u32 k = 0; k < 4; k++, p += 4) {
-                const u32 r = (u32)src.at(p) | ((u32)src.at(p + 1) << 8) |
-                              ((u32)src.at(p + 2) << 16) | ((u32)src.at(p + 3) << 24);
-                I0->R[k] = r;
-                if (r < RANS_LOW) st = ST_STATE;                       // :1010-1013
-            }
-        }
-        D->status = st;
-        if (st == ST_OK) {
-            I0->words = (u64)(in + p);
-            I0->words_len = end - p;
-            I0->out = D->s1; I0->out_sz = s1_size; I0->image = (u64)img;
-            I0->img_bytes = packed ? pk_img_bytes(nsym) : img_bytes(nsym, nsym); I0->nsym = nsym;
-            I0->packed = packed ? 1u : 0u;
-            I0->look = look; I0->order = 1;
-            __threadfence();
-            I0->active = s1_size != 0;
-        }
-    }
+    o1_tables(in, src, tbuf, false, bits, H.tab_pos, 0u, 0u, pay_pos, pay_len, s1_size, img, D, I0, S, &H.status, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1327,7 +1349,7 @@ __global__ __launch_bounds__(WAVE) void k_dec_back(BatchArgs a, DecWs ws, int ba
         u8 *s1 = (u8 *)D->s1, *s2 = (u8 *)D->s2, *s3 = (u8 *)D->s3;
         u32 s1_size = D->s1_size;
         if (D->cat_src) wave_copy(s1, (const u8 *)D->cat_src, D->cat_len, lane);
-        if (flags & (X_PACK | X_RLE)) { __threadfence(); __syncthreads(); }
+        if (flags & (X_PACK | X_RLE)) { wg_fence(); __syncthreads(); }
         u32 s2_size = s1_size;
         if (flags & X_RLE) {                                           // :1598-1613
             const u8 *meta = (const u8 *)D->rle_meta;
@@ -1346,7 +1368,7 @@ __global__ __launch_bounds__(WAVE) void k_dec_back(BatchArgs a, DecWs ws, int ba
                 else
                     s2_size = produced;
             }
-            __threadfence();
+            wg_fence();
             __syncthreads();
         }
         size = s2_size;
@@ -1366,9 +1388,12 @@ __global__ __launch_bounds__(WAVE) void k_dec_back(BatchArgs a, DecWs ws, int ba
 }
 
 // ---- host-callable launchers (r4x16_api.hip) ---------------------------------------------------
+static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitems, bool one_row_only, hipStream_t s);
 extern "C" void r4x16_launch_dec_front(const BatchArgs *a, const DecWs *ws, int base, int nblk, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_dec_front, dim3(nblk), dim3(WAVE), 0, s, *a, *ws, base);
+    hipLaunchKernelGGL(k_dec_front<0>, dim3(nblk), dim3(WAVE), 0, s, *a, *ws, base);
+    launch_dec_chain_of(ws, ws->items + 2 * (size_t)nblk, nblk, true, s);        // nested order-1 tables
+    hipLaunchKernelGGL(k_dec_front<1>, dim3(nblk), dim3(WAVE), 0, s, *a, *ws, base);
 }
 // LDS size classes: {bytes per stream (image + word ring), streams per wave, tree depth}.
 // LDS is allocated in 1,280-byte granules; streams per CU = floor(160 KB / granules(qpw * bytes)) * qpw.
@@ -1496,14 +1521,16 @@ extern "C" void r4x16_launch_cls_group(const u32 *cls, int nitems, u32 *count, u
     hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(64), 0, s, count);
     hipLaunchKernelGGL(k_cls_scatter, dim3((nitems + 255) / 256), dim3(256), 0, s, cls, nitems, count, list);
 }
-extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t s)
+extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t s) { launch_dec_chain_of(ws, ws->items, nitems, false, s); }
+// one_row_only: the items are order-0 streams (one-row images): only the classes such an image can fall into are launched
+static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitems, bool one_row_only, hipStream_t s)
 {
     {
         DecClassTab tab;
         tab.n = DEC_NCLS;
         for (u32 k = 0; k < DEC_NCLS; k++) { tab.bytes[k] = DEC_CLASSES[k].bytes; tab.lv[k] = (u32)DEC_CLASSES[k].lv; }
         r4x16_launch_cls_zero(ws->cls_count, s);
-        hipLaunchKernelGGL(k_dec_classify, dim3((nitems + 255) / 256), dim3(256), 0, s, ws->items, nitems, tab, ws->cls, ws->cls_count);
+        hipLaunchKernelGGL(k_dec_classify, dim3((nitems + 255) / 256), dim3(256), 0, s, items, nitems, tab, ws->cls, ws->cls_count);
         r4x16_launch_cls_group(ws->cls, nitems, ws->cls_count, ws->cls_list, s);
     }
     if (r4x16_first_on_device(1u)) {
@@ -1524,14 +1551,18 @@ extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t 
         const int grid = r4x16_resident_grid(ldsb, 1, (nitems + qpw - 1) / qpw);
         void (*kern)(const DecItem *, DecDesc *, const u32 *, const u32 *, int, u32) =
             c.lv == 1 ? k_dec_chain<true, 1> : c.lv == 5 ? k_dec_chain<true, 5> : c.lv == 2 ? k_dec_chain<true, 2> : c.lv == 3 ? k_dec_chain<true, 3> : k_dec_chain<true, 4>;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), ldsb, s, ws->items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci), qpw, c.bytes);
+        // (an order-0 image: at most IMG_O0_BYTES; depth 4 only as the lone row of an alphabet beyond 150 symbols)
+        const bool skip = one_row_only && (c.lv == 1 || c.lv == 5 || c.bytes > (c.lv == 4 ? 22528u : IMG_O0_BYTES + RING_BYTES + 128u));
+        if (!skip)
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), ldsb, s, items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci), qpw, c.bytes);
         ci++;
     }
+    if (one_row_only) return;                 // (such an image always fits a class)
     // images that fit no LDS class: tables stay in global memory (L2)
     const int grid = (nitems + 15) / 16;
-    hipLaunchKernelGGL((k_dec_chain<false, 2>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci + 0), 16, 0u);
-    hipLaunchKernelGGL((k_dec_chain<false, 3>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci + 1), 16, 0u);
-    hipLaunchKernelGGL((k_dec_chain<false, 4>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci + 2), 16, 0u);
+    hipLaunchKernelGGL((k_dec_chain<false, 2>), dim3(grid), dim3(WAVE), 0, s, items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci + 0), 16, 0u);
+    hipLaunchKernelGGL((k_dec_chain<false, 3>), dim3(grid), dim3(WAVE), 0, s, items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci + 1), 16, 0u);
+    hipLaunchKernelGGL((k_dec_chain<false, 4>), dim3(grid), dim3(WAVE), 0, s, items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci + 2), 16, 0u);
 }
 // Streams of one kind that a CU holds at once in the chain decoder (host arithmetic on the class table above).
 extern "C" int r4x16_dec_residency(u32 nsym, int order, u32 bits, int *streams_per_wave, int *waves_per_cu)
@@ -1821,7 +1852,6 @@ __global__ __launch_bounds__(WAVE) void k8_dec_front(BatchArgs a, X8Item *items,
         I->image = (u64)img; I->nsym = Z.n;
         a.status[i] = st;
         a.out_size[i] = st == ST_OK ? I->out_sz : 0;
-        __threadfence();
         I->active = st == ST_OK && I->out_sz != 0;
     }
 }

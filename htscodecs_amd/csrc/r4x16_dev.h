@@ -38,6 +38,11 @@ __device__ __forceinline__ void wsync()
     __builtin_amdgcn_wave_barrier();
 }
 
+// Ordering point for global memory that one thread of a workgroup wrote and another reads after the next barrier.
+// (__threadfence() is device scope: on gfx950 an L2 write-back and a cache invalidate per call, `buffer_wbl2 sc1` /
+// `buffer_inv sc1`, microseconds under load - and nothing here is read by another workgroup before the kernel ends.)
+__device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
 // Arguments of a device-resident batch (include/rans4x16_hip.h, *_dev entry points).
 struct BatchArgs {
     const u8  *in;

@@ -589,7 +589,7 @@ __device__ __forceinline__ u32 chain_encode_o0_lds(const u8 *img_lds, DP data, u
 // Shared state of k_enc_front.
 // ---------------------------------------------------------------------------------------------
 struct EncShared {
-    u32 F[256];          // order-0 counters / scratch row
+    alignas(16) u32 F[256];   // order-0 counters / scratch row (k_enc_tables, order 1: 64 pairs of doubles)
     u32 T[256];          // order-1: context totals (by compact index)
     int S[256];          // order-1: per-context target from compute_shift (by compact index)
     u32 rowlen[256];     // order-1: serialised length of each row
@@ -602,6 +602,11 @@ struct EncShared {
     u32 pk_n, pk_meta_len, pk_len;       // wg_pack results
     u32 rl_nsyms, rl_lits, rl_runs;      // wg_rle_split results
 };
+
+// A block's order-1 pair counters in global memory (alphabets beyond the LDS limit count there; all are handed from
+// k_enc_front to k_enc_tables there): up to 256 x 256 dwords at the bottom of the block's backward-write area, which
+// nothing else touches before the chain kernel runs (r4x16_api.hip sizes that area to at least ENC_F_BYTES).
+__device__ __forceinline__ u32 *enc_pair_counters(const EncWs &ws, u32 b) { return (u32 *)(ws.scratch + (u64)b * ws.scratch_stride); }
 
 // ---- wave histogram of bytes (hist8, utils.h:80-102) into S.F ---------------------------------
 __device__ void wave_hist8(const u8 *data, u32 n, u32 *F, u32 lane)
@@ -1014,7 +1019,7 @@ __device__ void wg_pack(const u8 *data, u32 n, u8 *meta, u8 *out, EncShared &S, 
             out[ob] = (u8)v;
         }
     }
-    __threadfence();
+    wg_fence();
     __syncthreads();
 }
 
@@ -1231,7 +1236,7 @@ __device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, 
         PROF(14);
         walk(std::true_type{}, d0, d1, d2, op, to_global(lits_end) - nl_all + cL[tid], to_global(runs_end) - nv_all + cV[tid]);
     }
-    __threadfence();
+    wg_fence();
     __syncthreads();
     PROF(15);
 }
@@ -1368,7 +1373,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
                 u8 *m = meta_end - mlen;
                 if (tid == 0) m[0] = (u8)nsy;
                 if (tid < nsy) m[1 + tid] = S.alpha[tid];                  // nsy <= 256 == FRONT_THREADS
-                __threadfence();
+                wg_fence();
                 __syncthreads();
                 // the meta is coded as an order-0 stream by the chain kernel (item I1)
                 u8 *mtab = ws.metatab + (u64)b * META_TAB_BYTES;
@@ -1382,7 +1387,6 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
                         I1->data = (u64)m; I1->n = mlen; I1->image = (u64)imgm; I1->bits = O0_BITS; I1->order = 0;
                         I1->ns = 256; I1->img_bytes = ENC_IMG_IDX + 2u * 257u;
                         I1->scratch_end = (u64)(ws.scratch2 + (u64)b * ws.scratch2_stride + ws.scratch2_stride);
-                        __threadfence();
                         I1->active = S.status == ST_OK;
                     }
                 }
@@ -1405,7 +1409,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
             H.run = n != 0;
         }
     }
-    __threadfence();
+    wg_fence();
     __syncthreads();                                                      // all four waves meet here
     if (!H.run) return;
 
@@ -1418,8 +1422,9 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
     // counters get one extra "any other byte" symbol, and only if that one is ever hit (never, on quality data: a
     // block's alphabet is complete within its first few thousand bytes) is the exact two-pass route taken.  One read
     // of the input instead of two (the front end fetched 2.0 x the batch).
-    const u32 SAMPLE = 65536u;
-    const bool sampled = H.order == 1 && n >= 4u * SAMPLE;
+    // Smaller blocks, down to 64 KiB, look at their first quarter.
+    const bool sampled = H.order == 1 && n >= 65536u;
+    const u32 SAMPLE = n >= 262144u ? 65536u : (n >> 2) & ~15u;
     if (H.order == 0) wg_hist8(data, n, S.F, (u32 *)dyn, tid);
     else              wg_present8(data, sampled ? SAMPLE : n, S.F, S.pmask, tid);
 
@@ -1432,7 +1437,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
     }
 
     // ---- order-1 (:694-780) ---------------------------------------------------------------------
-    u32 *Fg = ws.F + (u64)b * 65536u;
+    u32 *Fg = enc_pair_counters(ws, b);
     u32 ns = 0, nsx = 0;
     bool f_in_lds = false;
     for (u32 attempt = sampled ? 0u : 1u; attempt < 2u; attempt++) {
@@ -1521,7 +1526,6 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
             I0->data = (u64)data; I0->n = n; I0->image = (u64)img; I0->bits = O0_BITS; I0->order = 0;
             I0->ns = 256; I0->img_bytes = ENC_IMG_IDX + 2u * 257u;
             I0->scratch_end = (u64)scratch_end;
-            __threadfence();
             I0->active = S.status == ST_OK;
         }
         return;
@@ -1531,7 +1535,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
     const u32 ns = ST->ns;
     for (u32 j = lane; j < 256; j += WAVE) { S.present[j] = ST->present[j]; S.idx_of[j] = ST->idx_of[j]; S.alpha[j] = ST->alpha[j]; }
     if (lane == 0) S.nsym = ns;
-    u32 *Fg = ws.F + (u64)b * 65536u;
+    u32 *Fg = enc_pair_counters(ws, b);
     const bool f_in_lds = ns <= TABLES_LDS_NSYM;
     if (f_in_lds) for (u32 j = lane; j < ns * ns; j += WAVE) ((u32 *)dyn)[j] = Fg[j];
     wsync();
@@ -1549,6 +1553,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
     if (lane == 0) H.max_tot = 0;
     wsync();
     double e10 = 0, e12 = 0;                              // running sums, identical in every lane
+    double2 *terms = (double2 *)S.F;                      // 64 pairs = the 1 KB of S.F, which the order-1 path does not use
     // log(1024 + k), log(4096 + k) for k < 64 sit one per lane (k is a count of "tiny" symbols in a row and
     // nearly always small); a row's pair is then a lane read instead of two dependent global loads
     const double ltab10 = ws.logtab[lane], ltab12 = ws.logtab[257 + lane];
@@ -1567,26 +1572,31 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
         const double l10 = tiny10 < WAVE ? readlane_f64(ltab10, (int)tiny10) : ws.logtab[tiny10];
         const double l12 = tiny12 < WAVE ? readlane_f64(ltab12, (int)tiny12) : ws.logtab[257 + tiny12];
         // Terms in parallel, one symbol per lane; the sum must run in the reference's order (j ascending, one
-        // accumulator over all rows), so it walks the lanes with scalar lane reads - the terms never touch LDS.
+        // accumulator over all rows).  The terms of the symbols with a count go to LDS side by side, and every lane
+        // adds them up from there (same address in all lanes: a broadcast read, loads ahead of the dependent adds;
+        // fetching them lane by lane with v_readlane took 60 % of this kernel on 64 KiB quality blocks).
         for (u32 jb = 0; jb < ns; jb += WAVE) {
             const u32 j = jb + lane;
             const u32 f = j < ns ? Fp[r * ns + j] : 0u;
-            double t10 = 0, t12 = 0;
+            const u64 m = __ballot(f != 0);
             if (f) {
                 int x = (int)((double)1024 * (double)f / (double)Tr);
-                t10 = (double)f * (approx_log((double)(x > 1 ? x : 1)) - l10);
+                const double t10 = (double)f * (approx_log((double)(x > 1 ? x : 1)) - l10);
                 x = (int)((double)4096 * (double)f / (double)Tr);
-                t12 = (double)f * (approx_log((double)(x > 1 ? x : 1)) - l12);
+                const double t12 = (double)f * (approx_log((double)(x > 1 ? x : 1)) - l12);
+                terms[__popcll(m & ((1ull << lane) - 1ull))] = double2{t10, t12};
             }
-            u64 m = __ballot(f != 0);
-            while (m) {
-                const int src = __ffsll((unsigned long long)m) - 1;
-                m &= m - 1;
-                e10 -= readlane_f64(t10, src);               // scalar lane index: v_readlane, not the LDS crossbar
-                e12 -= readlane_f64(t12, src);
+            wsync();
+            const u32 cnt = (u32)__popcll(m);
+#pragma unroll 4
+            for (u32 k = 0; k < cnt; k++) {
+                const double2 t = terms[k];
+                e10 -= t.x;
+                e12 -= t.y;
                 e10 += 4;
                 e12 += 6;
             }
+            wsync();
         }
         if (lane == 0) {
             int target = target0;
@@ -1685,7 +1695,6 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
         }
     }
     if (packed && lane == 0) ((u32 *)(img + ENC_IMG_IDX))[ns * W] = 0;      // the pair window's second dword past the last row
-    __threadfence();
     wsync();
 
     TPROF(4);
@@ -1699,7 +1708,6 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
     if (1 + tlen > 1000) {
         u8 *ntab = scratch;                                           // the nested stream's own order-0 table
         u8 *img0 = img + ENC_IMG_NESTED;
-        __threadfence();
         wsync();
         enc_o0_front(tabraw, tlen, ntab, img0, S, lane);
         if (lane == 0 && S.status == ST_OK) {
@@ -1708,7 +1716,6 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
             I2->data = (u64)tabraw; I2->n = tlen; I2->image = (u64)img0; I2->bits = O0_BITS; I2->order = 0;
             I2->ns = 256; I2->img_bytes = ENC_IMG_IDX + 2u * 257u;
             I2->scratch_end = (u64)(scratch + NEST_AREA);
-            __threadfence();
             I2->active = 1;
         }
     }
@@ -1721,7 +1728,6 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
         I0->ns = ns; I0->img_bytes = packed ? enc_pk_img_bytes(ns) : ENC_IMG_IDX + 2u * ns * (ns + 1);
         I0->packed = packed ? 1u : 0u;
         I0->scratch_end = (u64)scratch_end;
-        __threadfence();
         I0->active = 1;
     }
 }
@@ -1982,10 +1988,10 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
         int qpw = (force_qpw && bytes == tuned) ? force_qpw : enc_class_qpw(bytes, pk);
         // One workgroup per CU is the best shape (measured: 30 streams per CU as 1 x 32 beat 2 x 16 by a
         // third and half-filled 64s by a fifth), so a batch that cannot fill the class's workgroups on
-        // every CU gets smaller ones (items [0, n/2) are the payload streams).
+        // every CU gets smaller ones (items [0, n/3) are the payload streams).
         {
             const int cus = r4x16_cu_count();
-            int want = (((nitems + 1) / 2 + cus - 1) / cus + 3) & ~3;
+            int want = (((nitems + 2) / 3 + cus - 1) / cus + 3) & ~3;
             if (want < 8) want = 8;
             if (qpw > want) qpw = want;
         }
@@ -2151,7 +2157,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void k8_enc_front(BatchArgs a, EncWs
         __syncthreads();
         const u32 ns = S.nsym;
         const bool f_in_lds = ns <= FRONT_LDS_NSYM;
-        u32 *Fg = ws.F + (u64)b * 65536u;
+        u32 *Fg = enc_pair_counters(ws, b);
         u32 *Fp = f_in_lds ? (u32 *)dyn : Fg;
         for (u32 j = tid; j < ns * ns; j += FRONT_THREADS) Fp[j] = 0;
         __syncthreads();
@@ -2225,14 +2231,13 @@ __global__ __launch_bounds__(FRONT_THREADS) void k8_enc_front(BatchArgs a, EncWs
         }
         H.ns = ns;
     }
-    __threadfence();
+    wg_fence();
     __syncthreads();
     if (tid == 0) {
         ws.desc[b].tab_len = H.tab_len;
         I0->data = (u64)data; I0->n = n; I0->image = (u64)img; I0->bits = 12; I0->order = H.order;
         I0->ns = H.ns; I0->img_bytes = 0;
         I0->scratch_end = (u64)scratch_end;
-        __threadfence();
         I0->active = 1;
     }
 }

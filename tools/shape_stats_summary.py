@@ -9,6 +9,7 @@ for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", "shape_stats", "*/"))
     tr = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
     if not tr:
         continue
+    tr.sort(key=os.path.getmtime, reverse=True)          # gpurun merges into gpurun_out/: earlier runs' files stay
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "summarize_trace.py"), tr[0], "100"], check=True,
                          stdout=subprocess.PIPE, text=True).stdout
     open(os.path.join(ROOT, "profiles", f"{tag}_shape_{name}_kernel_stats.csv"), "w").write(out)
