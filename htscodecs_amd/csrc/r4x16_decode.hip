@@ -682,6 +682,69 @@ __device__ __forceinline__ void o0_front(ByteSrc &src, u32 pos, u32 len, u32 out
 // ---------------------------------------------------------------------------------------------
 // k_dec_front
 // ---------------------------------------------------------------------------------------------
+// One row of an order-1 table (decode_freq_d :327-358: a varint per ranked member, zero runs as (0, count - 1)) parsed by
+// the whole wave from the register window, 64 bytes at a time, instead of by one lane byte after byte (that was most of
+// k_dec_front's time: 46 rows of ~40 values per quality block).  What a byte is - part of a varint or the count behind a
+// zero - depends on the bytes before it: a three-state machine (START of a value, CONTinuation of a varint, RUN count)
+// whose per-byte transition functions are composed by a wave scan.  Member indices are a prefix sum of "1 per value,
+// count per run byte"; the row ends at the first finished value (a zero with its count byte) at which np members are
+// reached, the next chunk starts after the last finished one.  Returns false - nothing is lost, the caller's one-lane
+// parse then does the row - on what only a damaged table holds: varints of more than five bytes, zeros spelt in several
+// bytes, no finished value in 64 bytes, or a table that ends within the chunk.
+__device__ __forceinline__ bool row_parse_wave(WinSrc &win, u32 wlimit, u32 p, u32 np, u32 *Fk, u32 *pp, u32 *ptotal, u32 lane)
+{
+    u32 k0 = 0, total = 0;
+    for (;;) {
+        if (p < win.wbase || p + 80u > win.wbase + win.wlen) {
+            win.fill(p, wlimit, lane);
+            if (p + 80u > win.wbase + win.wlen) return false;
+        }
+        const u32 bo = p - win.wbase + lane;
+        const int sl = (int)(bo >> 4);
+        const u32 d0 = (u32)__shfl((int)win.held.x, sl), d1 = (u32)__shfl((int)win.held.y, sl),
+                  d2 = (u32)__shfl((int)win.held.z, sl), d3 = (u32)__shfl((int)win.held.w, sl);
+        const u32 dlo = (bo & 4u) ? d1 : d0, dhi = (bo & 4u) ? d3 : d2;
+        const u32 b = (((bo & 8u) ? dhi : dlo) >> (8u * (bo & 3u))) & 0xffu;
+        const bool cont = (b & 0x80u) != 0;
+        // transition function of this byte, next state from START / CONT / RUN in bits 0-1 / 2-3 / 4-5
+        // (START = 0, CONT = 1, RUN = 2): continuation byte -> CONT, CONT, START; zero -> RUN, START, START; other -> START
+        u32 F = cont ? 5u : (b == 0 ? 2u : 0u);
+#pragma unroll
+        for (u32 d = 1; d < WAVE; d <<= 1) {
+            const u32 g = (u32)__shfl_up((int)F, d);          // the bytes before
+            if (lane >= d) {
+                const u32 h0 = (F >> (2u * (g & 3u))) & 3u, h1 = (F >> (2u * ((g >> 2) & 3u))) & 3u, h2 = (F >> (2u * ((g >> 4) & 3u))) & 3u;
+                F = h0 | (h1 << 2) | (h2 << 4);
+            }
+        }
+        const u32 prevF = (u32)__shfl_up((int)F, 1);
+        const u32 pre = lane ? (prevF & 3u) : 0u;             // this byte's state: the chunk starts at a value
+        const bool runb = pre == 2u, vend = pre != 2u && !cont, zero1 = pre == 0u && b == 0u;
+        const bool complete = runb || (vend && !zero1);
+        const u32 Mi = wave_incl_scan(runb ? b : (vend ? 1u : 0u), lane);
+        // the varint that ends here: up to four bytes before this one
+        const u32 pk = b | (pre << 8);
+        const u32 q1 = (u32)__shfl_up((int)pk, 1), q2 = (u32)__shfl_up((int)pk, 2), q3 = (u32)__shfl_up((int)pk, 3), q4 = (u32)__shfl_up((int)pk, 4);
+        const bool c1 = pre == 1u, c2 = c1 && (q1 >> 8) == 1u, c3 = c2 && (q2 >> 8) == 1u, c4 = c3 && (q3 >> 8) == 1u, c5 = c4 && (q4 >> 8) == 1u;
+        const u32 v = (b & 0x7fu) | (c1 ? (q1 & 0x7fu) << 7 : 0u) | (c2 ? (q2 & 0x7fu) << 14 : 0u) | (c3 ? (q3 & 0x7fu) << 21 : 0u) |
+                      (c4 ? (q4 & 0x7fu) << 28 : 0u);
+        const bool odd = vend && (c5 || (c1 && v == 0u));
+        const u64 cm = __ballot(complete), cand = __ballot(complete && k0 + Mi >= np);
+        if (!cm) return false;
+        const u32 last = cand ? (u32)__ffsll((unsigned long long)cand) - 1u : 63u - (u32)__clzll((long long)cm);
+        if (__ballot(odd && lane <= last)) return false;
+        const bool mine = vend && !zero1 && lane <= last;
+        if (mine) Fk[k0 + Mi - 1u] = v;
+        total += wave_sum(mine ? v : 0u);
+        k0 += (u32)__shfl((int)Mi, (int)last);
+        p += last + 1u;
+        if (cand) break;
+    }
+    *pp = p;
+    *ptotal = total;
+    return true;
+}
+
 // Order-1 frequency tables (:958-998) into the decoder image, then the payload item.  `tsrc` / `tend`: the table bytes -
 // the input itself, or tbuf where the table came as a nested order-0 stream.  One wave.
 __device__ void o1_tables(const u8 *in, ByteSrc &src, const u8 *tbuf, bool compressed, u32 bits, u32 tab_pos, u32 usz, u32 after_table,
@@ -738,12 +801,24 @@ __device__ void o1_tables(const u8 *in, ByteSrc &src, const u8 *tbuf, bool compr
         }
         __syncthreads();
         u32 total = 0;
+        const u32 ctx = S.alpha[ci];
+        bool parsed = false;
+        if (wlimit && S.present[ctx]) {                                // (uniform) the wave parses the row where no byte of it
+            const u32 p0 = S.pos;                                      // needs a bounds check - the one-lane fast path's condition
+            if (p0 != tend && p0 + 6u * np + 6u <= tend) {
+                u32 pn = 0;
+                parsed = row_parse_wave(win, wlimit, p0, np, S.Fk, &pn, &total, lane);
+                __syncthreads();
+                if (parsed && lane == 0) S.pos = pn;
+            }
+        }
         if (lane == 0) {
-            const u32 ctx = S.alpha[ci];
             S.empty = 0;
             S.go = 1;
             if (!S.present[ctx]) {
                 S.empty = 1;                                           // byte 0 outside F0
+            } else if (parsed) {
+                if (total == 0) S.empty = 1;                           // :977-980
             } else {
                 // decode_freq_d :327-358: one value per ranked member, zero runs as (0, count - 1)
                 u32 p = S.pos, zeros = 0;

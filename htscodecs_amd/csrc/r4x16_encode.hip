@@ -14,8 +14,9 @@
 #include <stdlib.h>
 #include "r4x16_dev.h"
 
-#define FRONT_DYN_LDS  61440u                           // LDS counters: alphabets up to 123 symbols
-#define FRONT_LDS_NSYM 123u
+#define FRONT_DYN_LDS  36864u                           // LDS counters: alphabets up to 96 symbols (three workgroups per CU;
+                                                        // 61,440 bytes / two per CU: +4 % on PACK|RLE blocks, +2 % on 64 KiB ones)
+#define FRONT_LDS_NSYM 96u
 
 // ---------------------------------------------------------------------------------------------
 // rANS_static4x16pr.c:360-372, same expression, same evaluation order, in double.
@@ -969,12 +970,15 @@ __device__ __forceinline__ void wg_hist1(const u8 *data, u32 n, FP Fp0, u32 ns, 
 // ---------------------------------------------------------------------------------------------
 // hts_pack, pack.c:56-151.  S.F holds the byte histogram of data[0..n).  Each thread packs 16-byte
 // pieces of the input (2 / 4 / 8 output bytes).  Ends on a workgroup barrier.
-__device__ void wg_pack(const u8 *data, u32 n, u8 *meta, u8 *out, EncShared &S, u32 tid)
+// `provisional`: S.F comes from the head of the block only.  Bytes it has not seen map to 0x80, and the return value says
+// whether one turned up (or the head alone cannot tell): the caller then repeats the call on the full presence flags.
+__device__ bool wg_pack(const u8 *data, u32 n, u8 *meta, u8 *out, EncShared &S, u32 tid, bool provisional)
 {
     if (tid == 0) {
         u32 ns = 0;
         for (u32 j = 0; j < 256; j++)
             if (S.F[j]) { S.idx_of[j] = (u8)ns; S.alpha[ns] = (u8)j; ns++; }
+            else S.idx_of[j] = 0x80;
         meta[0] = (u8)ns;                                 // 256 wraps to 0 (pack.c:74)
         if (ns <= 16) for (u32 j = 0; j < ns; j++) meta[1 + j] = S.alpha[j];
         S.pk_n = ns;
@@ -984,7 +988,10 @@ __device__ void wg_pack(const u8 *data, u32 n, u8 *meta, u8 *out, EncShared &S, 
     }
     __syncthreads();
     const u32 ns = S.pk_n;
-    if (ns > 16 || ns <= 1) return;                       // copy case (caller keeps `data`) / constant input
+    if (ns > 16) return provisional;                      // copy case (caller keeps `data`) - but exactly 256 symbols keep the
+                                                          // flag (pack.c:74), and only the whole block can tell
+    if (ns <= 1) return provisional;                      // constant input - as far as the head goes
+    u32 seen = 0;
     const u32 per = ns > 4 ? 2 : ns > 2 ? 4 : 8;
     const u32 width = 8 / per;
     const u32 pieces = n >> 4;
@@ -1004,6 +1011,7 @@ __device__ void wg_pack(const u8 *data, u32 n, u8 *meta, u8 *out, EncShared &S, 
                       i2 = S.idx_of[(w[c] >> 16) & 0xff], i3 = S.idx_of[w[c] >> 24];
             const u64 four = (u64)(i0 | (i1 << width) | (i2 << (2 * width)) | (i3 << (3 * width)));
             acc |= four << (4 * width * c);
+            seen |= i0 | i1 | i2 | i3;
         }
         gu8 *o = gout + (u64)pi * (16 / per);
         if (per == 2)      *(GAS u64_unaligned *)o = acc;
@@ -1015,12 +1023,12 @@ __device__ void wg_pack(const u8 *data, u32 n, u8 *meta, u8 *out, EncShared &S, 
         for (u32 ob = (pieces * 16) / per; ob < nout; ob++) {
             u32 v = 0;
             const u32 i0 = ob * per;
-            for (u32 k = 0; k < per && i0 + k < n; k++) v |= (u32)S.idx_of[data[i0 + k]] << (k * width);
+            for (u32 k = 0; k < per && i0 + k < n; k++) { const u32 ix = S.idx_of[data[i0 + k]]; seen |= ix; v |= ix << (k * width); }
             out[ob] = (u8)v;
         }
     }
     wg_fence();
-    __syncthreads();
+    return __syncthreads_or((int)(seen & 0x80u)) != 0;
 }
 
 // Phase timing of k_enc_front for variant builds (-DR4X16_PROF_FRONT; tools/front_phases.py): cycles of thread 0 between
@@ -1257,7 +1265,7 @@ __device__ __forceinline__ double approx_log(double a)            // fast_log :6
     return (double)(bits - 4606921278410026770LL) * 1.539095918623324e-16;
 }
 
-__global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs ws, int base)
+__global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs ws, int base, u32 dyn_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) u8 dyn[];
     __shared__ EncShared S;
@@ -1336,10 +1344,17 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
             u8 *pbuf = ws.packed + (u64)b * ws.xf_stride;
             // hts_pack only asks WHICH bytes occur (pack.c:62-75): the presence pass, plain byte stores, instead of the
             // counting histogram, whose LDS atomics all but serialise on the two to sixteen symbols PACK is made for
+            // Blocks of 256 KiB and more take the symbol set from their first 64 KiB and pack at once; the packing
+            // pass notices a byte from outside that set, and only then is the block looked at in full (as for the
+            // order-1 alphabet below: one read of the input instead of two).
             PROF(0);
-            wg_present8(data, n, S.F, S.pmask, tid);
+            const bool head_only = n >= 262144u;
+            wg_present8(data, head_only ? 65536u : n, S.F, S.pmask, tid);
             PROF(1);
-            wg_pack(data, n, D->hdr + hl, pbuf, S, tid);
+            if (wg_pack(data, n, D->hdr + hl, pbuf, S, tid, head_only)) {
+                wg_present8(data, n, S.F, S.pmask, tid);
+                wg_pack(data, n, D->hdr + hl, pbuf, S, tid, false);
+            }
             PROF(2);
             if (S.pk_meta_len == 1 && S.pk_n != 256) flags &= ~(u32)X_PACK;    // > 16 symbols (:1249); 256 wraps to 0 and stays
             else {
@@ -1459,9 +1474,9 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
         __syncthreads();
         ns = S.nsym;
         nsx = prov ? ns + 1 : ns;                                         // row / column count of the counters
-        f_in_lds = nsx <= FRONT_LDS_NSYM;
+        f_in_lds = 4u * nsx * nsx <= dyn_bytes;
         if (prov && !f_in_lds) continue;                                  // large alphabets: straight to the exact route
-        const u32 copies = !f_in_lds ? 1u : (16u * hist1_copy_stride(nsx, 4) <= FRONT_DYN_LDS ? 4u : (8u * hist1_copy_stride(nsx, 2) <= FRONT_DYN_LDS ? 2u : 1u));
+        const u32 copies = !f_in_lds ? 1u : (16u * hist1_copy_stride(nsx, 4) <= dyn_bytes ? 4u : (8u * hist1_copy_stride(nsx, 2) <= dyn_bytes ? 2u : 1u));
         if (f_in_lds) { for (u32 j = tid; j < copies * hist1_copy_stride(nsx, copies); j += FRONT_THREADS) ((u32 *)dyn)[j] = 0; }
         else          { for (u32 j = tid; j < nsx * nsx; j += FRONT_THREADS) Fg[j] = 0; }
         __syncthreads();
@@ -1913,8 +1928,9 @@ extern "C" void r4x16_launch_enc_front(const BatchArgs *a, const EncWs *ws, int 
 {
     // static + dynamic LDS exceeds the 64 KB default; gfx950 has 160 KB per CU
     if (r4x16_first_on_device(2u))
-        (void)hipFuncSetAttribute((const void *)k_enc_front, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_DYN_LDS);
-    hipLaunchKernelGGL(k_enc_front, dim3(nblk), dim3(FRONT_THREADS), FRONT_DYN_LDS, s, *a, *ws, base);
+        (void)hipFuncSetAttribute((const void *)k_enc_front, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    static const u32 dynb = getenv("R4X16_FRONT_LDS") ? (u32)atoi(getenv("R4X16_FRONT_LDS")) : FRONT_DYN_LDS;   // tuning aid
+    hipLaunchKernelGGL(k_enc_front, dim3(nblk), dim3(FRONT_THREADS), dynb, s, *a, *ws, base, dynb);
 }
 // {LDS bytes per stream, streams per wave}; LDS is allocated in 1,280-byte granules.
 // q4/q8 images are ~0.4 KB, an order-0 row 0.8 KB, q40 4.6 KB (16 x 4,800 = 60 granules: 2 waves, 32 streams per CU — fuller waves measured faster than more waves)

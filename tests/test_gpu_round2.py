@@ -284,6 +284,37 @@ def test_alphabet_that_grows_after_the_first_64_kib(H, oracle):
             assert e == oracle.compress(d, order), (k, order)
 
 
+def test_pack_symbol_set_that_grows_after_the_head(H, oracle):
+    """X_PACK takes its symbol set from the first 64 KiB of blocks of 256 KiB and more and repeats the step on the
+    whole block when the packing pass meets a byte from outside it; order-1 blocks from 64 KiB up take their alphabet
+    from their first quarter.  New symbols late in the block - keeping the packing width, changing it, ending packing
+    altogether, after a constant head - must give reference-identical streams."""
+    n = 600000
+    q4 = datagen.tile("q4", n, 5)
+    vals = sorted(set(q4[:70000].tolist()))
+    fresh = [v for v in range(256) if v not in vals]
+    cases = []
+    a = q4.copy(); cases.append(a)                                        # nothing new
+    a = q4.copy(); a[-1] = fresh[0]; cases.append(a)                      # a fifth symbol as the last byte: 4 -> 2 per byte
+    a = q4.copy(); a[65536] = fresh[1]; cases.append(a)                   # first byte after the head
+    a = q4.copy(); a[400000:400020] = np.array(fresh[:20], dtype=np.uint8); cases.append(a)   # more than sixteen: no packing
+    a = q4.copy(); a[:70000] = vals[0]; cases.append(a)                   # constant head
+    a = np.full(n, vals[1], dtype=np.uint8); a[-3] = vals[0]; cases.append(a)     # constant but for one late byte
+    a = np.full(n, vals[1], dtype=np.uint8); cases.append(a)              # constant
+    for m in (65536, 100000, 262143):                                     # quarter-sampled order-1 alphabets
+        a = datagen.tile("q40+dir", m, 2); cases.append(a.copy())
+        a = a.copy(); a[m // 4 + 16] = 201; cases.append(a)
+        a = a.copy(); a[-1] = 202; cases.append(a)
+    datas = [c.tobytes() for c in cases]
+    for order in (193, 129, 128, 1):
+        enc, st = H.compress_batch(datas, [order] * len(datas))
+        assert all(s == 0 for s in st)
+        for k, (d, e) in enumerate(zip(datas, enc)):
+            assert e == oracle.compress(d, order), (k, order)
+        dec, st2 = H.uncompress_batch(enc, [len(d) for d in datas])
+        assert all(s == 0 for s in st2) and dec == datas
+
+
 def test_stripe_blocks_device_resident(H, oracle):
     """X_STRIPE through rans4x16_hip_{compress,uncompress}_dev (r4x16_stripe.hip): planes, the N x K candidate
     encodings, the per-plane arg-min and the header on the device (rANS_static4x16pr.c:1154-1216); decode with the
