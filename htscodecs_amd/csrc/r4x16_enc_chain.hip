@@ -1,0 +1,126 @@
+// =============================================================================================
+// r4x16_enc_chain.hip - launcher of k_enc_chain (r4x16_enc_chain.h), the LDS size classes, and the instantiations for
+// u16 images.  The packed-row instantiation lives in r4x16_enc_chain_pk.hip.
+// =============================================================================================
+#include "r4x16_enc_chain.h"
+
+// r4x16_enc_chain_pk.hip: k_enc_chain<true, true>
+extern "C" void r4x16_enc_chain_pk_lds_limit(int bytes);
+extern "C" void r4x16_enc_chain_pk_launch(int grid, int threads, size_t lds, hipStream_t s, EncItem *items, const u32 *rcptab, u8 *dump,
+                                          const u32 *list, const u32 *count, int qpw, int spw, u32 lds_per_item);
+
+// ---- host-callable launcher ----------------------------------------------------------------------
+extern "C" bool r4x16_first_on_device(u32 bit);                                          // r4x16_decode.hip
+// {LDS bytes per stream, streams per wave}; LDS is allocated in 1,280-byte granules.
+// q4/q8 images are ~0.4 KB, an order-0 row 0.8 KB, q40 4.6 KB (16 x 4,800 = 60 granules: 2 waves, 32 streams per CU — fuller waves measured faster than more waves)
+// LDS size classes: bytes per stream (image + word ring).  A workgroup takes as many streams as
+// fit beside the shared reciprocal table, up to 64 (four waves); 1,280-byte allocation granules.
+// (sizes are 16 mod 128: consecutive streams start four LDS banks apart, so that the eight streams of a
+// 32-lane access group do not all hit the same bank when they touch the same offset)
+static const u32 ENC_CLASSES[] = {656, 1296, 2576, 4752, 6416, 12816, 33296, 73616, 147344};
+// packed rows (20..64 symbols, 10-bit tables): 46 symbols need 3,532 bytes -> 45 streams per CU beside the small
+// reciprocal table (3,536 is 80 mod 128: consecutive streams start 20 banks apart)
+static const u32 ENC_PK_CLASSES[] = {1168, 2064, 2832, 3536, 3728, 4752, 6416};
+#define ENC_NCLS    ((u32)(sizeof(ENC_CLASSES) / sizeof(ENC_CLASSES[0])))
+#define ENC_PK_NCLS ((u32)(sizeof(ENC_PK_CLASSES) / sizeof(ENC_PK_CLASSES[0])))
+static int enc_class_qpw(u32 bytes, bool pk = false)
+{
+    const u32 room = 163840u - (pk ? ENC_LRCP_PK_BYTES : ENC_LRCP_BYTES);
+    const u32 fit = room / bytes;
+    static const int cap = getenv("R4X16_ENC_QPW_CAP") ? atoi(getenv("R4X16_ENC_QPW_CAP")) : 64;   // tuning aid
+    return (int)(fit > (u32)cap ? (u32)cap : fit);
+}
+extern "C" int r4x16_resident_grid(size_t lds_bytes, int waves_per_wg, int wanted);      // r4x16_decode.hip
+extern "C" int r4x16_cu_count(void);
+struct EncClassTab { u32 n; u32 bytes[CLS_MAX]; u32 pk[CLS_MAX]; };     // classes: u16 images, then packed ones
+__global__ __launch_bounds__(256) void k_enc_classify(const EncItem *items, int nitems, EncClassTab tab, u32 *cls, u32 *count)
+{
+    __shared__ u32 local[CLS_MAX];
+    if (threadIdx.x < CLS_MAX) local[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < nitems) {
+        u32 c = CLS_NONE;
+        if (items[i].active) {
+            const u32 need = items[i].img_bytes + ENC_RING_BYTES, pk = items[i].packed;
+            c = tab.n;                                         // images too large for LDS (never a packed one)
+            for (u32 k = 0; k < tab.n; k++) if (tab.pk[k] == pk && need <= tab.bytes[k]) { c = k; break; }
+            atomicAdd(&local[c], 1u);
+        }
+        cls[i] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < CLS_MAX && local[threadIdx.x]) atomicAdd(&count[threadIdx.x], local[threadIdx.x]);
+}
+extern "C" void r4x16_launch_cls_group(const u32 *cls, int nitems, u32 *count, u32 *list, hipStream_t s);   // r4x16_decode.hip
+extern "C" void r4x16_launch_cls_zero(u32 *count, hipStream_t s);
+extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t s)
+{
+    {
+        EncClassTab tab;
+        tab.n = 0;
+        for (const u32 bytes : ENC_CLASSES) { tab.pk[tab.n] = 0; tab.bytes[tab.n++] = bytes; }
+        for (const u32 bytes : ENC_PK_CLASSES) { tab.pk[tab.n] = 1; tab.bytes[tab.n++] = bytes; }
+        r4x16_launch_cls_zero(ws->cls_count, s);
+        hipLaunchKernelGGL(k_enc_classify, dim3((nitems + 255) / 256), dim3(256), 0, s, (const EncItem *)ws->items, nitems, tab, ws->cls, ws->cls_count);
+        r4x16_launch_cls_group(ws->cls, nitems, ws->cls_count, ws->cls_list, s);
+    }
+    if (r4x16_first_on_device(4u)) {
+        (void)hipFuncSetAttribute((const void *)k_enc_chain<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+        r4x16_enc_chain_pk_lds_limit(163840);
+    }
+    u32 ci = 0;
+    static const int force_qpw = getenv("R4X16_ENC_QPW") ? atoi(getenv("R4X16_ENC_QPW")) : 0;   // tuning aids
+    static const int force_waves = getenv("R4X16_ENC_WAVES") ? atoi(getenv("R4X16_ENC_WAVES")) : 0;
+    for (u32 cls = 0; cls < ENC_NCLS + ENC_PK_NCLS; cls++) {
+        const bool pk = cls >= ENC_NCLS;
+        const u32 bytes = pk ? ENC_PK_CLASSES[cls - ENC_NCLS] : ENC_CLASSES[cls];
+        const u32 tuned = pk ? 3536u : 4752u;                // the class of the 46-symbol quality tables
+        int qpw = (force_qpw && bytes == tuned) ? force_qpw : enc_class_qpw(bytes, pk);
+        // One workgroup per CU is the best shape (measured: 30 streams per CU as 1 x 32 beat 2 x 16 by a
+        // third and half-filled 64s by a fifth), so a batch that cannot fill the class's workgroups on
+        // every CU gets smaller ones (items [0, n/3) are the payload streams).
+        {
+            const int cus = r4x16_cu_count();
+            int want = (((nitems + 2) / 3 + cus - 1) / cus + 3) & ~3;
+            if (want < 8) want = 8;
+            if (qpw > want) qpw = want;
+        }
+        int waves = (qpw + 7) / 8;                         // about eight streams per wave measured best (fewer
+        if (waves > 4) waves = 4;                          // lanes per LDS access, one wave per SIMD)
+        if (force_waves && bytes == tuned) waves = force_waves;
+        const int spw = (qpw + waves - 1) / waves;
+        const size_t ldsb = (size_t)(pk ? ENC_LRCP_PK_BYTES : ENC_LRCP_BYTES) + (size_t)qpw * bytes;
+        const int grid = r4x16_resident_grid(ldsb, waves, (nitems + qpw - 1) / qpw);
+        if (pk)
+            r4x16_enc_chain_pk_launch(grid, (int)(WAVE * waves), ldsb, s, ws->items, ws->rcptab, ws->dump, (const u32 *)ws->cls_list,
+                                      (const u32 *)(ws->cls_count + ci), qpw, spw, bytes);
+        else
+            hipLaunchKernelGGL((k_enc_chain<true, false>), dim3(grid), dim3(WAVE * waves), ldsb, s,
+                               ws->items, ws->rcptab, ws->dump, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci), qpw, spw, bytes);
+        ci++;
+    }
+    const int grid = (nitems + 15) / 16;
+    hipLaunchKernelGGL((k_enc_chain<false, false>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->rcptab, ws->dump,
+                       (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci), 16, 16, 0u);
+}
+extern "C" int r4x16_enc_residency(u32 nsym, int order, int *streams_per_wave, int *waves_per_cu)
+{
+    if (nsym == 0 || nsym > 256) return -1;
+    // (the packed rows need a 10-bit table: what every BASELINE text chooses; a 12-bit stream keeps the u16 rows)
+    const bool pk = order && nsym >= ENC_PK_MIN_NS && nsym <= ENC_PK_MAX_NS;
+    const u32 need = (pk ? enc_pk_img_bytes(nsym) : order ? ENC_IMG_IDX + 2u * nsym * (nsym + 1) : ENC_IMG_IDX + 2u * 257u) + ENC_RING_BYTES;
+    for (u32 cls = 0; cls < ENC_NCLS + ENC_PK_NCLS; cls++) {
+        if ((cls >= ENC_NCLS) != pk) continue;
+        const u32 bytes = pk ? ENC_PK_CLASSES[cls - ENC_NCLS] : ENC_CLASSES[cls];
+        if (need > bytes) continue;
+        const int qpw = enc_class_qpw(bytes, pk);
+        int waves = (qpw + 7) / 8;
+        if (waves > 4) waves = 4;
+        *streams_per_wave = (qpw + waves - 1) / waves;
+        *waves_per_cu = waves;                               // one workgroup per CU
+        return qpw;
+    }
+    *streams_per_wave = 16; *waves_per_cu = 8;
+    return 128;
+}
