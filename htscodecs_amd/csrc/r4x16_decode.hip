@@ -1272,10 +1272,18 @@ __device__ bool rle_expand(const u8 *lit, u32 lit_len, const u8 *runs, u32 run_l
     u32 rp = 0;
     bool err = false;
     const u64 lane_below = (1ull << lane) - 1ull;
+    // Both inputs are requested ahead of their use - the literals of the next two trips, the run bytes at the cursor as
+    // soon as the cursor moves - so that a trip does not begin with one or two dependent trips to memory (one wave per
+    // block: nothing else hides them; 6.3 ms for 4,096 x 1 MiB q4 blocks with X_PACK|X_RLE before).
+    gcu8 *glit = to_global(lit), *gruns = to_global(runs);
+    u32 lit1 = lane < lit_len ? glit[lane] : 0u, lit2 = WAVE + lane < lit_len ? glit[WAVE + lane] : 0u;
+    u32 cnext = lane < run_len ? gruns[lane] : 0u;        // runs[rp + lane]
     for (u32 base = 0; base < lit_len && !err; base += WAVE) {
         const u32 i = base + lane;
         const bool valid = i < lit_len;
-        const u32 bval = valid ? lit[i] : 0u;
+        const u32 bval = lit1;
+        lit1 = lit2;
+        lit2 = i + 2 * WAVE < lit_len ? glit[i + 2 * WAVE] : 0u;
         const bool r = valid && B.is_rle[bval];
         const u64 rmask = __ballot(r);
         const u32 nr = (u32)__popcll(rmask), myrank = (u32)__popcll(rmask & lane_below);
@@ -1283,7 +1291,7 @@ __device__ bool rle_expand(const u8 *lit, u32 lit_len, const u8 *runs, u32 run_l
         while (got < nr && rp < run_len) {                 // past the end a varint reads as 0 (varint.h:136)
             const u32 p = rp + lane;
             const bool have = p < run_len;
-            const u32 c = have ? runs[p] : 0u;
+            const u32 c = cnext;
             const bool isend = have && (!(c & 0x80u) || p == run_len - 1);
             const u64 E = __ballot(isend);
             if (!E) { err = true; break; }                 // a "varint" of 64+ bytes: never produced by an encoder
@@ -1303,6 +1311,7 @@ __device__ bool rle_expand(const u8 *lit, u32 lit_len, const u8 *runs, u32 run_l
             if (r && myrank >= got && myrank < got + ntake) runval = B.vals[myrank - got];
             const u64 lastm = __ballot(isend && erank == ntake - 1);
             rp += (u32)__ffsll((unsigned long long)lastm);   // index of that lane + 1
+            cnext = rp + lane < run_len ? gruns[rp + lane] : 0u;
             got += ntake;
             __syncthreads();
         }
@@ -1363,8 +1372,17 @@ __device__ bool unpack(const u8 *data, u32 len, u8 *out, u32 out_len, u32 per, B
         const u32 m4 = (u32)B.map[0] | ((u32)B.map[1] << 8) | ((u32)B.map[2] << 16) | ((u32)B.map[3] << 24);
         const u32 in_per = 4u, out_per = in_per * per;                       // bytes in / out per lane and trip
         const u32 trips = out_len / out_per;
-        for (u32 t = lane; t < trips; t += WAVE) {
-            const u32 w = *(const u32_unaligned *)(data + 4ull * t);
+        // four packed dwords per lane in flight (one wave per block: a trip's load would otherwise wait alone)
+        gcu8 *gdata = to_global(data);
+        auto ldw = [&](u32 t) -> u32 { return t < trips ? *(GAS const u32_unaligned *)(gdata + 4ull * t) : 0u; };
+        u32 wq[4] = {ldw(lane), ldw(lane + WAVE), ldw(lane + 2 * WAVE), ldw(lane + 3 * WAVE)};
+        for (u32 t0 = lane; t0 < trips; t0 += 4 * WAVE)
+#pragma unroll
+        for (u32 qi = 0; qi < 4; qi++) {
+            const u32 t = t0 + qi * WAVE;
+            const u32 w = wq[qi];
+            wq[qi] = ldw(t + 4 * WAVE);
+            if (t >= trips) continue;
             u8 *o = out + (u64)out_per * t;
             if (per == 4) {
                 // byte b -> selector bytes (b & 3, b >> 2 & 3, b >> 4 & 3, b >> 6): nibbles to bits 0 and 16, then pairs
