@@ -383,8 +383,8 @@ def main():
             w = pmc["workload"]
             if (w["blocks"], w["block_size"], w["data"], w["order"]) == (nblk, bs, args.data, order) \
                     and pmc.get("library_sha256_16") == build:
-                for key, v in pmc["kernels"].items():
-                    if key.startswith(kname):
+                for key, v in pmc["kernels"].items():       # the instantiation that did the work (k_dec_chain<true, 1>, not the
+                    if key.startswith(kname) and v["traffic_bytes"] > (traffic or 0):   # nested tables' k_dec_chain<true, 3>)
                         traffic = v["traffic_bytes"]
                         traffic_source = "profiles/r02_pmc_traffic.json"
                 sq = pmc.get("sq", {}).get(kname)
