@@ -1994,36 +1994,228 @@ __device__ __forceinline__ u32 chain_decode8(GImg img, u32 nsym, gcu8 *bytes, u3
     return bad;
 }
 
-__global__ __launch_bounds__(WAVE) void k8_dec_chain(const X8Item *items, BatchArgs a, int base, int nitems)
+// The same loop with the image and a 256-byte window of the stream's bytes in LDS (as k_dec_chain has them for 4x16):
+// the first version read its tables through L2 and fetched every renormalisation byte with a load that depended on the
+// step before (19-25 GB/s).  Ring: quarters h, h+1, h+2 of the stream are resident while the cursor is in quarter h (a
+// trip of eight steps moves it by at most 64 bytes), quarter h+3 waits in registers.
+#define X8_RING 272u
+#define X8_TRIP 8
+template <int ORDER, int LV>
+__device__ __forceinline__ u32 chain_decode8_lds(const u8 *img_lds, u32 nsym, u8 *ring, gcu8 *bytes, u32 bytes_len, gu8 *out, u32 out_sz,
+                                                 u32 x, bool active, u32 lane)
 {
-    const u32 lane = threadIdx.x;
-    const int slot = (int)blockIdx.x * 16 + (int)(lane >> 2);
-    const bool mine = slot < nitems;
-    const X8Item *I = &items[mine ? slot : 0];
+    const LImg img{lds_addr(img_lds)};
+    const u32 k = lane & 3;
+    const u32 rows = img_alpha_bytes(nsym), roww = img_row_bytes(nsym);
+    const u32 below = (1u << k) - 1u;
+    u32 count, pos;
+    if (ORDER == 0) { count = (out_sz + 3 - k) >> 2; pos = k; }
+    else { const u32 q = out_sz >> 2; count = q + (k == 3 ? out_sz - 4 * q : 0); pos = k * q; }
+    if (!active) count = 0;
+    // stream bytes relative to the 16-byte aligned address below `bytes`
+    gcu8 *abase = (gcu8 *)((u64)bytes & ~15ull);
+    const u32 off0 = (u32)((u64)bytes & 15ull);
+    const u32 avail = off0 + bytes_len;
+    const u32 lastc = avail ? (avail - 1u) >> 4 : 0u;
+    const bool loadable = active && avail != 0;
+    auto load_chunk = [&](u32 c) -> u32x4 {
+        u32x4 v = {0, 0, 0, 0};
+        if (loadable) v = *(gcu32x4 *)(abase + 16ull * (c < lastc ? c : lastc));   // past the input the last chunk repeats: never taken
+        return v;
+    };
+    if (active) {
+        const u32x4 c0 = load_chunk(k);
+        *(u32x4 *)(ring + 16 * k) = c0;
+        *(u32x4 *)(ring + 64 + 16 * k) = load_chunk(k + 4);
+        *(u32x4 *)(ring + 128 + 16 * k) = load_chunk(k + 8);
+        if (k == 0) *(u32x2 *)(ring + 256) = c0.xy;           // the first 8 bytes once more behind the ring: no wrap inside a window
+    }
+    u32x4 pend = load_chunk(12 + k);
+    u32 half = 0;
+    __syncthreads();
+    const u32 rbase = lds_addr(ring);
+    u32 row = rows, cursor = 0, bad = 0, t = 0;
+    u32x2 root = LV == 2 ? img.ld64(row) : u32x2{0u, 0u};
+    if (ORDER == 1 && count) bad = img.ld16(0) & ROW_EMPTY;
+    // Output: a trip's bytes are gathered in registers and leave at the top of the NEXT trip - the wave's vector-memory
+    // counter retires in order, so a store issued just before the ring refill would make the refill's wait for its
+    // prefetched chunk a wait for that store's acknowledgement (byte stores every step: 330 ns per step instead of 250).
+    // Order 1: a chain's eight consecutive bytes, one 8-byte store.  Order 0: step T puts byte 4T + k on chain k; the
+    // quad transposes four steps' bytes (k_dec_chain's scheme) and each lane stores the dword of one step.
+    u32 accA = 0, accB = 0, pendA = 0, pendB = 0;
+    u64 pend_at = 0;
+    bool pending = false;
+    const u32 qcount = ORDER == 0 ? (out_sz >> 2) : 0u;       // order 0: steps in which all four chains produce a byte
+    while (wave_any(t < count)) {
+        if (pending) {
+            if (ORDER == 1) *(GAS u32x2_unaligned *)(out + pend_at) = u32x2{pendA, pendB};
+            else { *(GAS u32_unaligned *)(out + pend_at) = pendA; *(GAS u32_unaligned *)(out + pend_at + 16) = pendB; }
+            pending = false;
+        }
+        // gathered route for this trip: every step of it produces a byte on this chain (order 1) / on all four chains
+        const bool whole = active && (ORDER == 1 ? t + X8_TRIP <= count : t + X8_TRIP <= qcount);   // (idle quads point at another's item)
+#pragma unroll
+        for (int u = 0; u < X8_TRIP; u++) {
+            const bool live = t + (u32)u < count;
+            // the eight bytes at the quad's cursor - all it can take in one step - are requested before the table
+            // look-ups, as three aligned dwords (k_dec_chain does the same with its words)
+            const u32 P0 = off0 + cursor, ra = rbase + (P0 & 252u);
+            const u32 d0 = *(LAS const volatile u32 *)(unsigned long)ra, d1 = *(LAS const volatile u32 *)(unsigned long)(ra + 4u),
+                      d2 = *(LAS const volatile u32 *)(unsigned long)(ra + 8u);
+            u32 xn = x;
+            const u32 s = lookup_step<LV>(img, row, X8_BITS, 4095u, xn, LV == 2 ? &root : nullptr);
+            // the next row's root: requested as soon as the symbol is known, used at the top of the next step
+            const u32 rown = ORDER == 1 ? rows + __umul24(s, roww) : row;
+            const u32x2 rootn = (LV == 2 && ORDER == 1) ? img.ld64_now(rown) : root;
+            const u32 al = img.ld16(2 * s);
+            x = live ? xn : x;
+            bad |= live ? (al & ROW_BAD) : 0u;
+            if (ORDER == 1) {
+                row = live ? rown : row;
+                root.x = live ? rootn.x : root.x;
+                root.y = live ? rootn.y : root.y;
+                bad |= (t + (u32)u + 1 < count) ? (al & ROW_EMPTY) : 0u;
+            }
+            if (live && !whole) { out[pos] = (u8)al; pos += ORDER == 0 ? 4 : 1; }
+            if (u < 4) accA = __builtin_amdgcn_alignbit(al, accA, 8); else accB = __builtin_amdgcn_alignbit(al, accB, 8);
+            // a chain takes one byte if x < 2^23 and a second one if x < 2^15; chains are served in the order 0..3, and
+            // nothing is read past the end (rANS_byte.h:541-551)
+            const bool w1 = live && x < X8_LOW, w2 = live && x < (1u << 15);
+            const u32 m1 = quad_ballot(w1, lane), m2 = quad_ballot(w2, lane);
+            const u32 pre = __popc(m1 & below) + __popc(m2 & below);        // bytes the chains before this one take: 0..6
+            const u32 at = cursor + pre;
+            const u32 want = (w1 ? 1u : 0u) + (w2 ? 1u : 0u);
+            const u32 room = at < bytes_len ? bytes_len - at : 0u;
+            const u32 take = want < room ? want : room;
+            const u32 wlo = __builtin_amdgcn_alignbyte(d1, d0, P0), whi = __builtin_amdgcn_alignbyte(d2, d1, P0);
+            const u64 win = (((u64)whi << 32) | wlo) >> (8u * pre);
+            const u32 b0 = (u32)win & 0xffu, b1 = ((u32)win >> 8) & 0xffu;
+            const u32 x1 = (x << 8) | b0, x2 = (x1 << 8) | b1;
+            x = take > 1 ? x2 : take ? x1 : x;
+            cursor += __popc(m1) + __popc(m2);
+        }
+        if (ORDER == 1) {
+            if (whole) { pendA = accA; pendB = accB; pend_at = pos; pos += X8_TRIP; pending = true; }
+        } else {
+            // (uniform over a quad: out_sz is) 4 x 4 byte transposes: lane j gets the dword of step t + j / t + 4 + j
+            const u32 sel = k | ((4u + k) << 8);
+            const u32 A0 = quad_bcast0(accA), A1 = quad_bcast1(accA), A2 = quad_bcast2(accA), A3 = quad_bcast3(accA);
+            const u32 B0 = quad_bcast0(accB), B1 = quad_bcast1(accB), B2 = quad_bcast2(accB), B3 = quad_bcast3(accB);
+            const u32 dA = __builtin_amdgcn_perm(__builtin_amdgcn_perm(A3, A2, sel), __builtin_amdgcn_perm(A1, A0, sel), 0x05040100u);
+            const u32 dB = __builtin_amdgcn_perm(__builtin_amdgcn_perm(B3, B2, sel), __builtin_amdgcn_perm(B1, B0, sel), 0x05040100u);
+            if (whole) { pendA = dA; pendB = dB; pend_at = 4ull * (t + k); pos += 4 * X8_TRIP; pending = true; }
+        }
+        t += X8_TRIP;
+        const u32 nh = (off0 + cursor) >> 6;
+        if (wave_any(active && nh != half)) {
+            if (active && nh != half) {
+                const u32 slot = ((nh + 2) & 3u) * 64u + 16u * k;
+                *(u32x4 *)(ring + slot) = pend;
+                if (slot == 0) *(u32x2 *)(ring + 256) = pend.xy;
+                pend = load_chunk(4 * (nh + 3) + k);
+                half = nh;
+            }
+            __syncthreads();
+        }
+    }
+    if (pending) {
+        if (ORDER == 1) *(GAS u32x2_unaligned *)(out + pend_at) = u32x2{pendA, pendB};
+        else { *(GAS u32_unaligned *)(out + pend_at) = pendA; *(GAS u32_unaligned *)(out + pend_at + 16) = pendB; }
+    }
+    return bad;
+}
+
+// streams grouped by LDS need (k_cls_scan / k_cls_scatter as for 4x16): class 0 - one-row images (order 0), 16 per
+// wave; class 1 - images up to X8_SLOT1 (order 1, up to 50 symbols: the quality alphabets), 12 per wave; class 2 - the
+// rest, tables through L2
+#define X8_SLOT0 (IMG_O0_BYTES + X8_RING)
+#define X8_SLOT1 6416u
+__global__ __launch_bounds__(256) void k8_classify(const X8Item *items, int nitems, u32 *cls, u32 *count)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i >= nitems) return;
+    const X8Item *I = &items[i];
+    u32 c = CLS_NONE;
+    if (I->active) {
+        const u32 need = img_bytes(I->nsym, I->order ? I->nsym : 1u) + X8_RING;
+        c = need <= X8_SLOT0 ? 0u : need <= X8_SLOT1 ? 1u : 2u;
+        atomicAdd(&count[c], 1u);
+    }
+    cls[i] = c;
+}
+
+template <bool LDS_IMG>
+__global__ __launch_bounds__(WAVE) void k8_dec_chain(const X8Item *items, BatchArgs a, int base, const u32 *list, const u32 *count,
+                                                     int qpw, u32 slot_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 lds[];
+    const u32 lane = threadIdx.x, quad = lane >> 2;
+    const int nmine = (int)count[0];
+    list += count[CLS_MAX];
+    const int slot = (int)blockIdx.x * qpw + (int)quad;
+    if ((int)blockIdx.x * qpw >= nmine) return;
+    const bool mine = quad < (u32)qpw && slot < nmine;
+    const u32 idx = list[mine ? slot : (int)blockIdx.x * qpw];
+    const X8Item *I = &items[idx];
     const bool active = mine && I->active;
-    if (!wave_any(active)) return;
     const u32 nsym = active ? I->nsym : 1u, order = active ? I->order : 2u;
     const u32 lv = img_levels(nsym);
-    GImg im{(gcu8 *)I->image};
     gcu8 *bytes = (gcu8 *)I->bytes;
     gu8 *out = (gu8 *)I->out;
     const u32 blen = I->bytes_len, osz = I->out_sz, x0 = I->R[lane & 3];
     u32 bad = 0;
-#define X8_RUN(O, L) bad |= chain_decode8<O, L>(im, nsym, bytes, blen, out, osz, x0, active && order == O && lv == L, lane)
-    X8_RUN(0, 2); X8_RUN(0, 3); X8_RUN(0, 4);
-    X8_RUN(1, 2); X8_RUN(1, 3); X8_RUN(1, 4);
+    if (LDS_IMG) {
+        const u64 my_img = active ? I->image : 0ull;
+        const u32 nbytes = active ? img_bytes(nsym, order ? nsym : 1u) : 0u;
+        for (int qd = 0; qd < qpw; qd++) {
+            const u64 src = __shfl(my_img, qd * 4);
+            const u32 nb = __shfl(nbytes, qd * 4);
+            if (!src) continue;
+            gcu32x4 *sp = (gcu32x4 *)src;
+            u32x4 *dd = (u32x4 *)(lds + (u64)qd * slot_bytes);
+            for (u32 j = lane; j < ((nb + 15) >> 4); j += WAVE) dd[j] = sp[j];
+        }
+        __syncthreads();
+        const u8 *im = lds + (u64)quad * slot_bytes;
+        u8 *ring = lds + (u64)quad * slot_bytes + (slot_bytes - X8_RING);
+#define X8_RUN(O, L) bad |= chain_decode8_lds<O, L>(im, nsym, ring, bytes, blen, out, osz, x0, active && order == O && lv == L, lane)
+        X8_RUN(0, 2); X8_RUN(0, 3); X8_RUN(0, 4);
+        X8_RUN(1, 2);                                          // (X8_SLOT1 holds 2-read images only: up to 50 symbols)
 #undef X8_RUN
+    } else {
+        GImg im{(gcu8 *)I->image};
+#define X8_RUN(O, L) bad |= chain_decode8<O, L>(im, nsym, bytes, blen, out, osz, x0, active && order == O && lv == L, lane)
+        X8_RUN(0, 2); X8_RUN(0, 3); X8_RUN(0, 4);
+        X8_RUN(1, 2); X8_RUN(1, 3); X8_RUN(1, 4);
+#undef X8_RUN
+    }
     if (active && bad) {
-        a.status[base + slot] = (bad & ROW_BAD) ? ST_TABLE : ST_CONTEXT;
-        a.out_size[base + slot] = 0;
+        a.status[base + (int)idx] = (bad & ROW_BAD) ? ST_TABLE : ST_CONTEXT;
+        a.out_size[base + (int)idx] = 0;
     }
 }
 
-extern "C" size_t r4x8_dec_ws_bytes(size_t nblk) { return align_up_sz(nblk * sizeof(X8Item), 256) + nblk * (size_t)IMG8_SLOT; }
+extern "C" size_t r4x8_dec_ws_bytes(size_t nblk)
+{
+    return align_up_sz(nblk * sizeof(X8Item), 256) + nblk * (size_t)IMG8_SLOT + 2 * align_up_sz(nblk * 4, 256) + align_up_sz(3 * CLS_MAX * 4, 256);
+}
 extern "C" void r4x8_launch_decode(const BatchArgs *a, u8 *ws, int base, int nblk, hipStream_t s)
 {
     X8Item *items = (X8Item *)ws;
     u8 *images = ws + align_up_sz((size_t)nblk * sizeof(X8Item), 256);
+    u32 *cls = (u32 *)(images + (size_t)nblk * IMG8_SLOT);
+    u32 *cls_list = (u32 *)((u8 *)cls + align_up_sz((size_t)nblk * 4, 256));
+    u32 *cls_count = (u32 *)((u8 *)cls_list + align_up_sz((size_t)nblk * 4, 256));
     hipLaunchKernelGGL(k8_dec_front, dim3(nblk), dim3(WAVE), 0, s, *a, items, images, base);
-    hipLaunchKernelGGL(k8_dec_chain, dim3((nblk + 15) / 16), dim3(WAVE), 0, s, (const X8Item *)items, *a, base, nblk);
+    r4x16_launch_cls_zero(cls_count, s);
+    hipLaunchKernelGGL(k8_classify, dim3((nblk + 255) / 256), dim3(256), 0, s, (const X8Item *)items, nblk, cls, cls_count);
+    r4x16_launch_cls_group(cls, nblk, cls_count, cls_list, s);
+    if (r4x16_first_on_device(8u)) lds_limit((const void *)k8_dec_chain<true>, 163840);
+    const int q0 = 16, q1 = 12;
+    hipLaunchKernelGGL(k8_dec_chain<true>, dim3((nblk + q0 - 1) / q0), dim3(WAVE), (size_t)q0 * X8_SLOT0, s, (const X8Item *)items, *a, base,
+                       (const u32 *)cls_list, (const u32 *)(cls_count + 0), q0, X8_SLOT0);
+    hipLaunchKernelGGL(k8_dec_chain<true>, dim3((nblk + q1 - 1) / q1), dim3(WAVE), (size_t)q1 * X8_SLOT1, s, (const X8Item *)items, *a, base,
+                       (const u32 *)cls_list, (const u32 *)(cls_count + 1), q1, X8_SLOT1);
+    hipLaunchKernelGGL(k8_dec_chain<false>, dim3((nblk + 15) / 16), dim3(WAVE), 0, s, (const X8Item *)items, *a, base,
+                       (const u32 *)cls_list, (const u32 *)(cls_count + 2), 16, 0u);
 }
