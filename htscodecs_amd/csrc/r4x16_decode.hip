@@ -2210,7 +2210,7 @@ extern "C" void r4x8_launch_decode(const BatchArgs *a, u8 *ws, int base, int nbl
     r4x16_launch_cls_zero(cls_count, s);
     hipLaunchKernelGGL(k8_classify, dim3((nblk + 255) / 256), dim3(256), 0, s, (const X8Item *)items, nblk, cls, cls_count);
     r4x16_launch_cls_group(cls, nblk, cls_count, cls_list, s);
-    if (r4x16_first_on_device(8u)) lds_limit((const void *)k8_dec_chain<true>, 163840);
+    if (r4x16_first_on_device(16u)) lds_limit((const void *)k8_dec_chain<true>, 163840);
     const int q0 = 16, q1 = 12;
     hipLaunchKernelGGL(k8_dec_chain<true>, dim3((nblk + q0 - 1) / q0), dim3(WAVE), (size_t)q0 * X8_SLOT0, s, (const X8Item *)items, *a, base,
                        (const u32 *)cls_list, (const u32 *)(cls_count + 0), q0, X8_SLOT0);
