@@ -211,58 +211,29 @@ __device__ __forceinline__ u32 pow2_ceil(u32 v)      // rANS_static4x16pr.c:105-
     return v + 1;
 }
 
-// byte-granular copy by NT threads (thread index t), any alignment, 16-byte pieces when possible
+// byte-granular copy by NT threads (thread index t), any alignment: head bytes until dst is 16-byte aligned, then
+// 16-byte stores fed by 16-byte loads at whatever alignment the source has (global loads need none), two pieces per
+// thread in flight.  (The first version fell back to dword pieces whenever source and destination were not co-aligned
+// - nearly always for a payload behind a header and a table: k_enc_finish moved its 12 GB at 4 bytes per lane.)
 template <u32 NT>
 __device__ __forceinline__ void group_copy(u8 *dst, const u8 *src, u32 n, u32 t)
 {
-    if ((((u64)dst ^ (u64)src) & 15) == 0 && n >= 64) {
-        u32 head = (u32)((16 - ((u64)dst & 15)) & 15);
-        for (u32 i = t; i < head; i += NT) dst[i] = src[i];
-        const u32 body = (n - head) >> 4;
-        const u32x4 *s16 = (const u32x4 *)(src + head);
-        u32x4 *d16 = (u32x4 *)(dst + head);
-        for (u32 i = t; i < body; i += NT) d16[i] = s16[i];
-        const u32 done = head + body * 16;
-        for (u32 i = done + t; i < n; i += NT) dst[i] = src[i];
-    } else if ((((u64)dst ^ (u64)src) & 3) == 0) {
-        u32 head = (u32)((4 - ((u64)dst & 3)) & 3);
-        if (head > n) head = n;
-        for (u32 i = t; i < head; i += NT) dst[i] = src[i];
-        const u32 body = (n - head) >> 2;
-        const u32 *s4 = (const u32 *)(src + head);
-        u32 *d4 = (u32 *)(dst + head);
-        for (u32 i = t; i < body; i += NT) d4[i] = s4[i];
-        const u32 done = head + body * 4;
-        for (u32 i = done + t; i < n; i += NT) dst[i] = src[i];
-    } else {
-        // misaligned pair: aligned dword stores assembled from two unaligned-source dwords
-        u32 head = (u32)((4 - ((u64)dst & 3)) & 3);
-        if (head > n) head = n;
-        for (u32 i = t; i < head; i += NT) dst[i] = src[i];
-        const u32 body = (n - head) >> 2;
-        u32 *d4 = (u32 *)(dst + head);
-        const u8 *sp = src + head;
-        for (u32 i = t; i < body; i += NT) d4[i] = *(const u32_unaligned *)(sp + 4 * (u64)i);
-        const u32 done = head + body * 4;
-        for (u32 i = done + t; i < n; i += NT) dst[i] = src[i];
+    u32 head = (u32)((16 - ((u64)dst & 15)) & 15);
+    if (head > n) head = n;
+    for (u32 i = t; i < head; i += NT) dst[i] = src[i];
+    const u32 body = (n - head) >> 4;
+    const u8 *sp = src + head;
+    u32x4 *d16 = (u32x4 *)(dst + head);
+    u32 i = t;
+    for (; i + NT < body; i += 2 * NT) {
+        const u32x4 a = *(const u32x4_unaligned *)(sp + 16ull * i), b = *(const u32x4_unaligned *)(sp + 16ull * (i + NT));
+        d16[i] = a;
+        d16[i + NT] = b;
     }
+    if (i < body) d16[i] = *(const u32x4_unaligned *)(sp + 16ull * i);
+    const u32 done = head + body * 16;
+    for (u32 j = done + t; j < n; j += NT) dst[j] = src[j];
 }
 
-// byte-granular copy by one wave, any alignment (header / table / payload assembly)
-__device__ __forceinline__ void wave_copy(u8 *dst, const u8 *src, u32 n, u32 lane)
-{
-    // head bytes until dst is 4-aligned, then dwords when src is co-aligned, else bytes
-    if ((((u64)dst ^ (u64)src) & 3) == 0) {
-        u32 head = (u32)((4 - ((u64)dst & 3)) & 3);
-        if (head > n) head = n;
-        if (lane < head) dst[lane] = src[lane];
-        u32 body = (n - head) >> 2;
-        const u32 *s4 = (const u32 *)(src + head);
-        u32 *d4 = (u32 *)(dst + head);
-        for (u32 i = lane; i < body; i += WAVE) d4[i] = s4[i];
-        u32 done = head + body * 4;
-        if (done + lane < n) dst[done + lane] = src[done + lane];
-    } else {
-        for (u32 i = lane; i < n; i += WAVE) dst[i] = src[i];
-    }
-}
+// byte-granular copy by one wave, any alignment (header / table / payload assembly): group_copy's scheme
+__device__ __forceinline__ void wave_copy(u8 *dst, const u8 *src, u32 n, u32 lane) { group_copy<WAVE>(dst, src, n, lane); }
