@@ -479,6 +479,88 @@ __device__ __forceinline__ void wg_hist1(const u8 *data, u32 n, FP Fp0, u32 ns, 
     }
 }
 
+// wg_hist1 for alphabets that sit in a narrow range of byte values [lo, lo + R) - quality values do: the counters
+// are indexed by (byte - lo) while counting, so that the sixteen byte -> compact index look-ups per 16-byte piece drop
+// out of the LDS queue, which is what bounds this pass (32 LDS instructions per piece, 4+ cycles each: 297 -> 193 us
+// per MiB and workgroup on 46-symbol quality data).  `nsa` = R, plus one "any other byte" index on the provisional
+// route (values outside the range clamp to it).  Afterwards the sums of the copies go to the compact nsx x nsx layout
+// every other pass uses; the four pairs that are coded in context 0 (the first byte and the three quarter starts,
+// rANS_static4x16pr.c:720-723) are added there.  Returns true - provisional route only - if a byte was counted that is
+// not in the alphabet (outside the range, or in a gap of it).  LDS counters only; nsa * nsa <= 18 * FRONT_THREADS.
+__device__ __forceinline__ bool wg_hist1_range(const u8 *data, u32 n, u32 *Fp0, u32 nsx, u32 copies, const EncShared &S, u32 lo, u32 nsa,
+                                               bool prov, u32 tid)
+{
+    const u32 csh = copies == 4 ? 2u : copies == 2 ? 1u : 0u;
+    u32 *Fp = Fp0 + (tid & (copies - 1));
+    const u32 top = nsa - 1, rsa = nsa | 1u;          // (odd row stride: an even one halves the banks a row pair can reach)
+    const u32 full = n >> 4;
+    struct Piece { u32x4 w; u32 before; };
+    auto ld = [&](u32 pi) -> Piece {
+        Piece p = {{0, 0, 0, 0}, 0};
+        if (pi < full) { p.w = *(GAS const u32x4_unaligned *)(to_global(data) + 16ull * pi); p.before = pi ? to_global(data)[16ull * pi - 1] : 0u; }
+        return p;
+    };
+    auto ix = [&](u32 b) -> u32 { const u32 d = b - lo; return d < top ? d : top; };      // (bytes below lo wrap around and clamp too)
+    auto count = [&](const Piece &p, u32 pi) {
+        if (pi >= full) return;
+        const u32 ww[4] = {p.w.x, p.w.y, p.w.z, p.w.w};
+        u32 ci[16];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            ci[4 * c] = ix(ww[c] & 0xff); ci[4 * c + 1] = ix((ww[c] >> 8) & 0xff);
+            ci[4 * c + 2] = ix((ww[c] >> 16) & 0xff); ci[4 * c + 3] = ix(ww[c] >> 24);
+        }
+        u32 prev = ix(p.before);
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            if (c || pi) atomicAdd(&Fp[(prev * rsa + ci[c]) << csh], 1u);       // (the block's first byte: context 0, below)
+            prev = ci[c];
+        }
+    };
+    const u32 T = FRONT_THREADS;
+    Piece q0 = ld(tid), q1 = ld(tid + T), q2 = ld(tid + 2 * T), q3 = ld(tid + 3 * T);
+    for (u32 pi = tid; pi < full; pi += 4 * T) {
+        count(q0, pi);         q0 = ld(pi + 4 * T);
+        count(q1, pi + T);     q1 = ld(pi + 5 * T);
+        count(q2, pi + 2 * T); q2 = ld(pi + 6 * T);
+        count(q3, pi + 3 * T); q3 = ld(pi + 7 * T);
+    }
+    if (tid == 0) {                                  // the last n % 16 bytes
+        u32 prev = full ? ix(data[16 * full - 1]) : 0u;
+        for (u32 i = 16 * full; i < n; i++) {
+            const u32 cur = ix(data[i]);
+            if (i) atomicAdd(&Fp[(prev * rsa + cur) << csh], 1u);
+            prev = cur;
+        }
+    }
+    __syncthreads();
+    // sums of the copies, each with its place in the compact layout
+    const u32 NONE = 0xffffffffu, R = prov ? top : nsa;
+    u32 sum[18], dst[18];
+    bool hit = false;
+#pragma unroll
+    for (u32 r = 0; r < 18; r++) {
+        const u32 j = tid + r * FRONT_THREADS;
+        sum[r] = 0; dst[r] = NONE;
+        if (j < nsa * nsa) {
+            const u32 ra = j / nsa, ca = j - ra * nsa;
+            u32 t = 0;
+            for (u32 c = 0; c < copies; c++) t += Fp0[((ra * rsa + ca) << csh) + c];
+            const bool ok = ra < R && ca < R && S.present[(lo + ra) & 0xffu] && S.present[(lo + ca) & 0xffu];
+            if (ok) { sum[r] = t; dst[r] = (u32)S.idx_of[(lo + ra) & 0xffu] * nsx + S.idx_of[(lo + ca) & 0xffu]; }
+            else if (t) hit = true;
+        }
+    }
+    __syncthreads();
+    for (u32 j = tid; j < nsx * nsx; j += FRONT_THREADS) Fp0[j] = 0;
+    __syncthreads();
+#pragma unroll
+    for (u32 r = 0; r < 18; r++) if (dst[r] != NONE) Fp0[dst[r]] = sum[r];
+    __syncthreads();
+    if (tid < 4) atomicAdd(&Fp0[S.idx_of[data[tid * (n >> 2)]]], 1u);             // row 0: the first byte, the quarter starts
+    return __syncthreads_or((int)hit) != 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // The two transforms, by all FRONT_THREADS threads of the workgroup.  (One-wave forms were latency-bound:
 // one dependent byte load per 64 bytes, 86 ms for 4,096 x 1 MiB blocks with X_PACK|X_RLE against 15 ms.)
@@ -784,7 +866,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
 {
     extern __shared__ __attribute__((aligned(16))) u8 dyn[];
     __shared__ EncShared S;
-    __shared__ struct { i32 status; u32 go, order, dlen, nested_len, flags, hl, run; u64 data; double e10, e12; int max_tot; u32 wcnt[4]; } H;
+    __shared__ struct { i32 status; u32 go, order, dlen, nested_len, flags, hl, run; u64 data; double e10, e12; int max_tot; u32 wcnt[4], wlo[4], whi[4], lo, span; } H;
 
     // Wave 0 runs the whole front end; waves 1..3 join only for the two histogram passes over the
     // block (the bulk of the memory traffic).  Inside wave-0-only code the ordering points are
@@ -985,24 +1067,40 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
             if (pr) { S.idx_of[tid] = (u8)k; S.alpha[k] = (u8)tid; }
             else if (prov) S.idx_of[tid] = (u8)(tot < 255 ? tot : 255);
             if (tid == 0) S.nsym = tot;
+            // the range of the byte values seen (byte 0 is in the alphabet by rule, not by being seen)
+            const u64 seen = __ballot(S.F[tid] != 0);
+            if (lane == 0) { H.wlo[tid >> 6] = seen ? (tid & ~63u) + (u32)__ffsll((unsigned long long)seen) - 1u : 256u;
+                             H.whi[tid >> 6] = seen ? (tid & ~63u) + 63u - (u32)__clzll((long long)seen) : 0u; }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            u32 l = 256, h = 0;
+            for (u32 w = 0; w < 4; w++) { if (H.wlo[w] < l) l = H.wlo[w]; if (H.wlo[w] != 256u && H.whi[w] > h) h = H.whi[w]; }
+            H.lo = l < 256u ? l : 0u; H.span = l < 256u ? h - l + 1u : 1u;
         }
         __syncthreads();
         ns = S.nsym;
         nsx = prov ? ns + 1 : ns;                                         // row / column count of the counters
         f_in_lds = 4u * nsx * nsx <= dyn_bytes;
         if (prov && !f_in_lds) continue;                                  // large alphabets: straight to the exact route
-        const u32 copies = (!f_in_lds || nsx * nsx > 18u * FRONT_THREADS) ? 1u : (16u * nsx * nsx <= dyn_bytes ? 4u : (8u * nsx * nsx <= dyn_bytes ? 2u : 1u));   // (wg_hist1 sums up to 18 counters per thread)
-        if (f_in_lds) { for (u32 j = tid; j < copies * nsx * nsx; j += FRONT_THREADS) ((u32 *)dyn)[j] = 0; }
+        u32 copies = (!f_in_lds || nsx * nsx > 18u * FRONT_THREADS) ? 1u : (16u * nsx * nsx <= dyn_bytes ? 4u : (8u * nsx * nsx <= dyn_bytes ? 2u : 1u));   // (wg_hist1 sums up to 18 counters per thread)
+        // the alphabet as a range of byte values (wg_hist1_range), if that costs no counter copies
+        const u32 lo = H.lo, nsa = H.span + (prov ? 1u : 0u);
+        const u32 copies_r = (!f_in_lds || nsa * nsa > 18u * FRONT_THREADS) ? 0u : (16u * nsa * (nsa | 1u) <= dyn_bytes ? 4u : (8u * nsa * (nsa | 1u) <= dyn_bytes ? 2u : 1u));
+        const bool ranged = copies_r >= copies && n >= 16;
+        if (ranged) copies = copies_r;
+        if (f_in_lds) { for (u32 j = tid; j < copies * (ranged ? nsa * (nsa | 1u) : nsx * nsx); j += FRONT_THREADS) ((u32 *)dyn)[j] = 0; }
         else          { for (u32 j = tid; j < nsx * nsx; j += FRONT_THREADS) Fg[j] = 0; }
         __syncthreads();
         // pass 2 over the block: order-1 pair histogram, all waves
         PROF(8);
-        if (f_in_lds) wg_hist1(data, n, (u32 *)dyn, nsx, copies, S.idx_of, tid);
-        else          wg_hist1(data, n, Fg, nsx, 1u, S.idx_of, tid);
+        bool hit = false;
+        if (ranged)        hit = wg_hist1_range(data, n, (u32 *)dyn, nsx, copies, S, lo, nsa, prov, tid);
+        else if (f_in_lds) wg_hist1(data, n, (u32 *)dyn, nsx, copies, S.idx_of, tid);
+        else               wg_hist1(data, n, Fg, nsx, 1u, S.idx_of, tid);
         PROF(9);
         if (!prov) break;
         // any pair with the overflow symbol (row ns or column ns of the (ns + 1)^2 counters)?
-        bool hit = false;
         for (u32 j = tid; j <= ns; j += FRONT_THREADS) hit |= ((u32 *)dyn)[ns * nsx + j] != 0 || ((u32 *)dyn)[j * nsx + ns] != 0;
         if (!__syncthreads_or(hit)) break;
     }
