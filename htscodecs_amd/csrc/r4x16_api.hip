@@ -430,7 +430,13 @@ struct Combiner {
     std::deque<CombReq *> q[2];                // [0] encode, [1] decode
     int device = 0;
     bool started = false, stop = false;
-    long window_us = 200, max_batch = 256;
+    // One worker per direction: requests that arrive while a batch runs queue up and form the next batch, and the
+    // callers of the batch that has just finished are given a moment to come back and join it - a twentieth of what
+    // that batch took (20 us .. 2 ms; 200 us before the first), so that a pool calling in lock-step ends up in ONE batch
+    // per round instead of two groups that alternate, each waiting for the other's (two workers with a fixed 200 us
+    // window: 32 threads x 1 MiB decoded at 205-410 MB/s depending on how the groups fell; this way: see INTEGRATION 1).
+    long window_us = -1, max_batch = 256, workers = 1;
+    long last_us[2] = {4000, 4000};
 
     void worker(int dir)
     {
@@ -440,14 +446,16 @@ struct Combiner {
         for (;;) {
             cv_work.wait(lk, [&] { return stop || !q[dir].empty(); });
             if (stop) break;
-            if ((long)q[dir].size() < max_batch && window_us > 0) {
+            const long win = window_us >= 0 ? window_us : std::min(2000L, std::max(20L, last_us[dir] / 20));
+            if ((long)q[dir].size() < max_batch && win > 0) {
                 // more callers may be a few microseconds behind: give them the window
-                cv_work.wait_for(lk, std::chrono::microseconds(window_us), [&] { return stop || (long)q[dir].size() >= max_batch; });
+                cv_work.wait_for(lk, std::chrono::microseconds(win), [&] { return stop || (long)q[dir].size() >= max_batch; });
                 if (stop) break;
             }
             std::vector<CombReq *> batch;
             while (!q[dir].empty() && (long)batch.size() < max_batch) { batch.push_back(q[dir].front()); q[dir].pop_front(); }
             lk.unlock();
+            const auto t0 = std::chrono::steady_clock::now();
             const int n = (int)batch.size();
             std::vector<const unsigned char *> in(n);
             std::vector<unsigned char *> out(n);
@@ -456,7 +464,9 @@ struct Combiner {
             for (int i = 0; i < n; i++) { in[i] = batch[i]->in; out[i] = batch[i]->out; isz[i] = batch[i]->in_size; osz[i] = batch[i]->cap; ord[i] = batch[i]->order; }
             const int rc = c ? r4x16_run_host_batch(c, n, dir == 1, in.data(), isz.data(), out.data(), osz.data(), dir == 0 ? ord.data() : nullptr, st.data()) : -1;
             if (c) r4x16_trim(c, (size_t)4 << 30);
+            const long took = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
             lk.lock();
+            last_us[dir] = took;
             for (int i = 0; i < n; i++) {
                 batch[i]->rc = rc < 0 ? -1 : (st[i] != 0 ? 1 : 0);
                 batch[i]->result = rc < 0 ? 0u : osz[i];
@@ -472,12 +482,13 @@ struct Combiner {
         std::unique_lock<std::mutex> lk(mu);
         if (!started) {
             started = true;
-            const char *w = getenv("R4X16_COMBINE_WINDOW_US"), *m = getenv("R4X16_COMBINE_MAX");
-            if (w && *w) window_us = atol(w);
+            const char *w = getenv("R4X16_COMBINE_WINDOW_US"), *m = getenv("R4X16_COMBINE_MAX"), *k = getenv("R4X16_COMBINE_WORKERS");
+            if (w && *w) window_us = atol(w);                   // a fixed window instead of the adaptive one
             if (m && *m && atol(m) > 0) max_batch = atol(m);
+            if (k && *k && atol(k) > 0 && atol(k) <= 4) workers = atol(k);
             // (detached, and the combiner itself is never destroyed: tearing GPU contexts down from static destructors
             //  at process exit races the runtime's own shutdown)
-            for (int d = 0; d < 2; d++) for (int k = 0; k < 2; k++) std::thread([this, d] { worker(d); }).detach();
+            for (int d = 0; d < 2; d++) for (long j = 0; j < workers; j++) std::thread([this, d] { worker(d); }).detach();
         }
         q[dir].push_back(&r);
         cv_work.notify_all();
