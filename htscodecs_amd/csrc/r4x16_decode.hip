@@ -709,22 +709,27 @@ __device__ __forceinline__ bool row_parse_wave(WinSrc &win, u32 wlimit, u32 p, u
         // transition function of this byte, next state from START / CONT / RUN in bits 0-1 / 2-3 / 4-5
         // (START = 0, CONT = 1, RUN = 2): continuation byte -> CONT, CONT, START; zero -> RUN, START, START; other -> START
         u32 F = cont ? 5u : (b == 0 ? 2u : 0u);
-#pragma unroll
-        for (u32 d = 1; d < WAVE; d <<= 1) {
-            const u32 g = (u32)__shfl_up((int)F, d);          // the bytes before
-            if (lane >= d) {
+        // (the scan's data moves on DPP row operations, as in wave_incl_scan: `g` = the composition of the bytes before)
+        auto after = [&](u32 g, bool has) {
+            if (has) {
                 const u32 h0 = (F >> (2u * (g & 3u))) & 3u, h1 = (F >> (2u * ((g >> 2) & 3u))) & 3u, h2 = (F >> (2u * ((g >> 4) & 3u))) & 3u;
                 F = h0 | (h1 << 2) | (h2 << 4);
             }
-        }
-        const u32 prevF = (u32)__shfl_up((int)F, 1);
+        };
+        after(dpp_row<0x111, 0xf>(F), (lane & 15u) >= 1u);
+        after(dpp_row<0x112, 0xf>(F), (lane & 15u) >= 2u);
+        after(dpp_row<0x114, 0xf>(F), (lane & 15u) >= 4u);
+        after(dpp_row<0x118, 0xf>(F), (lane & 15u) >= 8u);
+        after(dpp_row<0x142, 0xa>(F), (lane & 16u) != 0u);       // lane 15 of rows 0 / 2 -> rows 1 / 3
+        after(dpp_row<0x143, 0xc>(F), (lane & 32u) != 0u);       // lane 31 -> rows 2 and 3
+        const u32 prevF = dpp_row<0x138, 0xf>(F);                // wave_shr:1
         const u32 pre = lane ? (prevF & 3u) : 0u;             // this byte's state: the chunk starts at a value
         const bool runb = pre == 2u, vend = pre != 2u && !cont, zero1 = pre == 0u && b == 0u;
         const bool complete = runb || (vend && !zero1);
         const u32 Mi = wave_incl_scan(runb ? b : (vend ? 1u : 0u), lane);
         // the varint that ends here: up to four bytes before this one
         const u32 pk = b | (pre << 8);
-        const u32 q1 = (u32)__shfl_up((int)pk, 1), q2 = (u32)__shfl_up((int)pk, 2), q3 = (u32)__shfl_up((int)pk, 3), q4 = (u32)__shfl_up((int)pk, 4);
+        const u32 q1 = dpp_row<0x138, 0xf>(pk), q2 = dpp_row<0x138, 0xf>(q1), q3 = dpp_row<0x138, 0xf>(q2), q4 = dpp_row<0x138, 0xf>(q3);   // wave_shr:1
         const bool c1 = pre == 1u, c2 = c1 && (q1 >> 8) == 1u, c3 = c2 && (q2 >> 8) == 1u, c4 = c3 && (q3 >> 8) == 1u, c5 = c4 && (q4 >> 8) == 1u;
         const u32 v = (b & 0x7fu) | (c1 ? (q1 & 0x7fu) << 7 : 0u) | (c2 ? (q2 & 0x7fu) << 14 : 0u) | (c3 ? (q3 & 0x7fu) << 21 : 0u) |
                       (c4 ? (q4 & 0x7fu) << 28 : 0u);
@@ -1317,12 +1322,16 @@ __device__ bool rle_expand(const u8 *lit, u32 lit_len, const u8 *runs, u32 run_l
         }
         if (err) break;
         const u64 len = valid ? 1ull + runval : 0ull;
-        // exclusive prefix of lengths (64-bit: a hostile run can be 4 GiB)
+        // exclusive prefix of lengths (64-bit sums only when a run is long enough for sixty-four of them to pass 2^32: a
+        // hostile run can be 4 GiB)
         u64 incl = len;
+        if (!__ballot(runval > 0x00ffffffu)) incl = wave_incl_scan((u32)len, lane);
+        else {
 #pragma unroll
-        for (int dd = 1; dd < WAVE; dd <<= 1) {
-            const u64 tt = __shfl_up(incl, dd);
-            if (lane >= (u32)dd) incl += tt;
+            for (int dd = 1; dd < WAVE; dd <<= 1) {
+                const u64 tt = __shfl_up(incl, dd);
+                if (lane >= (u32)dd) incl += tt;
+            }
         }
         const u64 excl = incl - len;
         const u64 total = __shfl(incl, WAVE - 1);

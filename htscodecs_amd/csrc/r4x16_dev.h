@@ -186,22 +186,29 @@ __device__ __forceinline__ u32 quad_ballot(bool p, u32 lane)
 
 __device__ __forceinline__ u32 wave_any(bool p) { return __ballot(p) != 0ull; }
 
-// wave-wide inclusive prefix sum over 64 lanes (shuffle based; used outside the hot loops)
+// wave-wide inclusive prefix sum over 64 lanes on DPP row operations (VALU speed: four shifts inside the rows of
+// sixteen lanes, then lane 15 of rows 0 and 2 into rows 1 and 3, then lane 31 into the upper half; the version on
+// ds_bpermute shuffles cost six LDS-crossbar round trips on the dependent path of every table row and RLE trip)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ u32 dpp_row(u32 v)          // lanes without a source (and rows outside ROW_MASK) read 0
+{
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
 __device__ __forceinline__ u32 wave_incl_scan(u32 v, u32 lane)
 {
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        u32 t = __shfl_up(v, d);
-        if (lane >= (u32)d) v += t;
-    }
+    (void)lane;
+    v += dpp_row<0x111, 0xf>(v);                       // row_shr:1
+    v += dpp_row<0x112, 0xf>(v);                       // row_shr:2
+    v += dpp_row<0x114, 0xf>(v);                       // row_shr:4
+    v += dpp_row<0x118, 0xf>(v);                       // row_shr:8
+    v += dpp_row<0x142, 0xa>(v);                       // row_bcast:15 into rows 1 and 3
+    v += dpp_row<0x143, 0xc>(v);                       // row_bcast:31 into rows 2 and 3
     return v;
 }
 
 __device__ __forceinline__ u32 wave_sum(u32 v)
 {
-#pragma unroll
-    for (int d = WAVE / 2; d; d >>= 1) v += __shfl_xor(v, d);
-    return v;
+    return (u32)__builtin_amdgcn_readlane((int)wave_incl_scan(v, 0), WAVE - 1);
 }
 
 __device__ __forceinline__ u32 pow2_ceil(u32 v)      // rANS_static4x16pr.c:105-114
