@@ -258,6 +258,9 @@ def main():
     # rehearsal knobs (not used by the driver): several ranks on one card over gloo
     if "R4X16_FORCE_DEVICE" in os.environ:
         local = int(os.environ["R4X16_FORCE_DEVICE"])
+    elif os.environ.get("R4X16_OVERSUBSCRIBE") == "1" and torch.cuda.device_count() and local >= torch.cuda.device_count():
+        local %= torch.cuda.device_count()      # a launcher's ranks on fewer cards than ranks (rehearsal)
+        os.environ.setdefault("R4X16_DIST_BACKEND", "gloo")
     backend = os.environ.get("R4X16_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
