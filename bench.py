@@ -258,9 +258,9 @@ def main():
     # rehearsal knobs (not used by the driver): several ranks on one card over gloo
     if "R4X16_FORCE_DEVICE" in os.environ:
         local = int(os.environ["R4X16_FORCE_DEVICE"])
-    elif os.environ.get("R4X16_OVERSUBSCRIBE") == "1" and torch.cuda.device_count() and local >= torch.cuda.device_count():
-        local %= torch.cuda.device_count()      # a launcher's ranks on fewer cards than ranks (rehearsal)
-        os.environ.setdefault("R4X16_DIST_BACKEND", "gloo")
+    elif os.environ.get("R4X16_OVERSUBSCRIBE") == "1" and 0 < torch.cuda.device_count() < world:
+        local %= torch.cuda.device_count()      # a launcher's ranks on fewer cards than ranks (rehearsal): every rank
+        os.environ.setdefault("R4X16_DIST_BACKEND", "gloo")     # takes gloo, RCCL cannot put two ranks on one card
     backend = os.environ.get("R4X16_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
