@@ -404,14 +404,17 @@ static rans4x16_hip_ctx *thread_ctx()
 // ---------------------------------------------------------------------------------------------
 // The combiner behind the single-block entry points.  A CRAM reader / writer calls rans_compress_to_4x16 or
 // rans_uncompress_to_4x16 once per block from a pool of host threads.  One block is four chains: a GPU
-// call for it costs its chain latency (25-50 ms for 1 MiB) whatever else the card does, and thirty-two threads each
-// driving their own copies and launches mostly wait for the runtime's locks (measured: 278 ms per call).  So calls
-// that arrive together are served together: a caller queues its block and sleeps; a worker thread takes everything
-// queued for its direction (after a short gathering window once the first request is in), runs ONE host batch on
-// its own context and wakes each caller with its own result.  Two workers per direction, so that the next batch is
-// gathered and copied in while the previous one computes.
-//   R4X16_COMBINE=0           calls go straight to a per-thread context, as before
-//   R4X16_COMBINE_WINDOW_US   gathering window (default 200)      R4X16_COMBINE_MAX  blocks per batch (default 256)
+// call for it costs its chain latency whatever else the card does, and thirty-two threads each driving their own
+// copies and launches mostly wait for the runtime's locks (measured: 278 ms per call).  So calls that arrive together
+// are served together: a caller queues its block and sleeps; ONE worker thread per direction takes what is queued
+// (after a short, adaptive gathering window, see `window_us` below), runs one host batch on its own context and wakes
+// each caller with its own result.  Callers stay independent: a batch that fails as a whole (staging refused, out of
+// memory, a runtime error) is re-run block by block, so one hostile or oversized request cannot fail its neighbours;
+// a batch gathers at most R4X16_COMBINE_MAX_MB of buffers; a worker that cannot start marks its direction dead and
+// callers fall back to their own per-thread context.
+//   R4X16_COMBINE=0           calls go straight to a per-thread context
+//   R4X16_COMBINE_WINDOW_US   a fixed gathering window instead of the adaptive one
+//   R4X16_COMBINE_MAX         blocks per batch (default 256)      R4X16_COMBINE_MAX_MB  buffer bytes per batch (default 2048)
 // ---------------------------------------------------------------------------------------------
 #include <condition_variable>
 #include <deque>
@@ -436,13 +439,25 @@ struct Combiner {
     // per round instead of two groups that alternate, each waiting for the other's (two workers with a fixed 200 us
     // window: 32 threads x 1 MiB decoded at 205-410 MB/s depending on how the groups fell; this way: see INTEGRATION 1).
     long window_us = -1, max_batch = 256, workers = 1;
+    size_t max_bytes = (size_t)2048 << 20;     // input + output capacity gathered into one batch
     long last_us[2] = {4000, 4000};
+    bool dead[2] = {false, false};             // the direction's worker could not start: callers use their own context
+
+    static void finish(CombReq *r, int rc, unsigned int result) { r->rc = rc; r->result = result; r->done = true; }
 
     void worker(int dir)
     {
-        if (hipSetDevice(device) != hipSuccess) return;
-        rans4x16_hip_ctx *c = rans4x16_hip_create(device);
+        rans4x16_hip_ctx *c = hipSetDevice(device) == hipSuccess ? rans4x16_hip_create(device) : nullptr;
         std::unique_lock<std::mutex> lk(mu);
+        if (!c) {
+            // nobody may wait for a worker that does not exist: hand back what is queued (rc -2 = "use your own
+            // context") and refuse later submissions the same way
+            dead[dir] = true;
+            for (CombReq *r : q[dir]) finish(r, -2, 0u);
+            q[dir].clear();
+            cv_done.notify_all();
+            return;
+        }
         for (;;) {
             cv_work.wait(lk, [&] { return stop || !q[dir].empty(); });
             if (stop) break;
@@ -453,43 +468,62 @@ struct Combiner {
                 if (stop) break;
             }
             std::vector<CombReq *> batch;
-            while (!q[dir].empty() && (long)batch.size() < max_batch) { batch.push_back(q[dir].front()); q[dir].pop_front(); }
+            size_t bytes = 0;
+            while (!q[dir].empty() && (long)batch.size() < max_batch) {
+                CombReq *r = q[dir].front();
+                const size_t need = (size_t)r->in_size + (size_t)r->cap;
+                if (!batch.empty() && bytes + need > max_bytes) break;          // the rest forms the next batch
+                bytes += need;
+                batch.push_back(r);
+                q[dir].pop_front();
+            }
             lk.unlock();
             const auto t0 = std::chrono::steady_clock::now();
             const int n = (int)batch.size();
             std::vector<const unsigned char *> in(n);
             std::vector<unsigned char *> out(n);
             std::vector<unsigned int> isz(n), osz(n);
-            std::vector<int> ord(n), st(n, 0);
+            std::vector<int> ord(n), st(n, 0), rcs(n, 0);
             for (int i = 0; i < n; i++) { in[i] = batch[i]->in; out[i] = batch[i]->out; isz[i] = batch[i]->in_size; osz[i] = batch[i]->cap; ord[i] = batch[i]->order; }
-            const int rc = c ? r4x16_run_host_batch(c, n, dir == 1, in.data(), isz.data(), out.data(), osz.data(), dir == 0 ? ord.data() : nullptr, st.data()) : -1;
-            if (c) r4x16_trim(c, (size_t)4 << 30);
+            const int rc = r4x16_run_host_batch(c, n, dir == 1, in.data(), isz.data(), out.data(), osz.data(), dir == 0 ? ord.data() : nullptr, st.data());
+            if (rc < 0 && n > 1) {
+                // The batch failed as a whole (staging refused for one hostile size field, out of memory, a runtime
+                // error): the callers are unrelated, so each block gets its own one-block batch and its own verdict.
+                for (int i = 0; i < n; i++) {
+                    osz[i] = batch[i]->cap;
+                    st[i] = 0;
+                    rcs[i] = r4x16_run_host_batch(c, 1, dir == 1, &in[i], &isz[i], &out[i], &osz[i], dir == 0 ? &ord[i] : nullptr, &st[i]);
+                }
+            } else
+                for (int i = 0; i < n; i++) rcs[i] = rc;
+            r4x16_trim(c, (size_t)4 << 30);
             const long took = (long)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
             lk.lock();
             last_us[dir] = took;
-            for (int i = 0; i < n; i++) {
-                batch[i]->rc = rc < 0 ? -1 : (st[i] != 0 ? 1 : 0);
-                batch[i]->result = rc < 0 ? 0u : osz[i];
-                batch[i]->done = true;
-            }
+            for (int i = 0; i < n; i++) finish(batch[i], rcs[i] < 0 ? -1 : (st[i] != 0 ? 1 : 0), rcs[i] < 0 ? 0u : osz[i]);
             cv_done.notify_all();
         }
         lk.unlock();
         rans4x16_hip_destroy(c);
     }
+    // 0 ok, 1 block failed, -1 call failed, -2 no worker for this direction (the caller uses its own context)
     int submit(CombReq &r, int dir)
     {
         std::unique_lock<std::mutex> lk(mu);
         if (!started) {
             started = true;
-            const char *w = getenv("R4X16_COMBINE_WINDOW_US"), *m = getenv("R4X16_COMBINE_MAX"), *k = getenv("R4X16_COMBINE_WORKERS");
+            const char *w = getenv("R4X16_COMBINE_WINDOW_US"), *m = getenv("R4X16_COMBINE_MAX"), *k = getenv("R4X16_COMBINE_WORKERS"),
+                       *mb = getenv("R4X16_COMBINE_MAX_MB");
             if (w && *w) window_us = atol(w);                   // a fixed window instead of the adaptive one
             if (m && *m && atol(m) > 0) max_batch = atol(m);
             if (k && *k && atol(k) > 0 && atol(k) <= 4) workers = atol(k);
+            if (mb && *mb && atol(mb) > 0) max_bytes = (size_t)atol(mb) << 20;
             // (detached, and the combiner itself is never destroyed: tearing GPU contexts down from static destructors
-            //  at process exit races the runtime's own shutdown)
+            //  at process exit races the runtime's own shutdown.  After fork() the child has no workers and no usable
+            //  runtime either - HIP does not survive a fork - so nothing is done about that case.)
             for (int d = 0; d < 2; d++) for (long j = 0; j < workers; j++) std::thread([this, d] { worker(d); }).detach();
         }
+        if (dead[dir]) return -2;
         q[dir].push_back(&r);
         cv_work.notify_all();
         cv_done.wait(lk, [&] { return r.done; });
@@ -516,8 +550,10 @@ static int single_block(bool decode, const unsigned char *in, unsigned int in_si
         CombReq r;
         r.in = in; r.in_size = in_size; r.out = out; r.cap = *out_size; r.order = order;
         const int rc = cb->submit(r, decode ? 1 : 0);
-        *out_size = r.result;
-        return rc;
+        if (rc != -2) {
+            *out_size = r.result;
+            return rc;
+        }
     }
     rans4x16_hip_ctx *c = thread_ctx();
     if (!c) return -1;

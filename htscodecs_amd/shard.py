@@ -41,7 +41,8 @@ def init(backend, device_id=None):
         return None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    kw = {}
+    import datetime
+    kw = {"timeout": datetime.timedelta(seconds=int(os.environ.get("R4X16_DIST_TIMEOUT_S", 600)))}   # a dead peer ends the job
     if backend == "nccl" and device_id is not None:
         kw["device_id"] = device_id
     dist.init_process_group(backend, rank=rank, world_size=world, **kw)

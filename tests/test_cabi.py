@@ -75,3 +75,59 @@ def test_product_does_not_reference_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
                 text = open(os.path.join(dirpath, fn), errors="ignore").read()
                 assert "liboracle" not in text and "orc_" not in text and "cpu_libs" not in text, fn
+
+
+REF = "/root/reference"
+FIVE = {"rans_compress_bound_4x16", "rans_compress_to_4x16", "rans_compress_4x16",
+        "rans_uncompress_to_4x16", "rans_uncompress_4x16"}
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+def test_reference_drivers_link_unchanged_against_the_library(tmp_path):
+    """The drop-in claim, kept honest: the reference's own CLI / benchmark driver and its libFuzzer harness are compiled
+    from where they lie, UNCHANGED, and linked against librans4x16_hip.so instead of the reference's objects.
+    Call sites: tests/rANS_static4x16pr_test.c:155,170,193,206,236,242,270,292; tests/rANS_static4x16pr_fuzz.c:71.
+    The harness #includes the reference's .c file by name (fuzz.c:67); an empty file of that name first on the include
+    path makes it take the five symbols from the library like any other caller.  Without a GPU the driver must fail
+    cleanly (the library has no CPU path)."""
+    import subprocess
+    libdir = os.path.join(ROOT, "htscodecs_amd")
+    inc = tmp_path / "inc"
+    (inc / "htscodecs").mkdir(parents=True)
+    (inc / "config.h").write_text("")
+    (inc / "htscodecs" / "rANS_static4x16pr.c").write_text("/* the library under test provides these symbols */\n")
+    (tmp_path / "fuzz_main.c").write_text(
+        "#include <stdint.h>\n#include <stddef.h>\nint LLVMFuzzerTestOneInput(uint8_t *, size_t);\n"
+        "int main(void) { uint8_t b[4] = {0, 1, 2, 3}; return LLVMFuzzerTestOneInput(b, sizeof b); }\n")
+    common = ["gcc", "-O1", "-I", str(inc), "-I", REF, "-I", os.path.join(REF, "htscodecs")]
+    link = ["-L", libdir, "-lrans4x16_hip", "-Wl,-rpath," + libdir, "-lm", "-lpthread"]
+    exe = {}
+    for name, srcs in (("driver", [os.path.join(REF, "tests", "rANS_static4x16pr_test.c")]),
+                       ("fuzz", [os.path.join(REF, "tests", "rANS_static4x16pr_fuzz.c"), str(tmp_path / "fuzz_main.c")])):
+        objs = []
+        for src in srcs:
+            obj = str(tmp_path / (name + "_" + os.path.basename(src) + ".o"))
+            r = subprocess.run(common + ["-c", src, "-o", obj], capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            objs.append(obj)
+        und = subprocess.run(["nm", "-u"] + objs, capture_output=True, text=True, check=True).stdout
+        und = {ln.split()[-1].split("@")[0] for ln in und.splitlines() if ln.strip() and not ln.endswith(":")}
+        codec = {s for s in und if "rans" in s.lower() or "hts" in s.lower()}
+        assert codec and codec <= FIVE, codec                       # nothing of the codec but the five entry points
+        exe[name] = str(tmp_path / name)
+        r = subprocess.run(["gcc", "-o", exe[name]] + objs + link, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        # every one of them is bound to OUR library at run time
+        dyn = subprocess.run(["nm", "-D", "--undefined-only", exe[name]], capture_output=True, text=True, check=True).stdout
+        assert codec <= {ln.split()[-1].split("@")[0] for ln in dyn.splitlines() if ln.strip()}
+        ldd = subprocess.run(["ldd", exe[name]], capture_output=True, text=True, check=True).stdout
+        assert "librans4x16_hip.so" in ldd and libdir in ldd, ldd
+    import torch
+    if not torch.cuda.is_available():
+        # decode mode checks the NULL it gets (test.c:270-272: exit(1)); the stream-compress loop does not (:292-296)
+        stream = b"\x20\x05hello"                                   # X_CAT block of five bytes
+        src = tmp_path / "in.r4x16"
+        src.write_bytes(len(stream).to_bytes(4, "little") + stream)
+        r = subprocess.run([exe["driver"], "-d", str(src), str(tmp_path / "out")], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1, (r.returncode, r.stderr)           # fails the way the driver fails on NULL, no crash
+        assert "no CPU path" in r.stderr

@@ -165,10 +165,17 @@ def test_device_resident_batch(H, oracle):
 
 
 def test_full_size_blocks_roundtrip(H, oracle):
-    """1 MiB blocks (BASELINE.json size): sizes must equal the reference's published sizes and the
-    round trip must be the identity; a sample of blocks is compared byte-for-byte with the oracle."""
+    """1 MiB blocks (BASELINE.json size): sizes must equal the reference's published sizes (order 193 =
+    O1|PACK|RLE: 67,051 / 216,606 for q4 / q8), block 0 must match the md5 the real reference produced
+    (tests/golden/edge.json), EVERY block is compared byte-for-byte with the oracle, and the round trip must be
+    the identity."""
+    import hashlib
     want = {("q4", 0): 80768, ("q8", 0): 236614, ("q40+dir", 0): 526965,
-            ("q4", 1): 74990, ("q8", 1): 224009, ("q40+dir", 1): 507704}
+            ("q4", 1): 74990, ("q8", 1): 224009, ("q40+dir", 1): 507704,
+            ("q4", 193): 67051, ("q8", 193): 216606, ("q40+dir", 193): 507704}
+    with open(os.path.join(GOLD, "edge.json")) as f:
+        md5 = {(c["in"][1], c["order"]): (c["md5"], c["len"]) for c in json.load(f)["cases"]
+               if c["in"][0] == "tile" and c["n"] == 1 << 20 and c["in"][3:] == [0, 0]}
     datas, orders = [], []
     for (name, order) in want:
         for blk in range(4):
@@ -178,7 +185,9 @@ def test_full_size_blocks_roundtrip(H, oracle):
     assert all(s == 0 for s in st), st
     for k, (name, order) in enumerate(want):
         assert len(enc[4 * k]) == want[(name, order)], (name, order, len(enc[4 * k]))
-        assert enc[4 * k + 1] == oracle.compress(datas[4 * k + 1], order)
+        assert (hashlib.md5(enc[4 * k]).hexdigest(), len(enc[4 * k])) == md5[(name, order)], (name, order)
+        for blk in range(4):
+            assert enc[4 * k + blk] == oracle.compress(datas[4 * k + blk], order), (name, order, blk)
     dec, st = H.uncompress_batch(enc, [len(d) for d in datas])
     assert all(s == 0 for s in st), st
     assert all(a == b for a, b in zip(dec, datas))
