@@ -280,6 +280,8 @@ static size_t dec_ws_layout(u8 *base, size_t nblk, u64 tmp_stride, u64 meta_stri
     w->cls = cv.take<u32>(2 * nblk);
     w->cls_list = cv.take<u32>(2 * nblk);
     w->cls_count = cv.take<u32>(3 * CLS_MAX);
+    w->direct_budget = 0;
+    w->pad = 0;
     return align_up(cv.off, 256);
 }
 
@@ -330,6 +332,7 @@ extern "C" int rans4x16_hip_uncompress_dev(rans4x16_hip_ctx *c, int n,
 
     for (size_t base = 0; base < (size_t)n; base += chunk) {
         const int nb = (int)((size_t)n - base < chunk ? (size_t)n - base : chunk);
+        w.direct_budget = r4x16_dec_direct_budget(nb);       // few streams: LDS to spare, the short-step rows (r4x16_common.h)
         r4x16_launch_dec_front(&a, &w, (int)base, nb, s);
         TimedLaunch t;
         if (c->timing) time_begin(c, 1, s, t);

@@ -142,6 +142,29 @@ static inline __host__ __device__ u32 pk_root_bytes(u32 n) { return n > PK_MAX_N
 static inline __host__ __device__ u32 pk_row_bytes(u32 n) { return pk_root_bytes(n) + 4u + 16u * pk_groups(n) - (n % 12u ? 4u : 0u); }
 static inline __host__ __device__ u32 pk_img_bytes(u32 n) { return img_alpha_bytes(n) + n * pk_row_bytes(n); }
 
+// ---------------------------------------------------------------------------------------------
+// Direct rows ("level 6"): the short-step route for batches that leave LDS to spare.  The rows above trade
+// instructions for LDS bytes (a search over cumulative frequencies: ~35 vector instructions per symbol) because resident
+// streams are the throughput of a FULL chip; a batch below one round of resident streams has the LDS of the idle
+// slots to spend instead, and then the reference's own shape (ssym[ctx][m] + fb[ctx][sym], rANS_static4x16pr.c:538-549,
+// :985-995) is the faster step - one byte read for the symbol, one read for (start, freq), no search:
+//
+//   per context a block of  fb[n + 1] (u32)  then  tab[T] (u8),  T = 1 << (look - 1):
+//     fb[r]  = entry of the r-th symbol of this row that HAS a frequency:  idx | (freq - 1) << 8 | start << 20
+//              (compact symbol index, 8 bits; 12 bits each for freq - 1 and start: any table of 10 or 12 bits);
+//              fb[nnz] = a copy of fb[nnz - 1]
+//     tab[j] = rank r of the symbol that owns slot 2j.  Slot 2j + 1 belongs to the same symbol or to the next one
+//              with a frequency, which then STARTS there: one 8-byte read brings fb[r], fb[r + 1] and
+//              "m >= start of fb[r + 1]" picks (the copy after the last entry makes the test harmless there).
+//   Half-resolution tab: 512 bytes per context for 10-bit tables - a 46-symbol order-1 table takes 32 KB, four
+//   streams per CU, 1,024 per chip, against 55 KB with the reference's full-resolution ssym.
+// An empty row (context without a table) is one entry owning every slot with freq = 1 << look: the state is left as
+// it is and the stream is failed through the ROW_EMPTY flag of alpha[], as with the other row kinds.
+// ---------------------------------------------------------------------------------------------
+static inline __host__ __device__ u32 dir_fb_bytes(u32 n) { return 4u * (n + 1u); }
+static inline __host__ __device__ u32 dir_blk_bytes(u32 n, u32 look) { return dir_fb_bytes(n) + (1u << (look - 1u)); }
+static inline __host__ __device__ u32 dir_img_bytes(u32 n, u32 rows, u32 look) { return img_alpha_bytes(n) + rows * dir_blk_bytes(n, look); }
+
 #define IMG_O0_BYTES  1344u                       // 256 symbols, one row
 #define IMG_MAX_BYTES (512u + 256u * 824u)        // 256 symbols, 256 rows
 
@@ -159,10 +182,13 @@ struct DecItem {
     u32 active;      // 0 = nothing to do (failed block, CAT, empty)
     u32 blk;         // owning block (errors are reported there)
     u32 nsym;        // compact alphabet size n (decides the tree depth and the row size)
-    u32 packed;      // 1: packed 10-bit rows (level 1), 0: u16 rows of img_levels(nsym) levels
+    u32 packed;      // 0: u16 rows of img_levels(nsym) levels, 1: packed 10-bit rows (level 1 / 5), 2: direct rows (level 6)
     u32 pad;
 };
-static inline __host__ __device__ u32 item_levels(u32 nsym, u32 packed) { return packed ? (nsym > PK_MAX_NSYM ? 5u : 1u) : img_levels(nsym); }
+static inline __host__ __device__ u32 item_levels(u32 nsym, u32 packed)
+{
+    return packed == 2u ? 6u : packed ? (nsym > PK_MAX_NSYM ? 5u : 1u) : img_levels(nsym);
+}
 
 // Per-block record of the decode pipeline.
 struct DecDesc {
@@ -256,7 +282,7 @@ struct EncDesc {
 #define DEC_IMG_SLOT   (IMG_MAX_BYTES + 2u * IMG_O0_BYTES)   // payload image, nested-table image, RLE-meta image
 #define TAB_BYTES      198656u                          // >= 1 + 257*257*3 (assert at rANS_static4x16pr.c:784)
 
-#define CLS_MAX  48u
+#define CLS_MAX  64u
 #define CLS_NONE 0xffffffffu
 // An order-1 block whose table is itself an order-0 stream (rANS_static4x16pr.c:944-955): k_dec_front<0> hands that
 // stream to the chain kernel as an item of its own and leaves what k_dec_front<1> needs to carry on from the decoded
@@ -277,6 +303,8 @@ struct DecWs {
     u32 *cls;          // [2*nblk]  class of each item (CLS_NONE: nothing to run)   (the nested tables' pass uses the first nblk)
     u32 *cls_list;     // [2*nblk]  item indices, grouped by class
     u32 *cls_count;    // [3][CLS_MAX]  per class: number of items, first position in cls_list, fill cursor
+    u32 direct_budget; // LDS bytes a stream of this batch may take for direct rows (0: never); set per chunk by the host
+    u32 pad;
 };
 
 

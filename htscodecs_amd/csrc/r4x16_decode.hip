@@ -177,6 +177,22 @@ __device__ __forceinline__ u32 lookup_step_pk(u32 row, u32x2 rootv, u32x2 rootw,
     return first + 12u * g + 3u * q + 2u - rneg;
 }
 
+// One lookup + state update on a direct block (r4x16_common.h, "level 6"): `blk` is the LDS address of the context's
+// block, `fbb` the bytes of its fb[] part.  One byte read for the rank of the owner of the even slot, one 8-byte read
+// for that symbol's entry and the next one's, and "the next one starts at or below m" picks.  Returns the entry
+// (compact symbol index in its low byte); x becomes freq * (x >> look) + m - start.
+__device__ __forceinline__ u32 lookup_step_dir(u32 blk, u32 fbb, u32 look, u32 mask, u32 &x)
+{
+    const u32 j = __builtin_amdgcn_ubfe(x, 1u, look - 1u);
+    const u32 rk = *(LAS const volatile u8 *)(unsigned long)(blk + fbb + j);
+    const u32 m = x & mask, xs = x >> look;
+    const u32 mhi = (m << 20) | 0xfffffu;
+    const u32x2 e = *(LAS const volatile u32x2_a4 *)(unsigned long)(blk + 4u * rk);
+    const u32 E = e.y <= mhi ? e.y : e.x;
+    x = __umul24((E >> 8) & 0xfffu, xs) + (xs + m - (E >> 20));      // freq <= 4096, x >> look < 2^22: exact mod 2^32
+    return E;
+}
+
 // ---------------------------------------------------------------------------------------------
 // The chain decoder, general form: image and words read straight from global memory.  Used for
 // the small nested streams inside k_dec_front and for images too large for LDS.
@@ -271,7 +287,10 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     const u32 k = lane & 3;
     const u32 mask = (1u << look) - 1;
     constexpr bool PKD = LV == 1 || LV == 5, WIDE = LV == 5;       // packed rows (r4x16_common.h), with the 16-byte root
-    const u32 rows = lds_addr(img_lds) + img_alpha_bytes(nsym), roww = PKD ? pk_row_bytes(nsym) : img_row_bytes(nsym);
+    constexpr bool DIR = LV == 6;                                  // direct blocks
+    const u32 rows = lds_addr(img_lds) + img_alpha_bytes(nsym),
+              roww = DIR ? dir_blk_bytes(nsym, look) : PKD ? pk_row_bytes(nsym) : img_row_bytes(nsym);
+    const u32 fbb = dir_fb_bytes(nsym);
     const u32 nwords = words_len >> 1;
     const u32 below = (1u << k) - 1u;                      // quad lanes below this one
     u32 count;
@@ -315,7 +334,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     u32 row = rows, cursor = 0, bad = 0, t = 0;
     // root separators of `row`, read as soon as the row is known (one step ahead of their use,
     // so that this LDS round trip runs beside the renormalisation instead of after it)
-    u32x2 root = LV == 1 ? u32x2{img0.ld32(row), 0u} : img0.ld64(row);
+    u32x2 root = DIR ? u32x2{0u, 0u} : LV == 1 ? u32x2{img0.ld32(row), 0u} : img0.ld64(row);
     u32x2 root2 = WIDE ? img0.ld64(row + 8) : u32x2{0u, 0u};
     u32 acc = 0;                                          // order-1: the last (up to) 4 decoded bytes
     u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;                   // order-1: completed dwords not yet stored (a3 newest)
@@ -349,7 +368,10 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             const bool speculate = ORDER == 1 && LV == 2;
             u32 s, rown1 = 0;
             u32x2 rootn1 = {0u, 0u}, rootn2 = {0u, 0u};
-            if (PKD) {
+            if (DIR) {
+                s = lookup_step_dir(row, fbb, look, mask, xn) & 0xffu;
+                if (ORDER == 1) asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(rown1) : "v"(s), "v"(roww), "v"(rows));
+            } else if (PKD) {
                 s = lookup_step_pk<WIDE>(row, root, root2, hdr >> PK_FIRST_SHIFT, xn);
                 // the next row's root: requested as soon as the symbol is known, used at the top of the next step
                 asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(rown1) : "v"(s), "v"(roww), "v"(rows));   // (the compiler's own choice is a 64-bit multiply-add)
@@ -359,7 +381,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
                 } else
                     rootn1.x = *(LAS const volatile u32 *)(unsigned long)rown1;
             } else {
-                s = lookup_step<(PKD ? 2 : LV)>(img0, row, look, mask, xn, LV == 2 ? &root : nullptr, speculate ? &spec : nullptr);
+                s = lookup_step<((PKD || DIR) ? 2 : LV)>(img0, row, look, mask, xn, LV == 2 ? &root : nullptr, speculate ? &spec : nullptr);
             }
             const u32 hn = img.ld16(2 * s);               // byte value | ROW_EMPTY of the new context
             u32 byte0 = 0;
@@ -386,7 +408,9 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
                     }
                 }
                 hdr = live ? hn : hdr;
-                if (PKD) {
+                if (DIR) {
+                    row = live ? rown1 : row;
+                } else if (PKD) {
                     row = live ? rown1 : row;
                     root.x = live ? rootn1.x : root.x;
                     if (WIDE) {
@@ -499,6 +523,8 @@ struct FrontShared {
     u8  alpha[256];    // compact index -> byte        (order-1)
     u16 rankof[256];   // compact index -> its rank among the alphabet members that have a row entry, or 0xffff
     u32 Fk[256];       // order-1: frequencies of the row being parsed, by that rank
+    u16 cumnz[258];    // direct rows: starts of the symbols that have a frequency, by rank
+    u32 fbl[257];      // direct rows: their entries, staged for the copy behind the last one
     u32 np;            // number of ranked members
     u32 first;         // packed rows: index of the row's first symbol of non-zero frequency
     // scalars handed from lane 0 to the wave
@@ -625,10 +651,54 @@ __device__ void write_row_pk(u8 *rowp, const FrontShared &S, u32 n, bool empty, 
     }
 }
 
+// Whole wave: one direct block (r4x16_common.h, "level 6") from S.cum: fb[] = the symbols that have a frequency, by
+// rank, tab[j] = rank of the owner of slot 2j.  Callers synchronise before (S.cum complete) and after.
+__device__ void write_row_direct(u8 *blkp, FrontShared &S, u32 n, bool empty, u32 look, u32 lane)
+{
+    u32 *fb = (u32 *)blkp;
+    u32 *tab = (u32 *)(blkp + dir_fb_bytes(n));
+    const u32 T = 1u << (look - 1u);
+    if (empty) {
+        if (lane < 2) fb[lane] = ((1u << look) - 1u) << 8;     // symbol 0 owns every slot with freq = 1 << look: x stays as it is
+        for (u32 j = lane; j < T / 4u; j += WAVE) tab[j] = 0u;
+        return;
+    }
+    u32 nnz = 0;
+    for (u32 c0 = 0; c0 < n; c0 += WAVE) {
+        const u32 c = c0 + lane;
+        const u32 b = c < n ? S.cum[c] : 0u, e = c < n ? S.cum[c + 1] : 0u;
+        const bool nz = e > b;
+        const u64 mk = __ballot(nz);
+        const u32 r = nnz + (u32)__popcll(mk & ((1ull << lane) - 1ull));
+        if (nz) { S.fbl[r] = (b << 20) | ((e - b - 1u) << 8) | c; S.cumnz[r] = (u16)b; }
+        nnz += (u32)__popcll(mk);
+    }
+    __syncthreads();
+    for (u32 r = lane; r <= nnz; r += WAVE) fb[r] = S.fbl[r < nnz ? r : nnz - 1u];     // (a valid row has nnz >= 1: its total is 1 << look)
+    // each lane fills T / 64 consecutive pairs: one binary search for its first slot, then a merge walk
+    const u32 P = T / WAVE;
+    u32 slot = 2u * P * lane;
+    u32 lo = 0, hi = nnz;                                   // cumnz[lo] <= slot < cumnz[hi]  (cumnz[0] = 0, "cumnz[nnz]" = 1 << look)
+    while (hi - lo > 1u) { const u32 mid = (lo + hi) >> 1; if (S.cumnz[mid] <= slot) lo = mid; else hi = mid; }
+    u32 r = lo;
+    u32 nxt = r + 1u < nnz ? S.cumnz[r + 1u] : 0xffffu;
+    for (u32 q = 0; q < P; q += 4u) {
+        u32 w = 0;
+#pragma unroll
+        for (u32 k = 0; k < 4u; k++) {
+            while (nxt <= slot) { r++; nxt = r + 1u < nnz ? S.cumnz[r + 1u] : 0xffffu; }
+            w |= r << (8u * k);
+            slot += 2u;
+        }
+        tab[(P * lane + q) >> 2] = w;
+    }
+}
+
 // Order-0 stream front end: src[pos, pos+len) holds table, states, words.
 // rANS_static4x16pr.c:500-561.  All lanes call; on return S.status / S.R / S.words_pos are set
 // and the single-row image is at `img`.
-__device__ __forceinline__ void o0_front(ByteSrc &src, u32 pos, u32 len, u32 out_sz, u8 *img, FrontShared &S, u32 lane)
+__device__ __forceinline__ void o0_front(ByteSrc &src, u32 pos, u32 len, u32 out_sz, u8 *img, FrontShared &S, u32 lane,
+                                         u32 dir_budget = 0u, u32 *direct = nullptr)
 {
     for (u32 j = lane; j < 256; j += WAVE) { S.present[j] = 0; S.F[j] = 0; }
     __syncthreads();
@@ -674,7 +744,10 @@ __device__ __forceinline__ void o0_front(ByteSrc &src, u32 pos, u32 len, u32 out
     if (S.status == ST_OK) {
         const u32 ns = S.nsym;
         for (u32 j = lane; j < ns; j += WAVE) ((u16 *)img)[j] = S.alpha[j];
-        write_row(img + img_alpha_bytes(ns), S, ns, false, lane);
+        const bool dir = dir_img_bytes(ns, 1u, O0_BITS) + RING_BYTES <= dir_budget;      // (uniform)
+        if (dir) write_row_direct(img + img_alpha_bytes(ns), S, ns, false, O0_BITS, lane);
+        else write_row(img + img_alpha_bytes(ns), S, ns, false, lane);
+        if (direct) *direct = dir ? 1u : 0u;
     }
     __syncthreads();
 }
@@ -753,7 +826,8 @@ __device__ __forceinline__ bool row_parse_wave(WinSrc &win, u32 wlimit, u32 p, u
 // Order-1 frequency tables (:958-998) into the decoder image, then the payload item.  `tsrc` / `tend`: the table bytes -
 // the input itself, or tbuf where the table came as a nested order-0 stream.  One wave.
 __device__ void o1_tables(const u8 *in, ByteSrc &src, const u8 *tbuf, bool compressed, u32 bits, u32 tab_pos, u32 usz, u32 after_table,
-                          u32 pay_pos, u32 pay_len, u32 s1_size, u8 *img, DecDesc *D, DecItem *I0, FrontShared &S, i32 *hst, u32 lane)
+                          u32 pay_pos, u32 pay_len, u32 s1_size, u8 *img, DecDesc *D, DecItem *I0, FrontShared &S, i32 *hst, u32 lane,
+                          u32 dir_budget)
 {
     const u32 look = bits == 12 ? 12 : 10;                             // :1027, :1071
     ByteSrc tsrc(compressed ? tbuf : in);      // tbuf was never read by this CU before the fence above
@@ -780,8 +854,12 @@ __device__ void o1_tables(const u8 *in, ByteSrc &src, const u8 *tbuf, bool compr
 
     const u32 nsym = S.nsym;
     // 10-bit tables of quality-sized alphabets take the packed rows (smaller images: more streams per CU)
-    const bool packed = bits == 10 && nsym >= PK_MIN_NSYM && nsym <= PKW_MAX_NSYM;
-    const u32 stride = packed ? pk_row_bytes(nsym) : img_row_bytes(nsym);
+    // a batch that leaves LDS to spare takes the direct rows (the short step); else 10-bit tables of quality-sized
+    // alphabets take the packed rows (smaller images: more streams per CU)
+    // (table precisions other than 10 and 12 bits - damaged streams only - keep the u16 rows: the entry's 12-bit fields)
+    const bool direct = (bits == 10 || bits == 12) && dir_img_bytes(nsym, nsym, look) + RING_BYTES <= dir_budget;
+    const bool packed = !direct && bits == 10 && nsym >= PK_MIN_NSYM && nsym <= PKW_MAX_NSYM;
+    const u32 stride = direct ? dir_blk_bytes(nsym, look) : packed ? pk_row_bytes(nsym) : img_row_bytes(nsym);
     u8 *rows0 = img + img_alpha_bytes(nsym);
 
     // Every row lists a frequency for each member of F0 (decode_freq_d :327-358): rank them once.
@@ -908,7 +986,9 @@ __device__ void o1_tables(const u8 *in, ByteSrc &src, const u8 *tbuf, bool compr
             __syncthreads();
             if (!S.go) break;
         }
-        if (packed) {
+        if (direct)
+            write_row_direct(rows0 + (u64)ci * stride, S, nsym, S.empty != 0, look, lane);
+        else if (packed) {
             if (lane == 0 && !S.empty) ((u16 *)img)[ci] |= (u16)(S.first << PK_FIRST_SHIFT);
             write_row_pk(rows0 + (u64)ci * stride, S, nsym, S.empty != 0, lane);
         } else
@@ -935,8 +1015,8 @@ __device__ void o1_tables(const u8 *in, ByteSrc &src, const u8 *tbuf, bool compr
             I0->words = (u64)(in + p);
             I0->words_len = end - p;
             I0->out = D->s1; I0->out_sz = s1_size; I0->image = (u64)img;
-            I0->img_bytes = packed ? pk_img_bytes(nsym) : img_bytes(nsym, nsym); I0->nsym = nsym;
-            I0->packed = packed ? 1u : 0u;
+            I0->img_bytes = direct ? dir_img_bytes(nsym, nsym, look) : packed ? pk_img_bytes(nsym) : img_bytes(nsym, nsym); I0->nsym = nsym;
+            I0->packed = direct ? 2u : packed ? 1u : 0u;
             I0->look = look; I0->order = 1;
             I0->active = s1_size != 0;
         }
@@ -975,7 +1055,8 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
         if (!R.pending || D->status != ST_OK) return;
         if (lane == 0) H.status = ST_OK;
         __syncthreads();
-        o1_tables(in, src, tbuf, true, R.bits, 0u, R.usz, R.after_table, R.pay_pos, R.pay_len, R.s1_size, img, D, I0, S, &H.status, lane);
+        o1_tables(in, src, tbuf, true, R.bits, 0u, R.usz, R.after_table, R.pay_pos, R.pay_len, R.s1_size, img, D, I0, S, &H.status, lane,
+                  ws.direct_budget);
         return;
     }
 
@@ -1112,14 +1193,16 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
 
     if (H.order == 0) {
         // ---- order-0 payload ----------------------------------------------------------------
-        o0_front(src, pay_pos, pay_len, s1_size, img, S, lane);
+        __shared__ u32 o0_direct;
+        o0_front(src, pay_pos, pay_len, s1_size, img, S, lane, ws.direct_budget, &o0_direct);
         if (lane == 0) {
             D->status = S.status;
             if (S.status == ST_OK) {
                 I0->words = (u64)(in + S.words_pos);
                 I0->words_len = pay_pos + pay_len - S.words_pos;
                 I0->out = D->s1; I0->out_sz = s1_size; I0->image = (u64)img;
-                I0->img_bytes = img_bytes(S.nsym, 1); I0->nsym = S.nsym;
+                I0->img_bytes = o0_direct ? dir_img_bytes(S.nsym, 1u, O0_BITS) : img_bytes(S.nsym, 1); I0->nsym = S.nsym;
+                I0->packed = o0_direct ? 2u : 0u;
                 I0->look = O0_BITS; I0->order = 0;
                 for (int k = 0; k < 4; k++) I0->R[k] = S.R[k];
                 I0->active = s1_size != 0;
@@ -1182,7 +1265,7 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
         }
         return;
     }
-    o1_tables(in, src, tbuf, false, bits, H.tab_pos, 0u, 0u, pay_pos, pay_len, s1_size, img, D, I0, S, &H.status, lane);
+    o1_tables(in, src, tbuf, false, bits, H.tab_pos, 0u, 0u, pay_pos, pay_len, s1_size, img, D, I0, S, &H.status, lane, ws.direct_budget);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1516,6 +1599,11 @@ static const struct { u32 bytes; int qpw; int lv; } DEC_CLASSES[] = {
     {1296, 16, 3}, {10256, 1, 3}, {12816, 1, 3}, {16656, 1, 3}, {20496, 1, 3}, {25616, 1, 3}, {32016, 1, 3},
     {40976, 1, 3}, {53648, 1, 3}, {64016, 1, 3},
     {22528, 1, 4}, {32768, 1, 4}, {53248, 1, 4}, {81920, 1, 4}, {163840, 1, 4},
+    // direct blocks (level 6; only batches that leave LDS to spare make such images, r4x16_dec_direct_budget): four
+    // workgroups per CU - one wave per SIMD - with as many streams per wave as fit, then one stream per wave
+    {1296, 16, 6}, {2064, 16, 6}, {2576, 15, 6}, {3216, 12, 6}, {4112, 9, 6}, {5136, 7, 6}, {6672, 6, 6}, {8080, 5, 6},
+    {10128, 4, 6}, {13584, 3, 6}, {20368, 2, 6}, {25600, 1, 6}, {32000, 1, 6}, {40960, 1, 6}, {53760, 1, 6}, {81920, 1, 6},
+    {163840, 1, 6},
 };
 // workgroups of `lds_bytes` each that one CU holds at once (1,280-byte LDS granules, 32 wave slots)
 static int resident_per_cu(size_t lds_bytes, int waves_per_wg)
@@ -1641,6 +1729,7 @@ static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitem
         lds_limit((const void *)k_dec_chain<true, 2>, 163840);
         lds_limit((const void *)k_dec_chain<true, 3>, 163840);
         lds_limit((const void *)k_dec_chain<true, 4>, 163840);
+        lds_limit((const void *)k_dec_chain<true, 6>, 163840);
     }
     static const int force_qpw = getenv("R4X16_DEC_QPW") ? atoi(getenv("R4X16_DEC_QPW")) : 0;   // tuning aids
     static const int force_small = getenv("R4X16_DEC_QPW_SMALL") ? atoi(getenv("R4X16_DEC_QPW_SMALL")) : 0;
@@ -1652,9 +1741,11 @@ static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitem
         const size_t ldsb = (size_t)qpw * c.bytes;
         const int grid = r4x16_resident_grid(ldsb, 1, (nitems + qpw - 1) / qpw);
         void (*kern)(const DecItem *, DecDesc *, const u32 *, const u32 *, int, u32) =
-            c.lv == 1 ? k_dec_chain<true, 1> : c.lv == 5 ? k_dec_chain<true, 5> : c.lv == 2 ? k_dec_chain<true, 2> : c.lv == 3 ? k_dec_chain<true, 3> : k_dec_chain<true, 4>;
+            c.lv == 1 ? k_dec_chain<true, 1> : c.lv == 5 ? k_dec_chain<true, 5> : c.lv == 2 ? k_dec_chain<true, 2> : c.lv == 3 ? k_dec_chain<true, 3> :
+            c.lv == 6 ? k_dec_chain<true, 6> : k_dec_chain<true, 4>;
         // (an order-0 image: at most IMG_O0_BYTES; depth 4 only as the lone row of an alphabet beyond 150 symbols)
-        const bool skip = one_row_only && (c.lv == 1 || c.lv == 5 || c.bytes > (c.lv == 4 ? 22528u : IMG_O0_BYTES + RING_BYTES + 128u));
+        const bool skip = (one_row_only && (c.lv == 1 || c.lv == 5 || c.lv == 6 || c.bytes > (c.lv == 4 ? 22528u : IMG_O0_BYTES + RING_BYTES + 128u))) ||
+                          (c.lv == 6 && !ws->direct_budget);      // (no stream of this batch was given direct blocks)
         if (!skip)
             hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), ldsb, s, items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci), qpw, c.bytes);
         ci++;
@@ -1665,6 +1756,22 @@ static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitem
     hipLaunchKernelGGL((k_dec_chain<false, 2>), dim3(grid), dim3(WAVE), 0, s, items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci + 0), 16, 0u);
     hipLaunchKernelGGL((k_dec_chain<false, 3>), dim3(grid), dim3(WAVE), 0, s, items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci + 1), 16, 0u);
     hipLaunchKernelGGL((k_dec_chain<false, 4>), dim3(grid), dim3(WAVE), 0, s, items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci + 2), 16, 0u);
+}
+// LDS bytes a stream may spend on direct blocks (level 6) when `nblk` streams are to be resident at once: the largest
+// direct class that still holds the batch in ONE round of the chip (0: none does - the batch is large enough to be
+// bound by resident streams, which is what the compressed rows are for).
+//   R4X16_DEC_DIRECT=0  never;  =N (N >= 1)  accept up to N rounds of direct streams (default 1)
+extern "C" u32 r4x16_dec_direct_budget(int nblk)
+{
+    const char *ev = getenv("R4X16_DEC_DIRECT");           // (read per call: the tests switch it between calls)
+    const int rounds = ev && *ev ? atoi(ev) : 1;
+    if (rounds <= 0 || nblk <= 0) return 0u;
+    const long cus = cu_count();
+    const long per_cu = (nblk + cus * rounds - 1) / (cus * rounds);
+    u32 best = 0;
+    for (const auto &c : DEC_CLASSES)
+        if (c.lv == 6 && (long)resident_per_cu((size_t)c.qpw * c.bytes, 1) * c.qpw >= per_cu && c.bytes > best) best = c.bytes;
+    return best;
 }
 // Streams of one kind that a CU holds at once in the chain decoder (host arithmetic on the class table above).
 extern "C" int r4x16_dec_residency(u32 nsym, int order, u32 bits, int *streams_per_wave, int *waves_per_cu)

@@ -19,14 +19,21 @@ DEVICE_ORDERS = {0, 1, 16, 17, 32, 33, 64, 65, 128, 129, 192, 193, 0xd1}
 STRIPE_ORDERS = [8, 9, 0x48, 0xc9, (2 << 8) | 9, (3 << 8) | 0xc9, (5 << 8) | 8]
 
 
-@pytest.fixture(scope="module")
-def H():
+# Every test of this module runs twice: with the short-step ("direct") rows that small batches take by default, and with
+# them switched off, so that the compressed rows (u16 search trees, packed 10/11-bit rows) stay covered by the same cases.
+@pytest.fixture(scope="module", params=["short-step", "compressed-rows"])
+def H(request):
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import htscodecs_amd
     htscodecs_amd.load()
-    return htscodecs_amd
+    knobs = ("R4X16_DEC_DIRECT", "R4X16_ENC_DIRECT")
+    for k in knobs:
+        os.environ[k] = "1" if request.param == "short-step" else "0"
+    yield htscodecs_amd
+    for k in knobs:
+        os.environ.pop(k, None)
 
 
 def _fixture(fn):

@@ -16,14 +16,21 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def H():
+# Every test of this module runs twice: with the short-step ("direct") rows that small batches take by default, and with
+# them switched off, so that the compressed rows (u16 search trees, packed 10/11-bit rows) stay covered by the same cases.
+@pytest.fixture(scope="module", params=["short-step", "compressed-rows"])
+def H(request):
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import htscodecs_amd
     htscodecs_amd.load()
-    return htscodecs_amd
+    knobs = ("R4X16_DEC_DIRECT", "R4X16_ENC_DIRECT")
+    for k in knobs:
+        os.environ[k] = "1" if request.param == "short-step" else "0"
+    yield htscodecs_amd
+    for k in knobs:
+        os.environ.pop(k, None)
 
 
 ALL_ORDERS = [0, 1, 64, 65, 128, 129, 192, 193, 8, 9, 0x48, 0xc9, (2 << 8) | 9, 16 | 1, 32]

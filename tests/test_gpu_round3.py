@@ -68,3 +68,64 @@ def test_two_rounds_of_full_size_blocks_byte_compared(H, oracle):
         got = d_comp[b * slot:b * slot + int(csz[b])].cpu().numpy().tobytes()
         assert got == oracle.compress(raw.tobytes(), order), b
     assert int(csz[0]) == 507704                             # the reference's size for this tile
+
+
+def test_direct_rows_walk_several_rounds(H, oracle, monkeypatch):
+    """The short-step ("direct", r4x16_common.h level 6) rows are meant for batches of at most one round of their
+    resident streams; R4X16_DEC_DIRECT=8 lets 2,100 q40 streams (1,024 are resident at four per CU) take them anyway,
+    so that the persistent walk over several rounds is covered for this row kind too: every block round-trips, the
+    streams are the oracle's."""
+    monkeypatch.setenv("R4X16_DEC_DIRECT", "8")
+    monkeypatch.setenv("R4X16_ENC_DIRECT", "8")
+    nblk, bs, order = 2100, 65536, 1
+    bench, d_in, d_comp, csz, slot = _dev_roundtrip(H, "q40+dir", nblk, bs, order)
+    rs = np.random.RandomState(8)
+    for b in sorted(set([0, 1023, 1024, 2047, 2048, nblk - 1] + [int(x) for x in rs.randint(0, nblk, size=40)])):
+        raw = bench.block_bytes("q40+dir", bs, b, 0)
+        got = d_comp[b * slot:b * slot + int(csz[b])].cpu().numpy().tobytes()
+        assert got == oracle.compress(raw.tobytes(), order), b
+
+
+@pytest.mark.parametrize("knob", ["1", "0"])
+def test_small_batches_of_every_shape_both_row_kinds(H, oracle, monkeypatch, knob):
+    """Batches far below one round of resident streams, with the short-step rows (knob 1, the default) and without:
+    1, 3 and 64 blocks of 1 MiB and ragged sizes, q4 / q8 / q40, orders 0, 1, 65, 193, device-resident; the compressed
+    bytes are the oracle's for every block and every block round-trips."""
+    import torch
+    monkeypatch.setenv("R4X16_DEC_DIRECT", knob)
+    monkeypatch.setenv("R4X16_ENC_DIRECT", knob)
+    dc = H.DeviceCodec(0)
+    dev = dc.dev
+    for nblk, sizes in ((1, [1 << 20]), (3, [1 << 20, 777777, 5]), (64, [65536, 40001, 3, 131072])):
+        for name, order in (("q40+dir", 1), ("q40+dir", 0), ("q8", 1), ("q4", 193), ("q8", 65), ("q4", 1)):
+            blocks = [datagen.tile(name, sizes[b % len(sizes)], b) for b in range(nblk)]
+            in_off = np.cumsum([0] + [(len(b) + 255) // 256 * 256 for b in blocks])[:-1].astype(np.int64)
+            in_size = np.array([len(b) for b in blocks], dtype=np.int32)
+            arena = np.zeros(int(in_off[-1]) + ((len(blocks[-1]) + 255) // 256 * 256), dtype=np.uint8)
+            for b, off in zip(blocks, in_off):
+                arena[off:off + len(b)] = b
+            caps = np.array([H.rans_compress_bound_4x16(len(b), order) for b in blocks], dtype=np.int32)
+            out_off = np.cumsum([0] + [(int(c) + 255) // 256 * 256 for c in caps])[:-1].astype(np.int64)
+            t = lambda a: torch.from_numpy(a).to(dev)
+            d_in = t(arena)
+            d_out = torch.zeros(int(out_off[-1]) + int(caps[-1]) + 256, dtype=torch.uint8, device=dev)
+            d_in_off, d_in_size, d_out_off, d_caps = t(in_off), t(in_size), t(out_off), t(caps)
+            d_osz = torch.zeros(nblk, dtype=torch.int32, device=dev)
+            d_st = torch.full((nblk,), -1, dtype=torch.int32, device=dev)
+            dc.compress(d_in, d_in_off, d_in_size, d_out, d_out_off, d_caps, d_osz, d_st, order, int(in_size.max()))
+            torch.cuda.synchronize()
+            assert (d_st == 0).all(), (name, order, d_st.tolist())
+            osz = d_osz.cpu().numpy()
+            comp = d_out.cpu().numpy()
+            for i, b in enumerate(blocks):
+                assert comp[out_off[i]:out_off[i] + osz[i]].tobytes() == oracle.compress(b.tobytes(), order), (name, order, nblk, i)
+            d_dec = torch.zeros_like(d_in)
+            d_dsz = torch.zeros(nblk, dtype=torch.int32, device=dev)
+            d_dst = torch.full((nblk,), -1, dtype=torch.int32, device=dev)
+            dc.uncompress(d_out, d_out_off, d_osz, d_dec, d_in_off, t(in_size.copy()), d_dsz, d_dst, int(osz.max()), int(in_size.max()))
+            torch.cuda.synchronize()
+            assert (d_dst == 0).all(), (name, order, d_dst.tolist())
+            assert (d_dsz.cpu().numpy() == in_size).all()
+            dec = d_dec.cpu().numpy()
+            for b, off in zip(blocks, in_off):
+                assert (dec[off:off + len(b)] == b).all(), (name, order, nblk)
