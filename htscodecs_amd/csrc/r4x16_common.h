@@ -150,17 +150,32 @@ static inline __host__ __device__ u32 pk_img_bytes(u32 n) { return img_alpha_byt
 // :985-995) is the faster step - one byte read for the symbol, one read for (start, freq), no search:
 //
 //   per context a block of  fb[n + 1] (u32)  then  tab[T] (u8),  T = 1 << (look - 1):
-//     fb[r]  = entry of the r-th symbol of this row that HAS a frequency:  idx | (freq - 1) << 8 | start << 20
-//              (compact symbol index, 8 bits; 12 bits each for freq - 1 and start: any table of 10 or 12 bits);
-//              fb[nnz] = a copy of fb[nnz - 1]
+//     fb[r]  = entry of the r-th symbol of this row that HAS a frequency; fb[nnz] = a copy of fb[nnz - 1]
 //     tab[j] = rank r of the symbol that owns slot 2j.  Slot 2j + 1 belongs to the same symbol or to the next one
-//              with a frequency, which then STARTS there: one 8-byte read brings fb[r], fb[r + 1] and
-//              "m >= start of fb[r + 1]" picks (the copy after the last entry makes the test harmless there).
+//              with a frequency, which then STARTS there: one 8-byte read brings fb[r] and fb[r + 1].
+//   Entry, with sh = 32 - look:   start << sh  |  ~F & (2^sh - 1),   F = idx | freq << 7 [| DIR_EMPTY]
+//   (compact symbol index in 7 bits - direct rows serve alphabets of up to 128 symbols -, freq <= 4096 in 13; bit 20
+//   is free when look = 10).  The fields under `start` are stored COMPLEMENTED so that one subtraction from
+//   M = m << sh | 2^sh - 1  (no borrow ever leaves the low part) gives  D = (m - start) << sh | F : the offset inside
+//   the symbol's range and its fields at once.  Entries ascend with `start`, the first one never exceeds M, so
+//   "the last entry that starts at or below m" is the unsigned minimum of the two differences (an entry beyond m
+//   wraps to a huge one; the copy after the last entry ties): two subtractions and a minimum, no compare, no select.
 //   Half-resolution tab: 512 bytes per context for 10-bit tables - a 46-symbol order-1 table takes 32 KB, four
 //   streams per CU, 1,024 per chip, against 55 KB with the reference's full-resolution ssym.
 // An empty row (context without a table) is one entry owning every slot with freq = 1 << look: the state is left as
-// it is and the stream is failed through the ROW_EMPTY flag of alpha[], as with the other row kinds.
+// it is and the stream is failed through DIR_EMPTY (10-bit tables) or the ROW_EMPTY flag of alpha[], as with the other
+// row kinds.
+// Output bytes: alpha[idx] is one more LDS read per symbol - unless the alphabet is AFFINE, byte = idx + c for every
+// symbol that has a frequency anywhere (quality values are a run of consecutive byte values; byte 0, which every
+// order-1 alphabet lists, has none): then four indices are turned into four bytes by one masked add (DecItem.affine).
 // ---------------------------------------------------------------------------------------------
+#define DIR_MAX_NSYM 128u
+#define DIR_EMPTY (1u << 20)
+static inline __host__ __device__ u32 dir_entry(u32 start, u32 freq, u32 idx, u32 look, u32 flags)
+{
+    const u32 sh = 32u - look;
+    return (start << sh) | (~(idx | (freq << 7) | flags) & ((1u << sh) - 1u));
+}
 static inline __host__ __device__ u32 dir_fb_bytes(u32 n) { return 4u * (n + 1u); }
 static inline __host__ __device__ u32 dir_blk_bytes(u32 n, u32 look) { return dir_fb_bytes(n) + (1u << (look - 1u)); }
 static inline __host__ __device__ u32 dir_img_bytes(u32 n, u32 rows, u32 look) { return img_alpha_bytes(n) + rows * dir_blk_bytes(n, look); }
@@ -183,7 +198,7 @@ struct DecItem {
     u32 blk;         // owning block (errors are reported there)
     u32 nsym;        // compact alphabet size n (decides the tree depth and the row size)
     u32 packed;      // 0: u16 rows of img_levels(nsym) levels, 1: packed 10-bit rows (level 1 / 5), 2: direct rows (level 6)
-    u32 pad;
+    u32 affine;      // direct rows: c + 1 when byte = compact index + c for every symbol with a frequency, else 0
 };
 static inline __host__ __device__ u32 item_levels(u32 nsym, u32 packed)
 {

@@ -177,22 +177,6 @@ __device__ __forceinline__ u32 lookup_step_pk(u32 row, u32x2 rootv, u32x2 rootw,
     return first + 12u * g + 3u * q + 2u - rneg;
 }
 
-// One lookup + state update on a direct block (r4x16_common.h, "level 6"): `blk` is the LDS address of the context's
-// block, `fbb` the bytes of its fb[] part.  One byte read for the rank of the owner of the even slot, one 8-byte read
-// for that symbol's entry and the next one's, and "the next one starts at or below m" picks.  Returns the entry
-// (compact symbol index in its low byte); x becomes freq * (x >> look) + m - start.
-__device__ __forceinline__ u32 lookup_step_dir(u32 blk, u32 fbb, u32 look, u32 mask, u32 &x)
-{
-    const u32 j = __builtin_amdgcn_ubfe(x, 1u, look - 1u);
-    const u32 rk = *(LAS const volatile u8 *)(unsigned long)(blk + fbb + j);
-    const u32 m = x & mask, xs = x >> look;
-    const u32 mhi = (m << 20) | 0xfffffu;
-    const u32x2 e = *(LAS const volatile u32x2_a4 *)(unsigned long)(blk + 4u * rk);
-    const u32 E = e.y <= mhi ? e.y : e.x;
-    x = __umul24((E >> 8) & 0xfffu, xs) + (xs + m - (E >> 20));      // freq <= 4096, x >> look < 2^22: exact mod 2^32
-    return E;
-}
-
 // ---------------------------------------------------------------------------------------------
 // The chain decoder, general form: image and words read straight from global memory.  Used for
 // the small nested streams inside k_dec_front and for images too large for LDS.
@@ -287,10 +271,8 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     const u32 k = lane & 3;
     const u32 mask = (1u << look) - 1;
     constexpr bool PKD = LV == 1 || LV == 5, WIDE = LV == 5;       // packed rows (r4x16_common.h), with the 16-byte root
-    constexpr bool DIR = LV == 6;                                  // direct blocks
-    const u32 rows = lds_addr(img_lds) + img_alpha_bytes(nsym),
-              roww = DIR ? dir_blk_bytes(nsym, look) : PKD ? pk_row_bytes(nsym) : img_row_bytes(nsym);
-    const u32 fbb = dir_fb_bytes(nsym);
+    static_assert(LV != 6, "direct blocks have their own loop: chain_decode_dir");
+    const u32 rows = lds_addr(img_lds) + img_alpha_bytes(nsym), roww = PKD ? pk_row_bytes(nsym) : img_row_bytes(nsym);
     const u32 nwords = words_len >> 1;
     const u32 below = (1u << k) - 1u;                      // quad lanes below this one
     u32 count;
@@ -334,7 +316,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     u32 row = rows, cursor = 0, bad = 0, t = 0;
     // root separators of `row`, read as soon as the row is known (one step ahead of their use,
     // so that this LDS round trip runs beside the renormalisation instead of after it)
-    u32x2 root = DIR ? u32x2{0u, 0u} : LV == 1 ? u32x2{img0.ld32(row), 0u} : img0.ld64(row);
+    u32x2 root = LV == 1 ? u32x2{img0.ld32(row), 0u} : img0.ld64(row);
     u32x2 root2 = WIDE ? img0.ld64(row + 8) : u32x2{0u, 0u};
     u32 acc = 0;                                          // order-1: the last (up to) 4 decoded bytes
     u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;                   // order-1: completed dwords not yet stored (a3 newest)
@@ -368,10 +350,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             const bool speculate = ORDER == 1 && LV == 2;
             u32 s, rown1 = 0;
             u32x2 rootn1 = {0u, 0u}, rootn2 = {0u, 0u};
-            if (DIR) {
-                s = lookup_step_dir(row, fbb, look, mask, xn) & 0xffu;
-                if (ORDER == 1) asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(rown1) : "v"(s), "v"(roww), "v"(rows));
-            } else if (PKD) {
+            if (PKD) {
                 s = lookup_step_pk<WIDE>(row, root, root2, hdr >> PK_FIRST_SHIFT, xn);
                 // the next row's root: requested as soon as the symbol is known, used at the top of the next step
                 asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(rown1) : "v"(s), "v"(roww), "v"(rows));   // (the compiler's own choice is a 64-bit multiply-add)
@@ -381,7 +360,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
                 } else
                     rootn1.x = *(LAS const volatile u32 *)(unsigned long)rown1;
             } else {
-                s = lookup_step<((PKD || DIR) ? 2 : LV)>(img0, row, look, mask, xn, LV == 2 ? &root : nullptr, speculate ? &spec : nullptr);
+                s = lookup_step<(PKD ? 2 : LV)>(img0, row, look, mask, xn, LV == 2 ? &root : nullptr, speculate ? &spec : nullptr);
             }
             const u32 hn = img.ld16(2 * s);               // byte value | ROW_EMPTY of the new context
             u32 byte0 = 0;
@@ -408,9 +387,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
                     }
                 }
                 hdr = live ? hn : hdr;
-                if (DIR) {
-                    row = live ? rown1 : row;
-                } else if (PKD) {
+                if (PKD) {
                     row = live ? rown1 : row;
                     root.x = live ? rootn1.x : root.x;
                     if (WIDE) {
@@ -510,6 +487,206 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
         for (u32 j = 0; j < rem; j++) op[j] = (u8)(acc >> (8 * (4 - rem + j)));
     }
     return active ? (bad & ROW_EMPTY) : 0u;        // idle lanes ran on garbage in the fast trips
+}
+
+// ---------------------------------------------------------------------------------------------
+// The chain decoder for direct blocks (r4x16_common.h, "level 6"): the short step.  Same ring, same renormalisation
+// and the same output gathering as chain_decode_lds, but the step is laid out around its two dependent LDS reads -
+// a lone wave issues in order, so whatever does not depend on a read has to stand IN ITS SHADOW, between the read
+// and the first use of its result, or it costs its four cycles on top of the latency:
+//     x -> slot pair -> [read: rank]            shadow: m, x >> look, ring address, ring reads, last step's byte
+//       -> entry address -> [read: two entries]  shadow: the candidate words out of the ring dwords
+//       -> pick, state update, next block       -> renormalise
+// Measured against the same rows inside chain_decode_lds' step (ring reads first): see DESIGN 6.
+// ---------------------------------------------------------------------------------------------
+template <int ORDER, bool AFF>
+__device__ __forceinline__ u32 chain_decode_dir(const u8 *img_lds, u32 nsym, u8 *ring, gcu8 *words, u32 words_len,
+                                                gu8 *out, u32 out_sz, u32 x, u32 look, u32 aff, bool active, u32 lane)
+{
+    const u32 imga = lds_addr(img_lds);
+    const u32 k = lane & 3;
+    const u32 lookm1 = look - 1u;
+    const u32 sh = 32u - look, lowmask = (1u << sh) - 1u;
+    const u32 rows = imga + img_alpha_bytes(nsym), roww = dir_blk_bytes(nsym, look);
+    const u32 fbb = dir_fb_bytes(nsym);
+    const u32 nwords = words_len >> 1;
+    const u32 below = (1u << k) - 1u;
+    const u32 ringa = lds_addr(ring);
+    const u32 c4 = __umul24(aff - 1u, 0x010101u) + ((aff - 1u) << 24);      // AFF: the alphabet's offset in every byte
+    u32 count;
+    gu8 *op;
+    if (ORDER == 0) {
+        count = (out_sz + 3 - k) >> 2;
+        op = out + k;
+    } else {
+        const u32 q = out_sz >> 2;
+        count = q + (k == 3 ? out_sz - 4 * q : 0);
+        op = out + (u64)k * q;
+    }
+    if (!active) count = 0;
+
+    // ---- word ring: as in chain_decode_lds ----------------------------------------------------
+    gcu8 *abase = (gcu8 *)((u64)words & ~15ull);
+    const u32 off0 = (u32)((u64)words & 15ull);
+    const u32 avail = off0 + words_len;
+    const u32 lastc = avail ? (avail - 1u) >> 4 : 0u;
+    const bool loadable = active && avail != 0;
+    auto load_chunk = [&](u32 c) -> u32x4 {
+        u32x4 v = {0, 0, 0, 0};
+        if (loadable) v = *(gcu32x4 *)(abase + 16ull * (c < lastc ? c : lastc));
+        return v;
+    };
+    if (active) {
+        const u32x4 c0 = load_chunk(k), c1 = load_chunk(k + 4), c2 = load_chunk(k + 8);
+        *(u32x4 *)(ring + 16 * k) = c0;
+        *(u32x4 *)(ring + 64 + 16 * k) = c1;
+        *(u32x4 *)(ring + 128 + 16 * k) = c2;
+        if (k == 0) *(u32x2 *)(ring + 256) = c0.xy;
+    }
+    u32x4 pend = load_chunk(12 + k);
+    u32 half = 0;
+    __syncthreads();
+
+    u32 row = rows, cursor = 0, bad = 0, t = 0;
+    // acc gathers one byte per step: the output byte (order 1, !AFF: of the step before) or, AFF, the low byte of D
+    // (compact index + one bit of the frequency, masked off when four of them become four bytes)
+    u32 acc = 0;
+    u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    u32 hdr = 0, hdr_even = 0;                             // !AFF: alpha[] word of the symbol decoded last step;  AFF: D of the last step
+    if (ORDER == 1 && !AFF && count) bad = *(LAS const u16 *)(unsigned long)imga;
+    auto to_bytes = [&](u32 a) -> u32 { return AFF ? (a & 0x7f7f7f7fu) + c4 : a; };
+
+    auto trip = [&](auto fastc) {
+        constexpr bool FAST = decltype(fastc)::value;
+#pragma unroll
+        for (int u = 0; u < TRIP_STEPS; u++) {
+            const u32 T = t + (u32)u;
+            const bool live = FAST ? true : T < count;
+            // (1) the head of the dependent chain: rank of the owner of the even slot
+            const u32 j = __builtin_amdgcn_ubfe(x, 1u, lookm1);
+            const u32 rk = *(LAS const volatile u8 *)(unsigned long)(row + fbb + j);
+            __builtin_amdgcn_sched_barrier(0);
+            // (2) in its shadow: M, x >> look, the ring dwords, last step's byte
+            const u32 M = (x << sh) | lowmask;
+            const u32 xs = x >> look;
+            const u32 cb = off0 + 2 * cursor;
+            const u32 ra = ringa + (cb & 252u);
+            const u32x2 d01 = *(LAS const volatile u32x2_a4 *)(unsigned long)ra;
+            const u32 d0 = d01.x, d1 = d01.y, d2 = *(LAS const volatile u32 *)(unsigned long)(ra + 8u);
+            if (ORDER == 1) {
+                if (!AFF && (u > 0 || t > 0)) {
+                    if (!FAST) bad |= live ? hdr : 0u;
+                    else if (u & 1) bad |= hdr | hdr_even;
+                    else hdr_even = hdr;
+                    acc = (FAST || T <= count) ? __builtin_amdgcn_alignbit(hdr, acc, 8) : acc;
+                }
+                // AFF: acc took the symbol of step T - 1 in that step; either way symbols T-4 .. T-1 are in acc now
+                if ((u & 3) == 0 && T >= 4 && (FAST || T <= count)) {
+                    a0 = a1; a1 = a2; a2 = a3; a3 = to_bytes(acc);
+                    if (u == 0 && (t & 15u) == 0 && active) {
+                        const u32x4 v = {a0, a1, a2, a3};
+                        *(GAS u32x4_unaligned *)op = v;
+                        op += 16;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // (3) the entry of that symbol and of the next one with a frequency
+            const u32x2 e = *(LAS const volatile u32x2_a4 *)(unsigned long)(row + 4u * rk);
+            __builtin_amdgcn_sched_barrier(0);
+            // (4) in its shadow: the four candidate words
+            const u32 wlo = __builtin_amdgcn_alignbyte(d1, d0, cb), whi = __builtin_amdgcn_alignbyte(d2, d1, cb);
+            __builtin_amdgcn_sched_barrier(0);
+            // (5) pick (r4x16_common.h: the smaller difference), state update, next block
+            const u32 Da = M - e.x, Db = M - e.y;
+            const u32 D = Da < Db ? Da : Db;
+            const u32 xn = __umul24(__builtin_amdgcn_ubfe(D, 7u, 13u), xs) + (D >> sh);      // freq <= 4096, x >> look < 2^22: exact mod 2^32
+            const u32 s = D & 127u;
+            u32 rown1 = row;
+            if (ORDER == 1) asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(rown1) : "v"(s), "v"(roww), "v"(rows));
+            u32 byte0 = 0;
+            if (AFF) {
+                if (ORDER == 1) {
+                    if (!FAST) bad |= live ? D : 0u;
+                    else if (u & 1) bad |= D | hdr_even;
+                    else hdr_even = D;
+                    acc = live ? __builtin_amdgcn_alignbit(D, acc, 8) : acc;
+                    row = live ? rown1 : row;
+                } else byte0 = D;
+            } else {
+                const u32 hn = *(LAS const volatile u16 *)(unsigned long)(imga + 2u * s);  // byte | ROW_EMPTY: looked at in the next step
+                if (ORDER == 0) byte0 = hn & 0xffu;
+                else {
+                    hdr = live ? hn : hdr;
+                    row = live ? rown1 : row;
+                }
+            }
+            x = live ? xn : x;
+            // (6) renormalise: chains refill in order 0..3 from the shared cursor (see chain_decode_lds)
+            const bool want = live && x < RANS_LOW;
+            const u32 wm = quad_ballot(want, lane);
+            const u32 pre = __popc(wm & below);
+            const bool take = FAST ? want : (want && cursor + pre < nwords);
+            const u32 w = __builtin_amdgcn_perm(whi, wlo, __umul24(pre, 0x0202u) + 0x0c0c0100u);
+            u32 xr = (x << 16) | w;
+            asm volatile("" : "+v"(xr));
+            x = take ? xr : x;
+            cursor += __popc(wm);
+
+            if (ORDER == 0) {
+                if (FAST) {
+                    acc = __builtin_amdgcn_alignbit(byte0, acc, 8);
+                    if ((u & 3) == 3) {
+                        const u32 ab = to_bytes(acc);
+                        const u32 A0 = quad_bcast0(ab), A1 = quad_bcast1(ab), A2 = quad_bcast2(ab), A3 = quad_bcast3(ab);
+                        const u32 sel = k | ((4u + k) << 8);
+                        const u32 p01 = __builtin_amdgcn_perm(A1, A0, sel), p23 = __builtin_amdgcn_perm(A3, A2, sel);
+                        const u32 dw = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+                        if (active) *(gu32_unaligned *)(out + 4 * (u64)(T - 3u + k)) = dw;
+                    }
+                } else {
+                    if (AFF) byte0 = ((byte0 & 0x7fu) + c4) & 0xffu;
+                    const u32 b1 = quad_bcast1(byte0), b2 = quad_bcast2(byte0), b3 = quad_bcast3(byte0);
+                    const u32 l3 = quad_bcast3(live ? 1u : 0u);
+                    const u32 dw = byte0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+                    if (l3) { if (k == 0 && active) *(gu32_unaligned *)(op + 4 * (u64)T) = dw; }
+                    else if (live) op[4 * (u64)T] = (u8)byte0;
+                }
+            }
+        }
+        t += TRIP_STEPS;
+    };
+    while (wave_any(t < count)) {
+        const bool slow = active && (t + TRIP_STEPS > count || cursor + 4 * TRIP_STEPS > nwords);
+        if (!wave_any(slow)) trip(std::true_type{});
+        else trip(std::false_type{});
+        const u32 nh = (off0 + 2 * cursor) >> 6;
+        if (wave_any(active && nh != half)) {
+            if (active && nh != half) {
+                const u32 slot = ((nh + 2) & 3u) * 64u + 16u * k;
+                *(u32x4 *)(ring + slot) = pend;
+                if (slot == 0) *(u32x2 *)(ring + 256) = pend.xy;
+                pend = load_chunk(4 * (nh + 3) + k);
+                half = nh;
+            }
+            __syncthreads();
+        }
+    }
+    if (ORDER == 1 && count) {
+        // t steps ran (see chain_decode_lds).  !AFF: a chain whose count equals t still has its last byte in hdr.
+        // AFF: acc already holds every symbol decoded (the live ones only), the newest in its top byte.
+        const u32 lastq = count < t - 4 ? count : t - 4;
+        const u32 pushed = lastq >> 2, nd = pushed & 3u;
+        if (!AFF && count == t) acc = __builtin_amdgcn_alignbit(hdr, acc, 8);
+        if (nd == 3) { *(gu32_unaligned *)op = a1; op += 4; }
+        if (nd >= 2) { *(gu32_unaligned *)op = a2; op += 4; }
+        if (nd >= 1) { *(gu32_unaligned *)op = a3; op += 4; }
+        const u32 rem = count - 4 * pushed;                // 0..4, in the top `rem` bytes of acc
+        const u32 accb = to_bytes(acc);
+        for (u32 jj = 0; jj < rem; jj++) op[jj] = (u8)(accb >> (8 * (4 - rem + jj)));
+    }
+    if (!active) return 0u;
+    return AFF ? ((ORDER == 1 && (bad & DIR_EMPTY)) ? 1u : 0u) : (bad & ROW_EMPTY);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -653,24 +830,24 @@ __device__ void write_row_pk(u8 *rowp, const FrontShared &S, u32 n, bool empty, 
 
 // Whole wave: one direct block (r4x16_common.h, "level 6") from S.cum: fb[] = the symbols that have a frequency, by
 // rank, tab[j] = rank of the owner of slot 2j.  Callers synchronise before (S.cum complete) and after.
-__device__ void write_row_direct(u8 *blkp, FrontShared &S, u32 n, bool empty, u32 look, u32 lane)
+__device__ void write_row_direct(u8 *blkp, FrontShared &S, u32 n, bool empty, u32 look, u32 lane, u32 &used)
 {
     u32 *fb = (u32 *)blkp;
     u32 *tab = (u32 *)(blkp + dir_fb_bytes(n));
     const u32 T = 1u << (look - 1u);
     if (empty) {
-        if (lane < 2) fb[lane] = ((1u << look) - 1u) << 8;     // symbol 0 owns every slot with freq = 1 << look: x stays as it is
+        if (lane < 2) fb[lane] = dir_entry(0u, 1u << look, 0u, look, look == 10u ? DIR_EMPTY : 0u);   // x stays as it is
         for (u32 j = lane; j < T / 4u; j += WAVE) tab[j] = 0u;
         return;
     }
     u32 nnz = 0;
-    for (u32 c0 = 0; c0 < n; c0 += WAVE) {
+    for (u32 c0 = 0; c0 < n; c0 += WAVE) {                   // (n <= DIR_MAX_NSYM: two rounds)
         const u32 c = c0 + lane;
         const u32 b = c < n ? S.cum[c] : 0u, e = c < n ? S.cum[c + 1] : 0u;
         const bool nz = e > b;
         const u64 mk = __ballot(nz);
         const u32 r = nnz + (u32)__popcll(mk & ((1ull << lane) - 1ull));
-        if (nz) { S.fbl[r] = (b << 20) | ((e - b - 1u) << 8) | c; S.cumnz[r] = (u16)b; }
+        if (nz) { S.fbl[r] = dir_entry(b, e - b, c, look, 0u); S.cumnz[r] = (u16)b; used |= 1u << (c0 / WAVE); }
         nnz += (u32)__popcll(mk);
     }
     __syncthreads();
@@ -693,12 +870,29 @@ __device__ void write_row_direct(u8 *blkp, FrontShared &S, u32 n, bool empty, u3
         tab[(P * lane + q) >> 2] = w;
     }
 }
+// Whole wave: c + 1 if byte = index + c for every compact symbol marked in `used` (bit i: symbol 64 i + lane), else 0
+__device__ u32 affine_of(const FrontShared &S, u32 n, u32 used, u32 lane)
+{
+    u32 delta[2];
+    bool u[2];
+#pragma unroll
+    for (u32 i = 0; i < 2; i++) {
+        const u32 c = WAVE * i + lane;
+        u[i] = c < n && ((used >> i) & 1u);
+        delta[i] = c < n ? (u32)S.alpha[c] - c : 0u;
+    }
+    const u64 m0 = __ballot(u[0]), m1 = __ballot(u[1]);
+    if (!m0 && !m1) return 0u;
+    const u32 C = m0 ? (u32)__shfl((int)delta[0], __ffsll((unsigned long long)m0) - 1) : (u32)__shfl((int)delta[1], __ffsll((unsigned long long)m1) - 1);
+    const bool bad = (u[0] && delta[0] != C) || (u[1] && delta[1] != C);
+    return __ballot(bad) ? 0u : C + 1u;
+}
 
 // Order-0 stream front end: src[pos, pos+len) holds table, states, words.
 // rANS_static4x16pr.c:500-561.  All lanes call; on return S.status / S.R / S.words_pos are set
 // and the single-row image is at `img`.
 __device__ __forceinline__ void o0_front(ByteSrc &src, u32 pos, u32 len, u32 out_sz, u8 *img, FrontShared &S, u32 lane,
-                                         u32 dir_budget = 0u, u32 *direct = nullptr)
+                                         u32 dir_budget = 0u, u32 *direct = nullptr)      // *direct: 0, or 1 + DecItem.affine
 {
     for (u32 j = lane; j < 256; j += WAVE) { S.present[j] = 0; S.F[j] = 0; }
     __syncthreads();
@@ -744,10 +938,11 @@ __device__ __forceinline__ void o0_front(ByteSrc &src, u32 pos, u32 len, u32 out
     if (S.status == ST_OK) {
         const u32 ns = S.nsym;
         for (u32 j = lane; j < ns; j += WAVE) ((u16 *)img)[j] = S.alpha[j];
-        const bool dir = dir_img_bytes(ns, 1u, O0_BITS) + RING_BYTES <= dir_budget;      // (uniform)
-        if (dir) write_row_direct(img + img_alpha_bytes(ns), S, ns, false, O0_BITS, lane);
+        const bool dir = ns <= DIR_MAX_NSYM && dir_img_bytes(ns, 1u, O0_BITS) + RING_BYTES <= dir_budget;      // (uniform)
+        u32 used = 0;
+        if (dir) write_row_direct(img + img_alpha_bytes(ns), S, ns, false, O0_BITS, lane, used);
         else write_row(img + img_alpha_bytes(ns), S, ns, false, lane);
-        if (direct) *direct = dir ? 1u : 0u;
+        if (direct) *direct = dir ? 1u + affine_of(S, ns, used, lane) : 0u;
     }
     __syncthreads();
 }
@@ -857,7 +1052,8 @@ __device__ void o1_tables(const u8 *in, ByteSrc &src, const u8 *tbuf, bool compr
     // a batch that leaves LDS to spare takes the direct rows (the short step); else 10-bit tables of quality-sized
     // alphabets take the packed rows (smaller images: more streams per CU)
     // (table precisions other than 10 and 12 bits - damaged streams only - keep the u16 rows: the entry's 12-bit fields)
-    const bool direct = (bits == 10 || bits == 12) && dir_img_bytes(nsym, nsym, look) + RING_BYTES <= dir_budget;
+    const bool direct = (bits == 10 || bits == 12) && nsym <= DIR_MAX_NSYM && dir_img_bytes(nsym, nsym, look) + RING_BYTES <= dir_budget;
+    u32 dir_used = 0;                                               // symbols (64 i + lane) that have a frequency in some row
     const bool packed = !direct && bits == 10 && nsym >= PK_MIN_NSYM && nsym <= PKW_MAX_NSYM;
     const u32 stride = direct ? dir_blk_bytes(nsym, look) : packed ? pk_row_bytes(nsym) : img_row_bytes(nsym);
     u8 *rows0 = img + img_alpha_bytes(nsym);
@@ -987,7 +1183,7 @@ __device__ void o1_tables(const u8 *in, ByteSrc &src, const u8 *tbuf, bool compr
             if (!S.go) break;
         }
         if (direct)
-            write_row_direct(rows0 + (u64)ci * stride, S, nsym, S.empty != 0, look, lane);
+            write_row_direct(rows0 + (u64)ci * stride, S, nsym, S.empty != 0, look, lane, dir_used);
         else if (packed) {
             if (lane == 0 && !S.empty) ((u16 *)img)[ci] |= (u16)(S.first << PK_FIRST_SHIFT);
             write_row_pk(rows0 + (u64)ci * stride, S, nsym, S.empty != 0, lane);
@@ -996,6 +1192,8 @@ __device__ void o1_tables(const u8 *in, ByteSrc &src, const u8 *tbuf, bool compr
         __syncthreads();
     }
     if (*hst != ST_OK) { if (lane == 0) D->status = *hst; return; }
+    // (12-bit order-1 entries have no room for the empty-row flag: those streams keep alpha[] and its ROW_EMPTY flags)
+    const u32 affine = direct && look == 10u ? affine_of(S, nsym, dir_used, lane) : 0u;
 
     if (lane == 0) {
         u32 p = compressed ? after_table : S.pos;                    // :1000-1001
@@ -1017,6 +1215,7 @@ __device__ void o1_tables(const u8 *in, ByteSrc &src, const u8 *tbuf, bool compr
             I0->out = D->s1; I0->out_sz = s1_size; I0->image = (u64)img;
             I0->img_bytes = direct ? dir_img_bytes(nsym, nsym, look) : packed ? pk_img_bytes(nsym) : img_bytes(nsym, nsym); I0->nsym = nsym;
             I0->packed = direct ? 2u : packed ? 1u : 0u;
+            I0->affine = affine;
             I0->look = look; I0->order = 1;
             I0->active = s1_size != 0;
         }
@@ -1068,6 +1267,7 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
         I0->active = 0; I1->active = 0; I2->active = 0;
         I0->blk = b; I1->blk = b; I2->blk = b;
         I0->packed = 0; I1->packed = 0; I2->packed = 0;
+        I0->affine = 0; I1->affine = 0; I2->affine = 0;
         ws.resume[b].pending = 0;
         D->status = ST_OK; D->cat_src = 0; D->cat_len = 0; D->osz = 0; D->s1_size = 0;
         D->pack_per = 1; D->rle_meta_len = 0; D->rle_meta = 0;
@@ -1203,6 +1403,7 @@ __global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int b
                 I0->out = D->s1; I0->out_sz = s1_size; I0->image = (u64)img;
                 I0->img_bytes = o0_direct ? dir_img_bytes(S.nsym, 1u, O0_BITS) : img_bytes(S.nsym, 1); I0->nsym = S.nsym;
                 I0->packed = o0_direct ? 2u : 0u;
+                I0->affine = o0_direct ? o0_direct - 1u : 0u;
                 I0->look = O0_BITS; I0->order = 0;
                 for (int k = 0; k < 4; k++) I0->R[k] = S.R[k];
                 I0->active = s1_size != 0;
@@ -1321,9 +1522,22 @@ __global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDes
         const u8 *im = lds + (u64)quad * lds_per_item;
         u8 *ring = lds + (u64)quad * lds_per_item + (lds_per_item - RING_BYTES);
         // order-0 and order-1 streams may share a wave: run the two loops back to back
+        if constexpr (LV == 6) {
+            // (affine alphabets - byte = index + c - skip the alpha[] read per symbol; a wave takes that body only if
+            //  all its streams are affine)
+            const u32 aff = active ? I->affine : 1u;
+            if (!wave_any(aff == 0u)) {
+                bad = chain_decode_dir<1, true>(im, nsym, ring, words, words_len, out, out_sz, x0, look, aff, active && order == 1, lane);
+                bad |= chain_decode_dir<0, true>(im, nsym, ring, words, words_len, out, out_sz, x0, look, aff, active && order == 0, lane);
+            } else {
+                bad = chain_decode_dir<1, false>(im, nsym, ring, words, words_len, out, out_sz, x0, look, 0u, active && order == 1, lane);
+                bad |= chain_decode_dir<0, false>(im, nsym, ring, words, words_len, out, out_sz, x0, look, 0u, active && order == 0, lane);
+            }
+        } else {
         bad = chain_decode_lds<1, LV>(im, nsym, ring, words, words_len, out, out_sz, x0, look, active && order == 1, lane);
         if (LV != 1 && LV != 5)                               // packed rows exist for order-1 streams only
             bad |= chain_decode_lds<0, ((LV == 1 || LV == 5) ? 2 : LV)>(im, nsym, ring, words, words_len, out, out_sz, x0, look, active && order == 0, lane);
+        }
     } else {
         GImg im{(gcu8 *)I->image};                            // (never level 1: packed images always fit a class)
         bad = chain_decode<1, ((LV == 1 || LV == 5) ? 2 : LV)>(im, nsym, words, words_len, out, out_sz, x0, look, active && order == 1, lane);
