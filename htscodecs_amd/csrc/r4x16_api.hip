@@ -198,6 +198,8 @@ static size_t enc_ws_layout(u8 *base, size_t nblk, u64 scratch_stride, u64 xf_st
     w->cls_count = cv.take<u32>(3 * CLS_MAX);
     w->xf_stride = xf_stride;
     w->scratch2_stride = scratch2_stride;
+    w->direct_budget = 0;
+    w->pad = 0;
     return align_up(cv.off, 256);
 }
 
@@ -253,6 +255,7 @@ extern "C" int rans4x16_hip_compress_dev(rans4x16_hip_ctx *c, int n,
 
     for (size_t base = 0; base < (size_t)n; base += chunk) {
         const int nb = (int)((size_t)n - base < chunk ? (size_t)n - base : chunk);
+        w.direct_budget = r4x16_enc_direct_budget(nb);       // few streams: LDS to spare, symbol records (r4x16_common.h)
         r4x16_launch_enc_front(&a, &w, (int)base, nb, s);
         r4x16_launch_enc_tables(&a, &w, (int)base, nb, s);
         TimedLaunch t;

@@ -256,7 +256,7 @@ struct EncItem {
     u32 blk;
     u32 ns;          // symbols per image row (a row is ns+1 u16)
     u32 img_bytes;   // bytes of the image (what must sit in LDS)
-    u32 packed;      // 1: rows are 11-bit bit streams (below), 0: u16 rows
+    u32 packed;      // 0: u16 rows, 1: rows are 11-bit bit streams (below), 2: 16-byte symbol records (further below)
     u32 pad;
 };
 // Packed encoder rows: order-1 streams with 10-bit tables and 20..64 symbols (the quality alphabets).  Row r is a
@@ -268,6 +268,19 @@ struct EncItem {
 #define ENC_PK_MAX_NS 64u
 static inline __host__ __device__ u32 enc_pk_row_dwords(u32 ns) { return (11u * (ns + 1u) + 31u) / 32u; }
 static inline __host__ __device__ u32 enc_pk_img_bytes(u32 ns) { return ENC_IMG_IDX + 4u * ns * enc_pk_row_dwords(ns) + 4u; }
+
+// Symbol records ("kind 2"): the encoder's short-step route for batches that leave LDS to spare - the twin of the
+// decoder's direct rows.  The u16 / packed rows above make the coder derive start, freq, x_max, the reciprocal (one more
+// LDS read) and its shift from two cumulative values per symbol: ~50 instructions per symbol, each four cycles of a
+// lone wave's issue.  With LDS to spend, the image holds what the reference's RansEncSymbolInit (rANS_word.h:190-266)
+// precomputes, one 16-byte record per (context, symbol), read with one ds_read_b128:
+//     { rcp_freq,  x_max = freq << (31 - bits),  bias,  cmpl_freq | rcp_shift << 24 }
+// (freq == 1: rcp_freq = 2^32 - 1, rcp_shift = 0, bias = start + (1 << bits) - 1, as there), and a step is
+//     if (x >= x_max) emit; q = mulhi(x, rcp_freq) >> rcp_shift; x += bias + q * cmpl_freq      (:281-321)
+// with the multiply by cmpl_freq a 24-bit one that ignores the shift in the top byte.  Image: idx_of[256], then
+// rec[R][ns]: 34 KB for a 46-symbol order-1 table (four streams per CU), 4.4 KB for an order-0 one.
+#define ENC_RING_BYTES 144u          // per stream behind its image: the 128-byte ring of emitted words + a dump slot (+ pad)
+static inline __host__ __device__ u32 enc_rec_img_bytes(u32 ns, u32 rows) { return ENC_IMG_IDX + 16u * rows * ns; }
 
 // Per-block record of the encode pipeline.
 struct EncDesc {
@@ -354,6 +367,8 @@ struct EncWs {
     u8 *dump;           // [ENC_DUMP_BYTES]  target of the chain coder's idle output slots (never read)
     u64 xf_stride, scratch2_stride;
     u32 *cls, *cls_list, *cls_count;   // streams grouped by LDS size class (as in DecWs)
+    u32 direct_budget;  // LDS bytes a stream of this batch may take for symbol records (0: never); set per chunk by the host
+    u32 pad;
 };
 #define META_TAB_BYTES 1024u
 #define ENC_F_BYTES    262144u                          // 256 x 256 pair counters (bottom of a block's scratch area)

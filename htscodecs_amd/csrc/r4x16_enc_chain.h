@@ -91,7 +91,7 @@ __device__ __forceinline__ u32 chain_encode(gcu8 *data, u32 n, gcu8 *image, u32 
 // reciprocal table, the emitted words) and touches global memory exactly twice per eight steps,
 // unconditionally and in a fixed order: one 8-byte input load three double-trips ahead and one
 // 16-byte store (a completed half of the ring, or a dump slot nobody reads).
-#define ENC_RING_BYTES 144u          // ring + a 2-byte dump slot for lanes that do not emit (+ pad)
+// (ENC_RING_BYTES, r4x16_common.h: the ring + a 2-byte dump slot for lanes that do not emit, padded)
 #define ENC_LRCP_BYTES 16400u        // RCPTAB_ENTRIES dwords, padded to 16
 struct EncOut {
     u8 *ring;            // LDS

@@ -21,6 +21,16 @@ static const u32 ENC_CLASSES[] = {656, 1296, 2576, 4752, 6416, 12816, 33296, 736
 // packed rows (20..64 symbols, 10-bit tables): 46 symbols need 3,532 bytes -> 45 streams per CU beside the small
 // reciprocal table (3,536 is 80 mod 128: consecutive streams start 20 banks apart)
 static const u32 ENC_PK_CLASSES[] = {1168, 2064, 2832, 3536, 3728, 4752, 6416};
+// symbol records (kind 2, r4x16_enc_chain_rec.hip; only batches that leave LDS to spare make such images): one wave
+// per workgroup, {LDS bytes per stream, streams per wave}; four workgroups per CU, then fewer
+static const struct { u32 bytes; int qpw; } ENC_REC_CLASSES[] = {
+    {1296, 16}, {2064, 16}, {2576, 15}, {3216, 12}, {4112, 9}, {5136, 7}, {6672, 6}, {8080, 5}, {10128, 4}, {13584, 3}, {20368, 2},
+    {25600, 1}, {32000, 1}, {40960, 1}, {53760, 1}, {81920, 1}, {163840, 1},
+};
+#define ENC_REC_NCLS ((u32)(sizeof(ENC_REC_CLASSES) / sizeof(ENC_REC_CLASSES[0])))
+extern "C" void r4x16_enc_chain_rec_lds_limit(int bytes);
+extern "C" void r4x16_enc_chain_rec_launch(int grid, size_t lds, hipStream_t s, EncItem *items, const u32 *safe, u8 *dump,
+                                           const u32 *list, const u32 *count, int qpw, u32 lds_per_item);
 #define ENC_NCLS    ((u32)(sizeof(ENC_CLASSES) / sizeof(ENC_CLASSES[0])))
 #define ENC_PK_NCLS ((u32)(sizeof(ENC_PK_CLASSES) / sizeof(ENC_PK_CLASSES[0])))
 static int enc_class_qpw(u32 bytes, bool pk = false)
@@ -61,6 +71,7 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
         tab.n = 0;
         for (const u32 bytes : ENC_CLASSES) { tab.pk[tab.n] = 0; tab.bytes[tab.n++] = bytes; }
         for (const u32 bytes : ENC_PK_CLASSES) { tab.pk[tab.n] = 1; tab.bytes[tab.n++] = bytes; }
+        for (const auto &c : ENC_REC_CLASSES) { tab.pk[tab.n] = 2; tab.bytes[tab.n++] = c.bytes; }
         r4x16_launch_cls_zero(ws->cls_count, s);
         hipLaunchKernelGGL(k_enc_classify, dim3((nitems + 255) / 256), dim3(256), 0, s, (const EncItem *)ws->items, nitems, tab, ws->cls, ws->cls_count);
         r4x16_launch_cls_group(ws->cls, nitems, ws->cls_count, ws->cls_list, s);
@@ -68,6 +79,7 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
     if (r4x16_first_on_device(4u)) {
         (void)hipFuncSetAttribute((const void *)k_enc_chain<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         r4x16_enc_chain_pk_lds_limit(163840);
+        r4x16_enc_chain_rec_lds_limit(163840);
     }
     u32 ci = 0;
     static const int force_qpw = getenv("R4X16_ENC_QPW") ? atoi(getenv("R4X16_ENC_QPW")) : 0;   // tuning aids
@@ -100,9 +112,36 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
                                ws->items, ws->rcptab, ws->dump, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci), qpw, spw, bytes);
         ci++;
     }
+    for (const auto &c : ENC_REC_CLASSES) {
+        if (ws->direct_budget) {                              // (else no stream of this batch was given records)
+            const size_t ldsb = (size_t)c.qpw * c.bytes;
+            const int grid = r4x16_resident_grid(ldsb, 1, (nitems + c.qpw - 1) / c.qpw);
+            r4x16_enc_chain_rec_launch(grid, ldsb, s, ws->items, ws->rcptab, ws->dump, (const u32 *)ws->cls_list,
+                                       (const u32 *)(ws->cls_count + ci), c.qpw, c.bytes);
+        }
+        ci++;
+    }
     const int grid = (nitems + 15) / 16;
     hipLaunchKernelGGL((k_enc_chain<false, false>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->rcptab, ws->dump,
                        (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci), 16, 16, 0u);
+}
+// LDS bytes a stream may spend on symbol records when `nblk` streams are to be resident at once: the largest record
+// class that still holds the batch in one round of the chip (0: none).  R4X16_ENC_DIRECT=0 never; =N up to N rounds.
+extern "C" u32 r4x16_enc_direct_budget(int nblk)
+{
+    const char *ev = getenv("R4X16_ENC_DIRECT");           // (read per call: the tests switch it between calls)
+    const int rounds = ev && *ev ? atoi(ev) : 1;
+    if (rounds <= 0 || nblk <= 0) return 0u;
+    const long cus = r4x16_cu_count();
+    const long per_cu = (nblk + cus * rounds - 1) / (cus * rounds);
+    u32 best = 0;
+    for (const auto &c : ENC_REC_CLASSES) {
+        const long granules = ((long)c.qpw * c.bytes + 1279) / 1280;      // LDS is allocated in 1,280-byte granules
+        long wgs = 128 / granules;
+        if (wgs > 32) wgs = 32;
+        if (wgs * c.qpw >= per_cu && c.bytes > best) best = c.bytes;
+    }
+    return best;
 }
 extern "C" int r4x16_enc_residency(u32 nsym, int order, int *streams_per_wave, int *waves_per_cu)
 {

@@ -250,7 +250,17 @@ __device__ u32 put_alphabet_mask(u8 *cp, const u64 pm[4])
     return (u32)(cp - start);
 }
 
-__device__ void enc_o0_tables(u32 n, u8 *tab, u8 *image, EncShared &S, u32 lane)
+// One symbol record of the encoder's short-step images (r4x16_common.h, "kind 2"; RansEncSymbolInit, rANS_word.h:190-266).
+// rcptab[f] = ceil(2^(31 + ceil(log2 f)) / f) for f >= 2, the reference's rcp_freq (:252).
+__device__ __forceinline__ u32x4 enc_record(u32 start, u32 f, u32 bits, const u32 *rcptab)
+{
+    if (f == 0) return u32x4{0u, ~0u, 0u, 0u};                       // never coded in this context
+    if (f == 1) return u32x4{~0u, 1u << (31u - bits), start + (1u << bits) - 1u, (1u << bits) - 1u};
+    const u32 rsh = 31u - (u32)__clz((int)(f - 1u));                   // ceil(log2 f) - 1
+    return u32x4{rcptab[f], f << (31u - bits), start, ((1u << bits) - f) | (rsh << 24)};
+}
+
+__device__ void enc_o0_tables(u32 n, u8 *tab, u8 *image, EncShared &S, u32 lane, const u32 *rec_rcptab = nullptr)
 {
     u16 *imgrow = (u16 *)(image + ENC_IMG_IDX);      // cum[0..256]
     for (u32 j = lane; j < 256; j += WAVE) image[j] = (u8)j;       // order-0: symbols index the row directly
@@ -298,6 +308,16 @@ __device__ void enc_o0_tables(u32 n, u8 *tab, u8 *image, EncShared &S, u32 lane)
 #pragma unroll
     for (int c = 0; c < 4; c++) { f[c] = S.F[lane * 4 + c]; sum += f[c]; }
     u32 start = wave_incl_scan(sum, lane) - sum;
+    if (rec_rcptab) {                                       // symbol records instead of the cumulative row
+        u32x4 *rec = (u32x4 *)(image + ENC_IMG_IDX);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            rec[lane * 4 + c] = enc_record(start, f[c], O0_BITS, rec_rcptab);
+            start += f[c];
+        }
+        wsync();
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         imgrow[lane * 4 + c] = (u16)start;
@@ -1182,12 +1202,14 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
     if (lane == 0) H.status = ST_OK;
     wsync();
     if (ST->order == 0) {
-        enc_o0_tables(n, tab, img, S, lane);
+        const bool rec = enc_rec_img_bytes(256u, 1u) + ENC_RING_BYTES <= ws.direct_budget;      // (uniform)
+        enc_o0_tables(n, tab, img, S, lane, rec ? ws.rcptab : nullptr);
         if (lane == 0) {
             D->status = S.status;
             D->tab_len = S.tab_len;
             I0->data = (u64)data; I0->n = n; I0->image = (u64)img; I0->bits = O0_BITS; I0->order = 0;
-            I0->ns = 256; I0->img_bytes = ENC_IMG_IDX + 2u * 257u;
+            I0->ns = 256; I0->img_bytes = rec ? enc_rec_img_bytes(256u, 1u) : ENC_IMG_IDX + 2u * 257u;
+            I0->packed = rec ? 2u : 0u;
             I0->scratch_end = (u64)scratch_end;
             I0->active = S.status == ST_OK;
         }
@@ -1328,7 +1350,9 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
     // ---- encoder image: scale each row up to 1<<bits (:756) and build entries (:759-762) -----------
     for (u32 j = lane; j < 256; j += WAVE) img[j] = S.present[j] ? S.idx_of[j] : (u8)0;
     u16 *cumimg = (u16 *)(img + ENC_IMG_IDX);            // cum[r][0..ns]
-    const bool packed = bits == 10 && ns >= ENC_PK_MIN_NS && ns <= ENC_PK_MAX_NS;
+    // a batch that leaves LDS to spare takes symbol records (the short step); else quality-sized 10-bit tables pack
+    const bool recs = enc_rec_img_bytes(ns, ns) + ENC_RING_BYTES <= ws.direct_budget && enc_rec_img_bytes(ns, ns) <= ENC_IMG_MAIN;
+    const bool packed = !recs && bits == 10 && ns >= ENC_PK_MIN_NS && ns <= ENC_PK_MAX_NS;
     const u32 W = enc_pk_row_dwords(ns);
     // one context row per lane, serial over its ns entries (a row per wave with a scan per 64 entries and two
     // barriers per packed row took 98 us per block for 46 rows)
@@ -1339,7 +1363,10 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
         const u32 tgt = (u32)S.S[r];
         if (tgt != 0 && tgt != (1u << bits)) { u32 sz = tgt; while (sz < (1u << bits)) { sz *= 2; sh++; } }
         u32 x = 0;
-        if (!packed) {
+        if (recs) {
+            u32x4 *row = (u32x4 *)(img + ENC_IMG_IDX) + r * ns;
+            for (u32 j = 0; j < ns; j++) { const u32 f = Fp[r * ns + j] << sh; row[j] = enc_record(x, f, bits, ws.rcptab); x += f; }
+        } else if (!packed) {
             u16 *row = cumimg + r * (ns + 1);
             for (u32 j = 0; j < ns; j++) { row[j] = (u16)x; x += Fp[r * ns + j] << sh; }
             row[ns] = (u16)x;
@@ -1388,8 +1415,8 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
     if (lane == 0) {
         D->tab_len = final_len;
         I0->data = (u64)data; I0->n = n; I0->image = (u64)img; I0->bits = bits; I0->order = 1;
-        I0->ns = ns; I0->img_bytes = packed ? enc_pk_img_bytes(ns) : ENC_IMG_IDX + 2u * ns * (ns + 1);
-        I0->packed = packed ? 1u : 0u;
+        I0->ns = ns; I0->img_bytes = recs ? enc_rec_img_bytes(ns, ns) : packed ? enc_pk_img_bytes(ns) : ENC_IMG_IDX + 2u * ns * (ns + 1);
+        I0->packed = recs ? 2u : packed ? 1u : 0u;
         I0->scratch_end = (u64)scratch_end;
         I0->active = 1;
     }

@@ -6,7 +6,7 @@ name=$1; shift
 mkdir -p ../variants ../../build/var_$name
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -fno-fast-math -Wno-unused-function -Wno-unused-variable"
 objs=""
-for f in r4x16_api r4x16_host r4x16_multi r4x16_stripe r4x16_decode r4x16_encode r4x16_enc_chain; do
+for f in r4x16_api r4x16_host r4x16_multi r4x16_stripe r4x16_decode r4x16_encode r4x16_enc_chain r4x16_enc_chain_rec; do
   /opt/rocm/bin/hipcc $FLAGS "$@" -c $f.hip -o ../../build/var_$name/$f.o & objs="$objs ../../build/var_$name/$f.o"
 done
 /opt/rocm/bin/hipcc $FLAGS -mllvm -amdgpu-sched-strategy=max-ilp "$@" -c r4x16_enc_chain_pk.hip -o ../../build/var_$name/r4x16_enc_chain_pk.o &
