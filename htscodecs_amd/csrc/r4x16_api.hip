@@ -59,6 +59,10 @@ extern "C" void rans4x16_hip_destroy(rans4x16_hip_ctx *c)
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     for (int w = 0; w < 2; w++)
         for (auto &t : c->timed[w]) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    if (c->fork_made) {
+        for (int i = 0; i < R4_FORK_STREAMS; i++) if (c->fork.aux[i]) { (void)hipStreamSynchronize(c->fork.aux[i]); (void)hipStreamDestroy(c->fork.aux[i]); }
+        for (int i = 0; i <= R4_FORK_STREAMS; i++) if (c->fork.ev[i]) (void)hipEventDestroy(c->fork.ev[i]);
+    }
     if (c->ws_done) (void)hipEventDestroy(c->ws_done);
     if (c->ws) (void)hipFree(c->ws);
     if (c->xs) (void)hipFree(c->xs);
@@ -132,6 +136,30 @@ static size_t plan_chunk(rans4x16_hip_ctx *c, size_t n, size_t per_blk)
     if (chunk > n) chunk = n;
     const size_t rounds = (n + chunk - 1) / chunk;
     return (n + rounds - 1) / rounds;
+}
+
+// The side streams of a small batch's class launches (R4Fork, r4x16_dev.h); nullptr where the batch is not small or the
+// streams cannot be made.  R4X16_FORK=0 switches them off.
+extern "C" int r4x16_cu_count(void);
+// (small: at most eight streams per CU - such grids leave the chip mostly idle whatever their classes)
+static const R4Fork *fork_for(rans4x16_hip_ctx *c, bool small)
+{
+    static const bool enabled = !(getenv("R4X16_FORK") && atoi(getenv("R4X16_FORK")) == 0);
+    if (!small || !enabled || c->no_fork) return nullptr;
+    if (!c->fork_made) {
+        c->fork_made = true;
+        // Streams of one priority may share a hardware queue, which serialises their kernels (the host pipeline's
+        // lanes): the side streams take the priorities around the caller's - high, low, then normal.
+        int lo = 0, hi = 0, n = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo: least priority (largest number), hi: greatest
+        const int prio[R4_FORK_STREAMS] = {hi, lo, (lo + hi) / 2};
+        for (; n < R4_FORK_STREAMS; n++)
+            if (hipStreamCreateWithPriority(&c->fork.aux[n], hipStreamNonBlocking, prio[n]) != hipSuccess) { c->fork.aux[n] = nullptr; break; }
+        for (int i = 0; i <= n; i++)
+            if (hipEventCreateWithFlags(&c->fork.ev[i], hipEventDisableTiming) != hipSuccess) { c->fork.ev[i] = nullptr; n = 0; break; }
+        c->fork.n = n;
+    }
+    return c->fork.n ? &c->fork : nullptr;
 }
 
 // A context has ONE workspace: calls on different streams must not overlap on it.  Every *_dev call ends with an
@@ -260,7 +288,7 @@ extern "C" int rans4x16_hip_compress_dev(rans4x16_hip_ctx *c, int n,
         r4x16_launch_enc_tables(&a, &w, (int)base, nb, s);
         TimedLaunch t;
         if (c->timing) time_begin(c, 0, s, t);
-        r4x16_launch_enc_chain(&w, 3 * nb, s);
+        r4x16_launch_enc_chain(&w, 3 * nb, s, fork_for(c, nb <= 8 * r4x16_cu_count()));
         if (c->timing) time_end(c, 0, s, t);
         r4x16_launch_enc_finish(&a, &w, (int)base, nb, s);
     }
@@ -339,7 +367,7 @@ extern "C" int rans4x16_hip_uncompress_dev(rans4x16_hip_ctx *c, int n,
         r4x16_launch_dec_front(&a, &w, (int)base, nb, s);
         TimedLaunch t;
         if (c->timing) time_begin(c, 1, s, t);
-        r4x16_launch_dec_chain(&w, 2 * nb, s);
+        r4x16_launch_dec_chain(&w, 2 * nb, s, fork_for(c, nb <= 8 * r4x16_cu_count()));
         if (c->timing) time_end(c, 1, s, t);
         r4x16_launch_dec_back(&a, &w, (int)base, nb, s);
     }

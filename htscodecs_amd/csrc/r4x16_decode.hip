@@ -1787,7 +1787,7 @@ __global__ __launch_bounds__(WAVE) void k_dec_back(BatchArgs a, DecWs ws, int ba
 }
 
 // ---- host-callable launchers (r4x16_api.hip) ---------------------------------------------------
-static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitems, bool one_row_only, hipStream_t s);
+static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitems, bool one_row_only, hipStream_t s, const R4Fork *fk = nullptr);
 extern "C" void r4x16_launch_dec_front(const BatchArgs *a, const DecWs *ws, int base, int nblk, hipStream_t s)
 {
     hipLaunchKernelGGL(k_dec_front<0>, dim3(nblk), dim3(WAVE), 0, s, *a, *ws, base);
@@ -1925,10 +1925,11 @@ extern "C" void r4x16_launch_cls_group(const u32 *cls, int nitems, u32 *count, u
     hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(64), 0, s, count);
     hipLaunchKernelGGL(k_cls_scatter, dim3((nitems + 255) / 256), dim3(256), 0, s, cls, nitems, count, list);
 }
-extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t s) { launch_dec_chain_of(ws, ws->items, nitems, false, s); }
+extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t s, const R4Fork *fk) { launch_dec_chain_of(ws, ws->items, nitems, false, s, fk); }
 // one_row_only: the items are order-0 streams (one-row images): only the classes such an image can fall into are launched
-static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitems, bool one_row_only, hipStream_t s)
+static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitems, bool one_row_only, hipStream_t s0, const R4Fork *fk)
 {
+    hipStream_t s = s0;
     {
         DecClassTab tab;
         tab.n = DEC_NCLS;
@@ -1947,7 +1948,8 @@ static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitem
     }
     static const int force_qpw = getenv("R4X16_DEC_QPW") ? atoi(getenv("R4X16_DEC_QPW")) : 0;   // tuning aids
     static const int force_small = getenv("R4X16_DEC_QPW_SMALL") ? atoi(getenv("R4X16_DEC_QPW_SMALL")) : 0;
-    u32 ci = 0;
+    if (fk) fk->begin(s0);                     // a small batch: its classes run side by side (R4Fork, r4x16_dev.h)
+    u32 ci = 0, launched = 0;
     for (const auto &c : DEC_CLASSES) {
         static const int force_pk = getenv("R4X16_DEC_QPW_PK") ? atoi(getenv("R4X16_DEC_QPW_PK")) : 0;
         const int qpw = (c.lv == 1 && force_pk && c.bytes == 3496) ? force_pk :
@@ -1960,10 +1962,14 @@ static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitem
         // (an order-0 image: at most IMG_O0_BYTES; depth 4 only as the lone row of an alphabet beyond 150 symbols)
         const bool skip = (one_row_only && (c.lv == 1 || c.lv == 5 || c.lv == 6 || c.bytes > (c.lv == 4 ? 22528u : IMG_O0_BYTES + RING_BYTES + 128u))) ||
                           (c.lv == 6 && !ws->direct_budget);      // (no stream of this batch was given direct blocks)
-        if (!skip)
+        if (!skip) {
+            if (fk) s = fk->pick(s0, launched++);
             hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), ldsb, s, items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci), qpw, c.bytes);
+        }
         ci++;
     }
+    s = s0;
+    if (fk) fk->end(s0);
     if (one_row_only) return;                 // (such an image always fits a class)
     // images that fit no LDS class: tables stay in global memory (L2)
     const int grid = (nitems + 15) / 16;

@@ -43,6 +43,31 @@ __device__ __forceinline__ void wsync()
 // `buffer_inv sc1`, microseconds under load - and nothing here is read by another workgroup before the kernel ends.)
 __device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
+// Side streams of a context for the chain kernels of a SMALL batch.  The chain kernels are launched once per LDS size
+// class, in stream order - so a batch that mixes alphabets (q4 / q8 / q40 blocks: three classes) pays one chain latency
+// per class, one after the other, although each launch leaves most of the chip idle.  A batch below one round of
+// resident streams forks its class launches over these streams and joins them again (events); a full batch never
+// does (persistent grids that share the CUs run far slower than back to back: DESIGN 6).
+#define R4_FORK_STREAMS 3
+struct R4Fork {
+    hipStream_t aux[R4_FORK_STREAMS];
+    hipEvent_t ev[R4_FORK_STREAMS + 1];
+    int n;                         // side streams in use (0: none)
+    // fork: the side streams wait for what `s` holds so far
+    void begin(hipStream_t s) const
+    {
+        if (!n) return;
+        (void)hipEventRecord(ev[0], s);
+        for (int i = 0; i < n; i++) (void)hipStreamWaitEvent(aux[i], ev[0], 0);
+    }
+    hipStream_t pick(hipStream_t s, unsigned k) const { const unsigned j = k % (unsigned)(n + 1); return j == 0 ? s : aux[j - 1]; }
+    // join: `s` waits for every side stream
+    void end(hipStream_t s) const
+    {
+        for (int i = 0; i < n; i++) { (void)hipEventRecord(ev[i + 1], aux[i]); (void)hipStreamWaitEvent(s, ev[i + 1], 0); }
+    }
+};
+
 // Arguments of a device-resident batch (include/rans4x16_hip.h, *_dev entry points).
 struct BatchArgs {
     const u8  *in;

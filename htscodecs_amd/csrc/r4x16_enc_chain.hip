@@ -64,8 +64,9 @@ __global__ __launch_bounds__(256) void k_enc_classify(const EncItem *items, int 
 }
 extern "C" void r4x16_launch_cls_group(const u32 *cls, int nitems, u32 *count, u32 *list, hipStream_t s);   // r4x16_decode.hip
 extern "C" void r4x16_launch_cls_zero(u32 *count, hipStream_t s);
-extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t s)
+extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t s0, const R4Fork *fk)
 {
+    hipStream_t s = s0;
     {
         EncClassTab tab;
         tab.n = 0;
@@ -81,6 +82,8 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
         r4x16_enc_chain_pk_lds_limit(163840);
         r4x16_enc_chain_rec_lds_limit(163840);
     }
+    if (fk) fk->begin(s0);                     // a small batch: its classes run side by side (R4Fork, r4x16_dev.h)
+    u32 launched = 0;
     u32 ci = 0;
     static const int force_qpw = getenv("R4X16_ENC_QPW") ? atoi(getenv("R4X16_ENC_QPW")) : 0;   // tuning aids
     static const int force_waves = getenv("R4X16_ENC_WAVES") ? atoi(getenv("R4X16_ENC_WAVES")) : 0;
@@ -104,6 +107,7 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
         const int spw = (qpw + waves - 1) / waves;
         const size_t ldsb = (size_t)(pk ? ENC_LRCP_PK_BYTES : ENC_LRCP_BYTES) + (size_t)qpw * bytes;
         const int grid = r4x16_resident_grid(ldsb, waves, (nitems + qpw - 1) / qpw);
+        if (fk) s = fk->pick(s0, launched++);
         if (pk)
             r4x16_enc_chain_pk_launch(grid, (int)(WAVE * waves), ldsb, s, ws->items, ws->rcptab, ws->dump, (const u32 *)ws->cls_list,
                                       (const u32 *)(ws->cls_count + ci), qpw, spw, bytes);
@@ -116,11 +120,14 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
         if (ws->direct_budget) {                              // (else no stream of this batch was given records)
             const size_t ldsb = (size_t)c.qpw * c.bytes;
             const int grid = r4x16_resident_grid(ldsb, 1, (nitems + c.qpw - 1) / c.qpw);
+            if (fk) s = fk->pick(s0, launched++);
             r4x16_enc_chain_rec_launch(grid, ldsb, s, ws->items, ws->rcptab, ws->dump, (const u32 *)ws->cls_list,
                                        (const u32 *)(ws->cls_count + ci), c.qpw, c.bytes);
         }
         ci++;
     }
+    s = s0;
+    if (fk) fk->end(s0);
     const int grid = (nitems + 15) / 16;
     hipLaunchKernelGGL((k_enc_chain<false, false>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->rcptab, ws->dump,
                        (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci), 16, 16, 0u);

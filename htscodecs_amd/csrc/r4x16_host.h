@@ -21,11 +21,11 @@
 
 extern "C" {
 void r4x16_launch_dec_front(const BatchArgs *, const DecWs *, int, int, hipStream_t);
-void r4x16_launch_dec_chain(const DecWs *, int, hipStream_t);
+void r4x16_launch_dec_chain(const DecWs *, int, hipStream_t, const R4Fork *);
 void r4x16_launch_dec_back(const BatchArgs *, const DecWs *, int, int, hipStream_t);
 void r4x16_launch_enc_front(const BatchArgs *, const EncWs *, int, int, hipStream_t);
 void r4x16_launch_enc_tables(const BatchArgs *, const EncWs *, int, int, hipStream_t);
-void r4x16_launch_enc_chain(const EncWs *, int, hipStream_t);
+void r4x16_launch_enc_chain(const EncWs *, int, hipStream_t, const R4Fork *);
 void r4x16_launch_enc_finish(const BatchArgs *, const EncWs *, int, int, hipStream_t);
 u32  r4x16_compress_bound(u32 size, int order);
 u32  r4x16_dec_direct_budget(int nblk);
@@ -71,6 +71,10 @@ struct rans4x16_hip_ctx {
     hipEvent_t ws_done = nullptr;
     hipStream_t ws_stream = nullptr;
     bool ws_busy = false;
+    // side streams for the class launches of small batches (created at first use)
+    R4Fork fork = {};
+    bool fork_made = false;
+    bool no_fork = false;                   // a lane of the host pipeline: the lanes are its concurrency (one priority each)
     // host-buffer batches: this context's own stream, and the lane contexts large batches are pipelined over
     hipStream_t stream = nullptr;
     struct HostPipe *pipe = nullptr;

@@ -253,6 +253,7 @@ static int pipe_prepare(rans4x16_hip_ctx *c, int threads, int nlanes, size_t nev
         while ((int)hp->lanes.size() < nlanes) {
             rans4x16_hip_ctx *l = rans4x16_hip_create(c->device);
             if (!l) { c->err = "host batch: cannot create a lane context"; return -1; }
+            l->no_fork = true;          // (side streams of equal priority on two lanes would share a hardware queue)
             // The runtime keeps one pool of hardware queues per stream priority and multiplexes the streams of
             // a priority onto it; two lane streams of equal priority were seen sharing a queue, which runs their
             // kernels one after the other.  Lanes therefore take different priorities: different queues.
