@@ -148,11 +148,44 @@ def chain_figure(torch, dc, kname, kernel_ms, launches_per_step, nblk, bs, spc, 
            "ns_per_step_one_workgroup_alone": round(iso_ns, 1) if iso_ns else None,
            "probe_streams": k, "symbols_per_s": round(sym_s, 0),
            "ideal_symbols_per_s": round(ideal, 0) if ideal else None,
-           "frac": round(sym_s / ideal, 4) if ideal else None,
-           "meaning": "ideal = resident streams x 4 chains / the step latency of one workgroup alone; "
-                      "frac < 1 is contention inside a CU plus a partly filled last round"}
+           "contention_frac": round(sym_s / ideal, 4) if ideal else None,
+           "meaning": "NOT an efficiency: the kernel against ITSELF run alone - ideal = resident streams x 4 chains / the "
+                      "step latency of one workgroup alone on the chip; < 1 is contention inside a CU plus a partly filled "
+                      "last round.  How good the step is: roofline.issue"}
     if sq:
         out["sq_counters"] = sq                            # VALU issue fraction etc. from the committed PMC pass (same build)
+    return out
+
+
+def issue_figure(kname, kernel_ms, launches_per_step, nblk, bs, spc, lanes, cus, clk_khz, sq, isa):
+    """What actually bounds the chain kernels: instruction issue.  A wave that has its SIMD to itself issues one
+    instruction every four cycles, dependent or not, so a step costs 4 x its instruction count plus whatever latency no
+    instruction hides.  issue_frac = VALU instructions per wave and step x 4 cycles / measured cycles per step x
+    (waves per CU / 4 SIMDs): the fraction of the CU's vector issue slots that carry the codec's arithmetic (1.0 = all
+    four SIMDs issuing a vector instruction every slot).  VALU counts come from the SQ counters of the committed PMC pass
+    (same build, same workload); the static count from the ISA is given beside them."""
+    resident = spc * cus
+    per_launch = nblk / launches_per_step
+    rounds = max(1.0, float(-(-per_launch // resident)))
+    steps = bs // 4
+    waves_per_cu = -(-spc // (lanes // 4)) if lanes >= 4 else 0
+    cyc = kernel_ms * 1e6 / (rounds * steps) * clk_khz / 1e6
+    out = {"kernel": kname, "cycles_per_step": round(cyc, 1), "waves_per_cu": waves_per_cu, "simds_per_cu": 4,
+           "streams_per_wave": lanes // 4}
+    if isa:
+        out["isa_instructions_per_step"] = isa.get("instructions_per_step")
+        out["isa_valu_per_step"] = isa.get("valu_per_step")
+    if sq and sq.get("SQ_WAVES") and sq.get("SQ_INSTS_VALU"):
+        wave_steps = sq["SQ_WAVES"] * rounds * steps
+        valu = sq["SQ_INSTS_VALU"] / wave_steps
+        out["valu_per_wave_step"] = round(valu, 1)
+        if sq.get("SQ_INSTS_LDS"):
+            out["lds_per_wave_step"] = round(sq["SQ_INSTS_LDS"] / wave_steps, 1)
+        if sq.get("SQ_INSTS_SALU"):
+            out["salu_per_wave_step"] = round(sq["SQ_INSTS_SALU"] / wave_steps, 1)
+        out["wave_issue_frac"] = round(valu * 4 / cyc, 4)
+        out["issue_frac"] = round(valu * 4 / cyc * waves_per_cu / 4, 4)
+        out["source"] = "SQ_INSTS_VALU / (SQ_WAVES x rounds x steps), profiles PMC pass of this build"
     return out
 
 
@@ -199,6 +232,57 @@ def host_path(H, name, bs, order, nblk=3072):
             "value": round(tot / (min(t_enc) + min(t_dec)) / 1e6, 1), "unit": "MB/s",
             "sample": f"{nblk} x {bs} B {name} blocks, order {order}: pageable host buffers in, pageable host buffers out, "
                       f"through rans4x16_hip_compress_batch / rans4x16_hip_uncompress_batch; best of two passes after a warm one"}
+
+
+def configs4_leg(torch, H, dc, dev, dist, red_dev, shard, rank, world, steps=3, warmup=1, nblk=32768, bs=65536, order=1):
+    """BASELINE.json configs[4]'s real shape beside the headline: every GPU's share of a batch of 64 KiB blocks cycling
+    q4 / q8 / q40 (b mod 3), order 1, encode + decode, device-resident; same barrier / max-over-ranks timing as the
+    headline.  Every block must round-trip; rank 0 bit-compares a sample with the CPU reference."""
+    lo, hi = shard.uniform_share(world * nblk, world, rank)
+    d_in, in_off, in_size = build_batch(torch, dev, "mixed", nblk, bs, lo)
+    cap = H.rans_compress_bound_4x16(bs, order)
+    slot = (cap + 255) // 256 * 256
+    d_comp = torch.zeros(nblk * slot, dtype=torch.uint8, device=dev)
+    comp_off = torch.arange(nblk, dtype=torch.int64, device=dev) * slot
+    comp_cap = torch.full((nblk,), cap, dtype=torch.int32, device=dev)
+    comp_size = torch.zeros(nblk, dtype=torch.int32, device=dev)
+    st_e = torch.full((nblk,), -1, dtype=torch.int32, device=dev)
+    d_back = torch.zeros_like(d_in)
+    back_size = torch.zeros(nblk, dtype=torch.int32, device=dev)
+    st_d = torch.full((nblk,), -1, dtype=torch.int32, device=dev)
+
+    def step():
+        dc.compress(d_in, in_off, in_size, d_comp, comp_off, comp_cap, comp_size, st_e, order, bs)
+        dc.uncompress(d_comp, comp_off, comp_size, d_back, in_off, in_size, back_size, st_d, cap, 0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    elapsed = shard.max_over_ranks(dist, time.perf_counter() - t0, red_dev)
+    assert int((st_e != 0).sum()) == 0 and int((st_d != 0).sum()) == 0 and torch.equal(d_back, d_in), "configs[4] leg: round trip"
+    if rank == 0:
+        import cpu_libs
+        chk = cpu_libs.reference() or cpu_libs.oracle()
+        csz = comp_size.cpu().numpy()
+        rs = np.random.RandomState(11)
+        for b in sorted(set([0, 1, 2, nblk - 1] + [int(x) for x in rs.randint(0, nblk, size=28)])):
+            # block b of this rank = global block lo + b: text (lo + b) % 3 ... build_batch cycles by LOCAL index
+            want = chk.compress(block_bytes("mixed", bs, b, lo).tobytes(), order)
+            got = d_comp[b * slot:b * slot + int(csz[b])].cpu().numpy().tobytes()
+            assert got == want, f"configs[4] leg: block {b} differs from the CPU reference"
+    return {"workload": f"{nblk} x {bs} B blocks per GPU cycling q4/q8/q40+dir, order {order}, encode+decode, device-resident",
+            "value": round(world * nblk * bs / (elapsed / steps) / 1e6, 1), "unit": "MB/s", "n_gpus": world,
+            "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup}
 
 
 def spawn_ranks(n):
@@ -263,6 +347,7 @@ def main():
     ap.add_argument("--order", type=int, default=1)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host", action="store_true", help="skip the PCIe-inclusive host-buffer figure")
+    ap.add_argument("--no-configs4", action="store_true", help="skip the mixed 64 KiB leg (BASELINE configs[4]'s shape)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -389,6 +474,12 @@ def main():
             probe[which] = (k, ms)
 
     elapsed = shard.max_over_ranks(dist, elapsed, red_dev)
+    c4 = None
+    if not args.no_configs4:
+        del d_back, d_comp
+        d_back = d_comp = None
+        torch.cuda.empty_cache()
+        c4 = configs4_leg(torch, H, dc, dev, dist, red_dev, shard, rank, world)
 
     if rank == 0:
         total_unc = nblk * bs * world
@@ -409,10 +500,18 @@ def main():
         # WRITE_SIZE, separate runs, gfx950 FETCH correction applied) - only if they were taken on this very
         # workload AND with this very build of the library (its hash is stored with them): a kernel change without
         # a counter refresh reports null, never a stale figure
-        traffic, traffic_source, sq = None, None, None
+        traffic, traffic_source, sq, sq_all = None, None, None, {}
         build = library_hash()
+        isa = {}
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r03_isa_counts.json")) as f:
+                j = json.load(f)
+            if j.get("library_sha256_16") == build:
+                isa = j["kernels"]
+        except (OSError, KeyError, ValueError):
+            pass
+        try:
+            with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
                 pmc = json.load(f)
             w = pmc["workload"]
             if (w["blocks"], w["block_size"], w["data"], w["order"]) == (nblk, bs, args.data, order) \
@@ -420,13 +519,21 @@ def main():
                 for key, v in pmc["kernels"].items():       # the instantiation that did the work (k_dec_chain<true, 1>, not the
                     if key.startswith(kname) and v["traffic_bytes"] > (traffic or 0):   # nested tables' k_dec_chain<true, 3>)
                         traffic = v["traffic_bytes"]
-                        traffic_source = "profiles/r02_pmc_traffic.json"
-                sq = pmc.get("sq", {}).get(kname)
+                        traffic_source = "profiles/r03_pmc_traffic.json"
+                sq_all = pmc.get("sq", {})
+                sq = sq_all.get(kname)
         except (OSError, KeyError, ValueError):
             pass
         chain = chain_figure(torch, dc, kname, dec_avg if kname == "k_dec_chain" else enc_avg, launches_per_step,
                              nblk, bs, dec_spc if kname == "k_dec_chain" else enc_spc,
                              dec_lanes if kname == "k_dec_chain" else enc_lanes, cus, probe, sq)
+        clk_khz = dc.L.rans4x16_hip_device_clock_khz(dc.ctx.h)
+        issue = {
+            "k_dec_chain": issue_figure("k_dec_chain", dec_avg, launches_per_step, nblk, bs, dec_spc, dec_lanes, cus, clk_khz,
+                                        sq_all.get("k_dec_chain"), isa.get("k_dec_chain<true,1>")),
+            "k_enc_chain": issue_figure("k_enc_chain", enc_avg, launches_per_step, nblk, bs, enc_spc, enc_lanes, cus, clk_khz,
+                                        sq_all.get("k_enc_chain"), isa.get("k_enc_chain<true,true>")),
+        }
         out = {
             "metric": "MB/s uncompressed throughput (encode+decode), rANS4x16 order-1, q40 blocks",
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
@@ -440,19 +547,21 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic, "traffic_source": traffic_source, "library_sha256_16": build,
-                         "limiter": "dependent-chain latency x resident streams, not bandwidth (see chain)",
-                         "chain": chain, "avg_kernel_ms": round(kavg, 3),
+                         "limiter": "instruction issue of lone waves x resident streams, not bandwidth (see issue, chain)",
+                         "issue": issue, "chain": chain, "avg_kernel_ms": round(kavg, 3),
                          "enc_chain_ms": round(enc_avg, 3), "dec_chain_ms": round(dec_avg, 3),
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "note": "avg_kernel_ms = HIP-event time of the chain kernel per step; the kernel is launched "
                                  "once per LDS size class and all but one class exit in microseconds, so compare with "
-                                 "rocprof's TotalDurationNs / steps (profiles/r02_final_working_launches.csv)"},
+                                 "rocprof's TotalDurationNs / steps (profiles/r03_final_working_launches.csv)"},
             "workspace_GB": round(dc.workspace_bytes() / 2**30, 2),
             "gate": {"roundtrip_blocks": nblk, "bytes_equal_cpu_blocks": gate_blocks,
                      "how": "untimed extra step into cleared outputs after the timed ones"},
         }
+        if c4:
+            out["configs4"] = c4
         if world == 1 and not args.no_host:
-            del d_back, d_comp                              # room for the host path's own staging
+            d_back = d_comp = None                          # room for the host path's own staging
             torch.cuda.empty_cache()
             out["host_path"] = host_path(H, args.data, bs, order)
         if world == 1 and not args.no_cpu:

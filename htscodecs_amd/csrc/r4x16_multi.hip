@@ -28,10 +28,101 @@ extern "C" int rans4x16_hip_partition(int n, const unsigned int *weight, int par
     return 0;
 }
 
+// ---- host feed: each device's worker on the CPUs of the device's NUMA node (include/rans4x16_hip.h part 3) ----------
+#include <pthread.h>
+#include <sched.h>
+
+extern "C" int rans4x16_hip_cpulist_parse(const char *list, unsigned char *mask, int mask_bytes)
+{
+    if (!list || !mask || mask_bytes <= 0) return -1;
+    memset(mask, 0, (size_t)mask_bytes);
+    int count = 0;
+    const char *p = list;
+    auto skip = [&] { while (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r') p++; };
+    auto number = [&](long *v) -> bool {
+        if (*p < '0' || *p > '9') return false;
+        long x = 0;
+        while (*p >= '0' && *p <= '9') { x = x * 10 + (*p - '0'); if (x > 1000000) return false; p++; }
+        *v = x;
+        return true;
+    };
+    skip();
+    if (!*p) return 0;                                    // an empty list: a node without CPUs
+    for (;;) {
+        long a, b;
+        if (!number(&a)) return -1;
+        b = a;
+        if (*p == '-') { p++; if (!number(&b) || b < a) return -1; }
+        if (b >= 8L * mask_bytes) return -1;
+        for (long c = a; c <= b; c++)
+            if (!(mask[c >> 3] & (1u << (c & 7)))) { mask[c >> 3] |= (unsigned char)(1u << (c & 7)); count++; }
+        skip();
+        if (*p == ',') { p++; skip(); continue; }
+        if (!*p) break;
+        return -1;
+    }
+    return count;
+}
+
+static bool read_text(const std::string &path, char *buf, size_t cap)
+{
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    const size_t n = fread(buf, 1, cap - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    return n > 0;
+}
+static int device_numa_node(int device)
+{
+    char id[64] = {0};
+    if (hipDeviceGetPCIBusId(id, (int)sizeof id, device) != hipSuccess) return -1;
+    for (char *q = id; *q; q++) if (*q >= 'A' && *q <= 'F') *q = (char)(*q - 'A' + 'a');     // sysfs spells it in lower case
+    char buf[64];
+    if (!read_text(std::string("/sys/bus/pci/devices/") + id + "/numa_node", buf, sizeof buf)) return -1;
+    return atoi(buf);
+}
+// the CPUs of `node` as a cpu_set_t; false if unknown, empty or the whole machine anyway
+static bool node_cpus(int node, cpu_set_t *set)
+{
+    if (node < 0) return false;
+    char buf[4096];
+    if (!read_text("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist", buf, sizeof buf)) return false;
+    unsigned char mask[CPU_SETSIZE / 8];
+    const int n = rans4x16_hip_cpulist_parse(buf, mask, (int)sizeof mask);
+    if (n <= 0) return false;
+    CPU_ZERO(set);
+    for (int c = 0; c < CPU_SETSIZE; c++) if (mask[c >> 3] & (1u << (c & 7))) CPU_SET(c, set);
+    return true;
+}
+// RAII: the calling thread on the device's node (threads it starts inherit the mask), its old mask back at the end
+struct NodeBinding {
+    cpu_set_t old;
+    bool bound = false;
+    explicit NodeBinding(int node)
+    {
+        static const bool enabled = !(getenv("R4X16_NUMA") && atoi(getenv("R4X16_NUMA")) == 0);
+        cpu_set_t want;
+        if (!enabled || !node_cpus(node, &want)) return;
+        if (pthread_getaffinity_np(pthread_self(), sizeof old, &old) != 0) return;
+        cpu_set_t both;
+        CPU_AND(&both, &want, &old);                         // never outside what the process is allowed (cgroups, taskset)
+        if (CPU_COUNT(&both) == 0 || CPU_EQUAL(&both, &old)) return;
+        bound = pthread_setaffinity_np(pthread_self(), sizeof both, &both) == 0;
+    }
+    ~NodeBinding() { if (bound) (void)pthread_setaffinity_np(pthread_self(), sizeof old, &old); }
+};
+
 struct rans4x16_hip_multi {
     std::vector<rans4x16_hip_ctx *> ctx;
+    std::vector<int> node;                  // NUMA node of each device (-1: unknown)
     std::string err;
 };
+
+extern "C" int rans4x16_hip_multi_numa_node(const rans4x16_hip_multi *m, int index)
+{
+    return (m && index >= 0 && index < (int)m->node.size()) ? m->node[(size_t)index] : -1;
+}
 
 extern "C" rans4x16_hip_multi *rans4x16_hip_multi_create(int ndev, const int *devices)
 {
@@ -48,6 +139,7 @@ extern "C" rans4x16_hip_multi *rans4x16_hip_multi_create(int ndev, const int *de
         rans4x16_hip_ctx *c = rans4x16_hip_create(devices ? devices[d] : d);
         if (!c) { rans4x16_hip_multi_destroy(m); return nullptr; }
         m->ctx.push_back(c);
+        m->node.push_back(device_numa_node(c->device));
     }
     return m;
 }
@@ -78,6 +170,8 @@ static int run_multi(rans4x16_hip_multi *m, int n, bool decode,
     auto work = [&](int p) {
         const int lo = bounds[(size_t)p], hi = bounds[(size_t)p + 1];
         if (hi <= lo) return;
+        // this device's copier threads and bounce buffers on the socket the device hangs off (header, part 3)
+        NodeBinding bind(m->node[(size_t)p]);
         rc[(size_t)p] = r4x16_run_host_batch(m->ctx[(size_t)p], hi - lo, decode, in + lo, in_size + lo, out + lo, out_size + lo,
                                              order ? order + lo : nullptr, status ? status + lo : nullptr);
     };

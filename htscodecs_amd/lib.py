@@ -41,6 +41,8 @@ SIGNATURES = {
     "rans4x16_hip_residency": (C.c_int, [C.c_void_p, C.c_int, C.c_uint, C.c_int, C.c_uint, C.POINTER(C.c_int),
                                         C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rans4x16_hip_partition": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "rans4x16_hip_cpulist_parse": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int]),
+    "rans4x16_hip_multi_numa_node": (C.c_int, [C.c_void_p, C.c_int]),
     "rans4x16_hip_multi_create": (C.c_void_p, [C.c_int, C.c_void_p]),
     "rans4x16_hip_multi_destroy": (None, [C.c_void_p]),
     "rans4x16_hip_multi_devices": (C.c_int, [C.c_void_p]),

@@ -198,6 +198,22 @@ int rans4x16_hip_uncompress_batch_multi(rans4x16_hip_multi *m, int n,
                                         unsigned char *const *out, unsigned int *out_size,
                                         int *status);
 
+/* Host feed of a multi-GPU node.  With eight devices the limiter is the host side: each device's
+ * pipeline has eight copier threads moving the caller's buffers through pinned bounce buffers, and on a two-socket
+ * node a copier on the wrong socket pushes every byte over the inter-socket link first.  The multi-device calls
+ * therefore run each device's worker - and with it the copier threads it starts and the bounce buffers it
+ * allocates - on the CPUs of the NUMA node the device hangs off (PCI bus id -> /sys/bus/pci/devices/<id>/numa_node
+ * -> /sys/devices/system/node/node<N>/cpulist); the calling thread's own mask is restored afterwards.
+ * R4X16_NUMA=0 switches it off; nothing happens where the node is unknown (-1) or the machine has one node. */
+
+/* Parse a kernel "cpulist" ("0-15,32-47", "3", "0-3,8") into a bit mask of mask_bytes bytes (CPU c = bit c & 7 of byte
+ * c >> 3).  Returns the number of CPUs set, or -1 on a malformed list or a CPU beyond the mask.  Pure text work,
+ * usable (and tested) without a GPU. */
+int rans4x16_hip_cpulist_parse(const char *list, unsigned char *mask, int mask_bytes);
+
+/* NUMA node of a device of `m` (index into its device list) as the kernel reports it, -1 if unknown. */
+int rans4x16_hip_multi_numa_node(const rans4x16_hip_multi *m, int index);
+
 #pragma GCC visibility pop
 
 #ifdef __cplusplus

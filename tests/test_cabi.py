@@ -131,3 +131,33 @@ def test_reference_drivers_link_unchanged_against_the_library(tmp_path):
         r = subprocess.run([exe["driver"], "-d", str(src), str(tmp_path / "out")], capture_output=True, text=True, timeout=120)
         assert r.returncode == 1, (r.returncode, r.stderr)           # fails the way the driver fails on NULL, no crash
         assert "no CPU path" in r.stderr
+
+
+def test_cpulist_parser_for_the_numa_feed():
+    """include/rans4x16_hip.h part 3: the multi-device calls pin each device's copier threads to the CPUs of the
+    device's NUMA node, read from the kernel's cpulist text.  The parser is pure text work: checked here."""
+    import ctypes as C
+    L = htscodecs_amd.load()
+
+    def parse(text, nbytes=32):
+        buf = (C.c_ubyte * nbytes)()
+        n = L.rans4x16_hip_cpulist_parse(text.encode(), buf, nbytes)
+        cpus = [c for c in range(8 * nbytes) if buf[c >> 3] & (1 << (c & 7))]
+        return n, cpus
+
+    assert parse("0-15,32-47\n") == (32, list(range(16)) + list(range(32, 48)))
+    assert parse("3") == (1, [3])
+    assert parse("0-3,8") == (5, [0, 1, 2, 3, 8])
+    assert parse(" 0-1 , 4-5 ,7\n") == (5, [0, 1, 4, 5, 7])
+    assert parse("0-3,2-5") == (6, [0, 1, 2, 3, 4, 5])            # overlapping ranges count once
+    assert parse("") == (0, []) and parse("\n") == (0, [])        # a node without CPUs
+    assert parse("255") == (1, [255])
+    for bad in ("256", "5-3", "1,,2", "a", "1-", "-1", "1 2", "0-1000000000000"):
+        assert parse(bad)[0] == -1, bad
+    # the machine's own lists parse, whatever they are
+    import glob
+    for path in glob.glob("/sys/devices/system/node/node*/cpulist"):
+        with open(path) as f:
+            text = f.read()
+        n, cpus = parse(text, 1024)
+        assert n == len(cpus) and n >= 0, (path, text)
