@@ -129,3 +129,53 @@ def test_small_batches_of_every_shape_both_row_kinds(H, oracle, monkeypatch, kno
             dec = d_dec.cpu().numpy()
             for b, off in zip(blocks, in_off):
                 assert (dec[off:off + len(b)] == b).all(), (name, order, nblk)
+
+
+def test_direct_rows_alphabet_shapes(H, oracle, monkeypatch):
+    """The short-step rows' special cases, each against the oracle both ways through the batch calls (few blocks: the
+    default budget gives every stream its direct rows):
+      * many symbols ONE slot wide (a dominant symbol and a hundred rare ones): slot pairs shared by two symbols, ranks
+        that step by one from pair to pair;
+      * affine alphabets (byte = index + c) with and without byte 0 in the data, and alphabets that are not affine
+        (gaps; byte 0 used beside an offset run), which keep the per-symbol alpha[] read;
+      * exactly 128 symbols (the largest alphabet the 7-bit index field serves) and 129 (falls back to the other rows);
+      * 12-bit order-1 tables (no room for the empty-row flag: never affine)."""
+    rs = np.random.RandomState(77)
+    datas, orders = [], []
+    def add(a, both=True):
+        for o in ((0, 1) if both else (1,)):
+            datas.append(a.tobytes()); orders.append(o)
+    n = 70000
+    add(datagen.weighted(n, [5000] + [1] * 100, 5))                        # one-slot symbols
+    add(datagen.weighted(n, [3000] + [2] * 60 + [1] * 60, 6))
+    add((datagen.weighted(n, [400] + [1] * 40, 7).astype(np.int32) + 33).astype(np.uint8))   # offset run, no byte 0
+    a = (datagen.weighted(n, [50] * 20, 8).astype(np.int32) + 40).astype(np.uint8)
+    a[::97] = 0                                                            # byte 0 used beside an offset run: not affine
+    add(a)
+    add(datagen.weighted(n, [9] * 30, 9))                                   # contiguous from 0: affine with c = 0
+    add((datagen.weighted(n, [7] * 25, 10).astype(np.int32) * 3 + 10).astype(np.uint8))     # gaps: not affine
+    add(datagen.rand(n, 11, 128, 0))
+    add(datagen.rand(n, 12, 128, 100))
+    add(datagen.rand(n, 13, 129, 0))
+    add(datagen.weighted(1 << 18, [30000] + [1] * 127, 3), both=False)      # shift 12 (SURVEY 8c's edge case, smaller alphabet)
+    add(datagen.weighted(1 << 18, [100000, 50000] + [1] * 100, 3), both=False)
+    add(datagen.tile("q40+dir", 100001, 3))
+    add(datagen.tile("q8", 99999, 4))
+    for knob in ("1", "0"):
+        monkeypatch.setenv("R4X16_DEC_DIRECT", knob)
+        monkeypatch.setenv("R4X16_ENC_DIRECT", knob)
+        enc, st = H.compress_batch(datas, orders)
+        assert all(s == 0 for s in st), st
+        want = [oracle.compress(d, o) for d, o in zip(datas, orders)]
+        bad = [(i, orders[i]) for i in range(len(datas)) if enc[i] != want[i]]
+        assert not bad, (knob, bad)
+        dec, st = H.uncompress_batch(want, [len(d) for d in datas])
+        assert all(s == 0 for s in st), (knob, st)
+        bad = [(i, orders[i]) for i in range(len(datas)) if dec[i] != datas[i]]
+        assert not bad, (knob, bad)
+    def shift_of(c):                                                        # flags, varint size, then shift << 4 | compressed
+        i = 1
+        while c[i] & 0x80:
+            i += 1
+        return c[i + 1] >> 4
+    assert sum(1 for w in want if (w[0] & 1) and shift_of(w) == 12) >= 2, "no 12-bit order-1 table among the cases"
