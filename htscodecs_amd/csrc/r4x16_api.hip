@@ -141,7 +141,14 @@ static size_t plan_chunk(rans4x16_hip_ctx *c, size_t n, size_t per_blk)
 // The side streams of a small batch's class launches (R4Fork, r4x16_dev.h); nullptr where the batch is not small or the
 // streams cannot be made.  R4X16_FORK=0 switches them off.
 extern "C" int r4x16_cu_count(void);
-// (small: at most eight streams per CU - such grids leave the chip mostly idle whatever their classes)
+// small: at most eight blocks per CU (R4X16_FORK_PER_CU) - such grids leave most of the chip idle whatever their classes.
+// (Sixteen per CU, measured on 4,096 blocks: mixed 64 KiB blocks 11.5 -> 9.1 ms and q8 with X_RLE 83 -> 77 ms, but 1 MiB
+//  q40 blocks 82 -> 90 ms: a payload class that fills the CUs' LDS does not share them with the nested-table class.)
+static int fork_blocks()
+{
+    static const int per_cu = getenv("R4X16_FORK_PER_CU") ? atoi(getenv("R4X16_FORK_PER_CU")) : 8;
+    return per_cu * r4x16_cu_count();
+}
 static const R4Fork *fork_for(rans4x16_hip_ctx *c, bool small)
 {
     static const bool enabled = !(getenv("R4X16_FORK") && atoi(getenv("R4X16_FORK")) == 0);
@@ -288,7 +295,7 @@ extern "C" int rans4x16_hip_compress_dev(rans4x16_hip_ctx *c, int n,
         r4x16_launch_enc_tables(&a, &w, (int)base, nb, s);
         TimedLaunch t;
         if (c->timing) time_begin(c, 0, s, t);
-        r4x16_launch_enc_chain(&w, 3 * nb, s, fork_for(c, nb <= 8 * r4x16_cu_count()));
+        r4x16_launch_enc_chain(&w, 3 * nb, s, fork_for(c, nb <= fork_blocks()));
         if (c->timing) time_end(c, 0, s, t);
         r4x16_launch_enc_finish(&a, &w, (int)base, nb, s);
     }
@@ -367,7 +374,7 @@ extern "C" int rans4x16_hip_uncompress_dev(rans4x16_hip_ctx *c, int n,
         r4x16_launch_dec_front(&a, &w, (int)base, nb, s);
         TimedLaunch t;
         if (c->timing) time_begin(c, 1, s, t);
-        r4x16_launch_dec_chain(&w, 2 * nb, s, fork_for(c, nb <= 8 * r4x16_cu_count()));
+        r4x16_launch_dec_chain(&w, 2 * nb, s, fork_for(c, nb <= fork_blocks()));
         if (c->timing) time_end(c, 1, s, t);
         r4x16_launch_dec_back(&a, &w, (int)base, nb, s);
     }
