@@ -169,8 +169,12 @@ static const R4Fork *fork_for(rans4x16_hip_ctx *c, bool small)
     return c->fork.n ? &c->fork : nullptr;
 }
 
+static int ws_order_begin(rans4x16_hip_ctx *c, hipStream_t s);
+static int ws_order_end(rans4x16_hip_ctx *c, hipStream_t s);
 // A context has ONE workspace: calls on different streams must not overlap on it.  Every *_dev call ends with an
 // event on its stream; a call on another stream first waits for the previous call's event.
+int r4x16_ws_order_begin(rans4x16_hip_ctx *c, hipStream_t s) { return ws_order_begin(c, s); }
+int r4x16_ws_order_end(rans4x16_hip_ctx *c, hipStream_t s) { return ws_order_end(c, s); }
 static int ws_order_begin(rans4x16_hip_ctx *c, hipStream_t s)
 {
     if (c->ws_busy && s != c->ws_stream) HIPCHK(c, hipStreamWaitEvent(s, c->ws_done, 0));
@@ -836,6 +840,12 @@ extern "C" unsigned char *rans_uncompress(unsigned char *in, unsigned int in_siz
 {
     rans4x16_hip_ctx *c = thread_ctx();
     if (!c || !out_size || in_size < 9) return nullptr;                          // rANS_static.c:937
+    // the reference's cheap header checks come BEFORE its allocation (rANS_static.c:241-253, :686-698): a hostile
+    // nine-byte stream must not cost a 2 GiB malloc and a device staging arena
+    if (in[0] > 1) return nullptr;
+    if (in_size < (in[0] ? 27u : 26u)) return nullptr;
+    const unsigned int csz = (unsigned int)in[1] | ((unsigned int)in[2] << 8) | ((unsigned int)in[3] << 16) | ((unsigned int)in[4] << 24);
+    if (csz != in_size - 9) return nullptr;
     unsigned int usz = (unsigned int)in[5] | ((unsigned int)in[6] << 8) | ((unsigned int)in[7] << 16) | ((unsigned int)in[8] << 24);
     if (usz >= INT_MAX) return nullptr;
     unsigned char *out = (unsigned char *)malloc(usz ? usz : 1);

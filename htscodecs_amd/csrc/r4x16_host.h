@@ -38,6 +38,9 @@ struct HostPipe;
 void r4x16_pipe_destroy(HostPipe *);
 int r4x16_ensure_stage(rans4x16_hip_ctx *c, size_t bytes);
 void r4x16_trim(rans4x16_hip_ctx *c, size_t keep);
+// stream ordering of a context's arenas (workspace, stripe arena) between calls on different streams: r4x16_api.hip
+int r4x16_ws_order_begin(rans4x16_hip_ctx *c, hipStream_t s);
+int r4x16_ws_order_end(rans4x16_hip_ctx *c, hipStream_t s);
 int r4x16_stripe_compress_dev(rans4x16_hip_ctx *c, int n, const BatchArgs &a, int order, uint32_t max_in_size, hipStream_t s);
 int r4x16_stripe_uncompress_dev(rans4x16_hip_ctx *c, int n, const BatchArgs &a, uint32_t max_in_size, uint32_t max_out_cap,
                                 uint32_t max_stripe_out, hipStream_t s);

@@ -170,12 +170,15 @@ int r4x16_stripe_compress_dev(rans4x16_hip_ctx *c, int n, const BatchArgs &a, in
     StripeArrays w;
     if (ensure_xs(c, carve(&w, nullptr, (size_t)n, P, pl_stride, oslot)) != 0) return -1;
     carve(&w, c->xs, (size_t)n, P, pl_stride, oslot);
+    // the stripe arena is ordered between calls on different streams like the workspace: nothing of this call touches it
+    // before the previous call's last kernel is done, and the event recorded after the finishing kernel covers it
+    if (r4x16_ws_order_begin(c, s) != 0) return -1;
     hipLaunchKernelGGL(k_stripe_enc_prepare, dim3(n), dim3(256), 0, s, a, w, e);
     if (rans4x16_hip_compress_dev(c, (int)((size_t)n * P), w.planes, w.in_off, w.in_size, w.out, w.out_off, w.out_cap, w.out_size,
                                   w.status, 0, w.order, item_max, s) != 0) return -1;
     hipLaunchKernelGGL(k_stripe_enc_pick, dim3(n), dim3(WAVE), 0, s, a, w, e);
     HIPCHK(c, hipGetLastError());
-    return 0;
+    return r4x16_ws_order_end(c, s);
 }
 
 // ---- decode ------------------------------------------------------------------------------------------
@@ -268,6 +271,7 @@ int r4x16_stripe_uncompress_dev(rans4x16_hip_ctx *c, int n, const BatchArgs &a, 
     StripeArrays w;
     if (ensure_xs(c, carve(&w, nullptr, (size_t)n, P, pl_stride, 0)) != 0) return -1;
     carve(&w, c->xs, (size_t)n, P, pl_stride, 0);
+    if (r4x16_ws_order_begin(c, s) != 0) return -1;          // (as in r4x16_stripe_compress_dev)
     hipLaunchKernelGGL(k_stripe_dec_prepare, dim3(n), dim3(WAVE), 0, s, a, w, (u32)P);
     // the internal items: inputs relative to the caller's input arena, outputs relative to the plane buffer
     c->in_stripe = true;
@@ -277,5 +281,5 @@ int r4x16_stripe_uncompress_dev(rans4x16_hip_ctx *c, int n, const BatchArgs &a, 
     if (rc != 0) return -1;
     hipLaunchKernelGGL(k_stripe_dec_join, dim3(n), dim3(256), 0, s, a, w, (u32)P);
     HIPCHK(c, hipGetLastError());
-    return 0;
+    return r4x16_ws_order_end(c, s);
 }

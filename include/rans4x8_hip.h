@@ -43,7 +43,11 @@ int rans4x8_hip_uncompress_batch(rans4x16_hip_ctx *ctx, int n,
                                  unsigned char *const *out, unsigned int *out_size, int *status);
 
 /* Device-resident buffers (every pointer a DEVICE pointer; see rans4x16_hip_compress_dev for the layout).
- * The calls only enqueue work on `stream`. */
+ * The calls only enqueue work on `stream`.
+ * PADDING: the decoder fetches a stream in aligned 16-byte pieces, so up to 15 bytes before a block's first byte and
+ * after its last one are READ (never used): d_in must stay readable for 16 bytes beyond the end of its last block, and
+ * a block must not start within 15 bytes of the start of the allocation unless that start is 16-byte aligned (any
+ * hipMalloc'ed arena is).  The host-buffer calls above pad their own staging. */
 int rans4x8_hip_compress_dev(rans4x16_hip_ctx *ctx, int n,
                              const unsigned char *d_in, const uint64_t *d_in_off, const uint32_t *d_in_size,
                              unsigned char *d_out, const uint64_t *d_out_off, const uint32_t *d_out_cap,
