@@ -179,3 +179,50 @@ def test_direct_rows_alphabet_shapes(H, oracle, monkeypatch):
             i += 1
         return c[i + 1] >> 4
     assert sum(1 for w in want if (w[0] & 1) and shift_of(w) == 12) >= 2, "no 12-bit order-1 table among the cases"
+
+
+def test_combiner_keeps_callers_apart(oracle):
+    """ADVICE (round 2): the combiner behind the five drop-in symbols serves unrelated callers with one batch - a bad or
+    greedy request must not fail its neighbours.  A pool of 24 threads (fresh process: the combiner reads its knobs once)
+    mixes valid blocks with garbage streams, truncated streams and streams whose size field claims 1.5 GB into a small
+    caller buffer, with the batch byte cap at 1 MB so that batches split: every valid block decodes to its input, every
+    bad one returns None, nobody hangs."""
+    import subprocess, textwrap
+    code = textwrap.dedent('''
+        import sys, os, threading
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+        import numpy as np, datagen, cpu_libs
+        import htscodecs_amd as H
+        orc = cpu_libs.oracle()
+        good = [datagen.tile(["q4", "q8", "q40+dir"][i %% 3], 30000 + 997 * i, i).tobytes() for i in range(48)]
+        comp = [orc.compress(d, (0, 1, 65, 193)[i %% 4]) for i, d in enumerate(good)]
+        rs = np.random.RandomState(5)
+        jobs = []
+        for i, (d, c) in enumerate(zip(good, comp)):
+            jobs.append(("ok", c, len(d), d))
+            if i %% 3 == 0: jobs.append(("bad", rs.bytes(200 + i), 4096, None))
+            if i %% 5 == 0: jobs.append(("bad", c[:len(c) // 2], len(d), None))
+            if i %% 7 == 0: jobs.append(("bad", bytes([0]) + bytes([0x85, 0xcb, 0xa5, 0xe0, 0x00]) + c[4:], 1000, None))   # claims ~1.5 GB
+        res = [None] * len(jobs)
+        def work(k):
+            for j in range(k, len(jobs), 24):
+                kind, c, cap, want = jobs[j]
+                res[j] = H.rans_uncompress_4x16(c, cap)
+        th = [threading.Thread(target=work, args=(k,)) for k in range(24)]
+        [t.start() for t in th]; [t.join(120) for t in th]
+        assert not any(t.is_alive() for t in th), "a caller hangs"
+        for (kind, c, cap, want), r in zip(jobs, res):
+            if kind == "ok": assert r == want, "a valid block failed beside a bad one"
+            else: assert r is None or r == orc.uncompress(c, cap), "a bad block did not fail like the oracle"
+        # and the encode side: valid inputs beside an empty one
+        enc = [None] * 48
+        def work2(k):
+            for j in range(k, 48, 24): enc[j] = H.rans_compress_4x16(good[j], (0, 1, 65, 193)[j %% 4])
+        th = [threading.Thread(target=work2, args=(k,)) for k in range(24)]
+        [t.start() for t in th]; [t.join(120) for t in th]
+        assert enc == comp
+        print("isolated ok")
+    ''') % (ROOT, ROOT)
+    env = dict(os.environ, R4X16_COMBINE_MAX_MB="1", R4X16_COMBINE_MAX="8")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "isolated ok" in r.stdout, r.stdout + r.stderr
