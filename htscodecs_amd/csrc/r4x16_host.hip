@@ -367,10 +367,14 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
     // small slabs cost many floors (60,000 blocks of <= 64 KiB in slabs of 1,900: 717 ms; in four slabs: see §6).
     const size_t tot = in_tot + out_tot;
     const size_t rounds = (tot + (size_t)nlanes * ((size_t)8 << 30) - 1) / ((size_t)nlanes * ((size_t)8 << 30));
-    // (encode slabs are half that: its chain kernel is the shorter one, ~28 ms per MiB of block size against the
-    //  decoder's ~52, and sparse bound-sized output slots make its copy-out the slower DMA - a smaller last
-    //  slab shortens the tail of the pipeline)
-    size_t nslab = (rounds ? rounds : 1) * (size_t)nlanes * (decode ? 1u : 2u);
+    // One slab per lane for both directions (R4X16_HOST_DEC_SLABS / R4X16_HOST_ENC_SLABS per lane).  Measured on 3,072 x
+    // 1 MiB q40 blocks, round 3: encode 30.1 GB/s with one slab per lane against 26.8 with two and 19.0 with three (round
+    // 2's default was two: its chain kernel needed 28 ms per slab whatever the slab, now 22 for slabs of up to 1,024
+    // blocks and still a floor per slab); decode 23.3 with one, 19.7 with two, 14.9 with three.  Three decode slabs of
+    // exactly 1,024 blocks on ONE lane reach 25.3 GB/s (each takes the short-step rows, 31 ms, and its output leaves
+    // while the next runs) - but only for alphabets whose direct rows fit four streams per CU, which the host cannot
+    // know; with any other data three serial slabs cost three full chain latencies.  Not adopted.
+    size_t nslab = (rounds ? rounds : 1) * (size_t)nlanes * (size_t)(decode ? env_long("R4X16_HOST_DEC_SLABS", 1) : env_long("R4X16_HOST_ENC_SLABS", 1));
     const long slab_min_mb = env_long("R4X16_HOST_SLAB_MIN_MB", 32);
     while (nslab > 1 && tot / nslab < ((size_t)(slab_min_mb > 0 ? slab_min_mb : 1) << 20)) nslab--;
     if (nslab > (size_t)n) nslab = (size_t)n;
