@@ -1549,20 +1549,245 @@ __global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDes
 }
 
 // ---------------------------------------------------------------------------------------------
-// Run-length expansion, rle.c:142-187, by one wave.  64 literals per trip: the run varints of the
+// Run-length expansion, rle.c:142-187, by a whole workgroup: the route of SMALL batches (round 3).  One wave per block
+// (rle_expand_wave below) walks the literals 64 at a time, each trip a chain of ballots, shuffles and LDS exchanges:
+// 18.6 ms for a 1 MiB q8 block however few blocks there are.  Here every thread owns a contiguous chunk of the
+// literals and walks it serially - twice (more instructions per literal, since the threads of a wave diverge, but 256
+// threads per block.  Measured on 1 MiB q8 blocks with X_RLE: 64 blocks 4.5 ms against 11.0, 1,024 blocks 7.0, 4,096
+// blocks 21.7 against 18.6 - hence the switch by batch size in the launcher.  Phases 1-3 take 0.12 ms, the counting
+// walk 0.9 ms, the writing walk 3.5 ms: its byte-by-byte run fill, which a wave repeats for its longest run):
+//   1  run-stream chunks: how many varints END in each (scan -> how many end before it)
+//   2  literal chunks: how many literals are run-length symbols (scan -> the rank of a chunk's first varint)
+//   3  each thread finds where its first varint starts: the run chunk that holds the end of the varint before it
+//      (binary search over the scan of step 1), then a walk inside that chunk
+//   4  walk: the bytes the chunk expands to (scan, 64-bit: a hostile run is up to 4 GiB -> the chunk's output offset)
+//   5  walk again, writing: a literal, or a run as 16-byte pieces
+// Bounds as in the reference: every literal needs room (rle.c:165), a run needs room for all of it (:173); a varint
+// that would start past the end of the run stream reads as 0 (varint.h:136), of any length otherwise.
+// ---------------------------------------------------------------------------------------------
+#define BACK_THREADS 256u
+struct BackShared {
+    u8  is_rle[256];
+    u32 scan_a[BACK_THREADS + 1];      // varint ends before each run chunk (+ total)
+    u32 rank0[BACK_THREADS];           // rank of each literal chunk's first varint
+    u32 wave_tot[8];
+    u64 wave_tot64[8];
+    u32 err;
+    u8  map[16];
+    u32 vals[WAVE];                    // (the one-wave route's exchange buffer)
+    u8  tile[BACK_THREADS * 68u];      // 64 literals per thread at a stride of 17 dwords (no two threads on one bank)
+};
+
+// exclusive prefix sum over the workgroup (every thread calls); *total = the sum
+__device__ __forceinline__ u32 wg_excl_scan(u32 v, u32 *total, BackShared &B, u32 tid)
+{
+    const u32 lane = tid & (WAVE - 1), wv = tid / WAVE;
+    const u32 incl = wave_incl_scan(v, lane);
+    __syncthreads();
+    if (lane == WAVE - 1) B.wave_tot[wv] = incl;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+    for (u32 w = 0; w < BACK_THREADS / WAVE; w++) { const u32 t = B.wave_tot[w]; if (w < wv) base += t; tot += t; }
+    *total = tot;
+    return base + incl - v;
+}
+__device__ __forceinline__ u64 wg_excl_scan64(u64 v, u64 *total, BackShared &B, u32 tid)
+{
+    const u32 lane = tid & (WAVE - 1), wv = tid / WAVE;
+    u64 incl = v;
+#pragma unroll
+    for (int dd = 1; dd < WAVE; dd <<= 1) {
+        const u64 tt = __shfl_up(incl, dd);
+        if (lane >= (u32)dd) incl += tt;
+    }
+    __syncthreads();
+    if (lane == WAVE - 1) B.wave_tot64[wv] = incl;
+    __syncthreads();
+    u64 base = 0, tot = 0;
+    for (u32 w = 0; w < BACK_THREADS / WAVE; w++) { const u64 t = B.wave_tot64[w]; if (w < wv) base += t; tot += t; }
+    *total = tot;
+    return base + incl - v;
+}
+
+// a thread's output: bytes gathered into 16-byte pieces (global stores need no alignment)
+struct RunOut {
+    gu8 *p;
+    u32x4 acc;           // the last (up to) sixteen bytes, the newest in the top byte
+    u32 cnt;
+    __device__ __forceinline__ void put(u32 b)
+    {
+        acc.x = __builtin_amdgcn_alignbit(acc.y, acc.x, 8);
+        acc.y = __builtin_amdgcn_alignbit(acc.z, acc.y, 8);
+        acc.z = __builtin_amdgcn_alignbit(acc.w, acc.z, 8);
+        acc.w = (acc.w >> 8) | (b << 24);
+        if (++cnt == 16) { *(GAS u32x4_unaligned *)p = acc; p += 16; cnt = 0; }
+    }
+    __device__ __forceinline__ void flush()
+    {
+        for (u32 k = cnt; k < 16; k++) {
+            acc.x = __builtin_amdgcn_alignbit(acc.y, acc.x, 8);
+            acc.y = __builtin_amdgcn_alignbit(acc.z, acc.y, 8);
+            acc.z = __builtin_amdgcn_alignbit(acc.w, acc.z, 8);
+            acc.w >>= 8;
+        }
+        const u32 w[4] = {acc.x, acc.y, acc.z, acc.w};
+        for (u32 k = 0; k < cnt; k++) p[k] = (u8)(w[k >> 2] >> (8 * (k & 3)));
+        p += cnt; cnt = 0;
+    }
+    // `n` copies of byte b
+    __device__ __forceinline__ void fill(u32 b, u64 n)
+    {
+        if (n < 40) { for (u32 k = 0; k < (u32)n; k++) put(b); return; }
+        while (cnt) { put(b); n--; }                       // completes the piece in hand (cnt < 16 <= n)
+        const u32 b4 = b * 0x01010101u;
+        const u32x4 v = {b4, b4, b4, b4};
+        for (; n >= 16; n -= 16) { *(GAS u32x4_unaligned *)p = v; p += 16; }
+        for (u32 k = 0; k < (u32)n; k++) put(b);
+    }
+};
+
+__device__ bool rle_expand_wg(const u8 *lit, u32 lit_len, const u8 *runs, u32 run_len, const u8 *syms,
+                           u32 nsyms, u8 *out, u32 cap, u32 &produced, BackShared &B, u32 tid)
+{
+    for (u32 j = tid; j < 256; j += BACK_THREADS) B.is_rle[j] = 0;
+    if (tid == 0) B.err = 0;
+    __syncthreads();
+    for (u32 j = tid; j < nsyms; j += BACK_THREADS) B.is_rle[syms[j]] = 1;
+    __syncthreads();
+
+    // 1: varint ends per run chunk (a byte without the continuation bit, or the last byte of the stream)
+    const u32 rc = ((run_len + BACK_THREADS - 1) / BACK_THREADS + 15u) & ~15u;       // chunk bytes, a multiple of 16
+    const u32 r0 = tid * rc < run_len ? tid * rc : run_len, r1 = r0 + rc < run_len ? r0 + rc : run_len;
+    u32 ends = 0;
+    {
+        gcu8 *g = to_global(runs);
+        u32 i = r0;
+        for (; i + 16 <= r1; i += 16) {
+            const u32x4 v = *(GAS const u32x4_unaligned *)(g + i);
+            ends += __popc(~v.x & 0x80808080u) + __popc(~v.y & 0x80808080u) + __popc(~v.z & 0x80808080u) + __popc(~v.w & 0x80808080u);
+        }
+        for (; i < r1; i++) ends += (g[i] & 0x80u) ? 0u : 1u;
+        if (r1 == run_len && r1 > r0 && (g[r1 - 1] & 0x80u)) ends++;                  // the stream ends inside a varint: it ends there
+    }
+    u32 total_ends;
+    const u32 ends_before = wg_excl_scan(ends, &total_ends, B, tid);
+    B.scan_a[tid] = ends_before;
+    if (tid == 0) B.scan_a[BACK_THREADS] = total_ends;
+
+    // 2: run-length symbols per literal chunk
+    const u32 lc = ((lit_len + BACK_THREADS - 1) / BACK_THREADS + 15u) & ~15u;
+    const u32 l0 = tid * lc < lit_len ? tid * lc : lit_len, l1 = l0 + lc < lit_len ? l0 + lc : lit_len;
+    u32 nr = 0;
+    {
+        gcu8 *g = to_global(lit);
+        u32 i = l0;
+        for (; i + 16 <= l1; i += 16) {
+            const u32x4 v = *(GAS const u32x4_unaligned *)(g + i);
+            const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                nr += (u32)B.is_rle[w[q] & 0xff] + (u32)B.is_rle[(w[q] >> 8) & 0xff] + (u32)B.is_rle[(w[q] >> 16) & 0xff] + (u32)B.is_rle[w[q] >> 24];
+        }
+        for (; i < l1; i++) nr += B.is_rle[g[i]];
+    }
+    u32 total_rle;
+    const u32 rank = wg_excl_scan(nr, &total_rle, B, tid);       // (also orders scan_a's writes before the reads below)
+    __syncthreads();
+
+    // 3: where this chunk's first varint starts = one past the end of varint number `rank` (counting from 1)
+    u32 rp = 0;
+    if (rank != 0) {
+        if (rank > total_ends) rp = run_len;                      // the stream has run out: every later varint reads as 0
+        else {
+            u32 lo = 0, hi = BACK_THREADS;                        // scan_a[lo] < rank <= scan_a[hi]
+            while (hi - lo > 1u) { const u32 mid = (lo + hi) >> 1; if (B.scan_a[mid] < rank) lo = mid; else hi = mid; }
+            u32 need = rank - B.scan_a[lo];                       // the need-th end inside run chunk lo
+            u32 i = lo * rc;
+            const u32 iend = i + rc < run_len ? i + rc : run_len;
+            ByteSrc rs0(runs);
+            for (; i < iend; i++) {
+                const bool e = !(rs0.at(i) & 0x80u) || i == run_len - 1u;
+                if (e && --need == 0) break;
+            }
+            rp = i + 1u;
+        }
+    }
+
+    // The literals of a chunk come through LDS, 64 per thread at a time: four 16-byte loads in flight instead of one
+    // dependent 8-byte load per eight literals (a thread's walk is a chain of memory latencies otherwise).
+    ByteSrc rs(runs);
+    gcu8 *glit = to_global(lit);
+    u8 *slot = B.tile + tid * 68u;
+    auto stage = [&](u32 i0) {                              // literals [i0, i0 + 64) of this thread's chunk into its slot
+        u32x4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u32 at = i0 + 16u * (u32)q;
+            v[q] = u32x4{0, 0, 0, 0};
+            if (at + 16u <= l1) v[q] = *(GAS const u32x4_unaligned *)(glit + at);
+            else for (u32 k = 0; at + k < l1 && k < 16u; k++) ((u8 *)&v[q])[k] = glit[at + k];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            u32 *d = (u32 *)(slot + 16 * q);
+            d[0] = v[q].x; d[1] = v[q].y; d[2] = v[q].z; d[3] = v[q].w;
+        }
+    };
+    // 4: the bytes this chunk expands to
+    u64 mine = 0;
+    {
+        u32 r = rp;
+        for (u32 i0 = l0; i0 < l1; i0 += 64u) {
+            stage(i0);
+            const u32 m = l1 - i0 < 64u ? l1 - i0 : 64u;
+            for (u32 k = 0; k < m; k++) {
+                const u32 b = slot[k];
+                u32 rlen = 0;
+                if (B.is_rle[b]) r += var_get(rs, r, run_len, &rlen);
+                mine += 1ull + rlen;
+            }
+        }
+    }
+    u64 total_out;
+    const u64 obase = wg_excl_scan64(mine, &total_out, B, tid);
+
+    // 5: write
+    {
+        u32 r = rp;
+        u64 o = obase;
+        RunOut ro{to_global(out) + (o < cap ? o : 0), {0, 0, 0, 0}, 0};
+        bool bad = false;
+        for (u32 i0 = l0; i0 < l1 && !bad; i0 += 64u) {
+            stage(i0);
+            const u32 m = l1 - i0 < 64u ? l1 - i0 : 64u;
+            for (u32 k = 0; k < m; k++) {
+                if (o >= cap) { bad = true; break; }                               // rle.c:165
+                const u32 b = slot[k];
+                u32 rlen = 0;
+                if (B.is_rle[b]) r += var_get(rs, r, run_len, &rlen);
+                if (rlen) {
+                    if (o + rlen >= cap) { bad = true; break; }                    // rle.c:173
+                    ro.fill(b, 1ull + rlen);
+                } else ro.put(b);
+                o += 1ull + rlen;
+            }
+        }
+        ro.flush();
+        if (bad) B.err = 1;
+    }
+    __syncthreads();
+    produced = (u32)total_out;
+    return B.err == 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Run-length expansion, rle.c:142-187, by one wave (the route of LARGE batches: about 3.5 instruction issues per literal
+// and block, every block resident at once - with thousands of blocks that is as good as the wave slots allow).  64 literals per trip: the run varints of the
 // RLE-symbol literals are matched to them by rank (k-th RLE literal <-> k-th varint), lengths are
 // prefix-summed, and the output bytes are written balanced over the lanes (each output byte finds
 // its literal by binary search over the trip's 64 prefix sums).
 // ---------------------------------------------------------------------------------------------
-struct BackShared {
-    u8  is_rle[256];
-    u32 vals[WAVE];
-    u32 pfx[WAVE];
-    u8  lb[WAVE];
-    u8  map[16];
-};
-
-__device__ bool rle_expand(const u8 *lit, u32 lit_len, const u8 *runs, u32 run_len, const u8 *syms,
+__device__ bool rle_expand_wave(const u8 *lit, u32 lit_len, const u8 *runs, u32 run_len, const u8 *syms,
                            u32 nsyms, u8 *out, u32 cap, u32 &produced, BackShared &B, u32 lane)
 {
     for (u32 j = lane; j < 256; j += WAVE) B.is_rle[j] = 0;
@@ -1660,13 +1885,14 @@ __device__ bool rle_expand(const u8 *lit, u32 lit_len, const u8 *runs, u32 run_l
     return !err;
 }
 
-// hts_unpack, pack.c:211-348, by one wave.  Returns false when the packed data is too short.
-__device__ bool unpack(const u8 *data, u32 len, u8 *out, u32 out_len, u32 per, BackShared &B, u32 lane)
+// hts_unpack, pack.c:211-348, by the workgroup.  Returns false when the packed data is too short.
+template <u32 NT>
+__device__ bool unpack(const u8 *data, u32 len, u8 *out, u32 out_len, u32 per, BackShared &B, u32 lane /* thread of the workgroup */)
 {
-    if (per == 1) { wave_copy(out, data, len, lane); return true; }
+    if (per == 1) { group_copy<NT>(out, data, len, lane); return true; }
     if (per == 0) {
         const u8 v = B.map[0];
-        for (u32 i = lane; i < out_len; i += WAVE) out[i] = v;
+        for (u32 i = lane; i < out_len; i += NT) out[i] = v;
         return true;
     }
     if ((out_len + per - 1) / per > len) return false;
@@ -1681,13 +1907,13 @@ __device__ bool unpack(const u8 *data, u32 len, u8 *out, u32 out_len, u32 per, B
         // four packed dwords per lane in flight (one wave per block: a trip's load would otherwise wait alone)
         gcu8 *gdata = to_global(data);
         auto ldw = [&](u32 t) -> u32 { return t < trips ? *(GAS const u32_unaligned *)(gdata + 4ull * t) : 0u; };
-        u32 wq[4] = {ldw(lane), ldw(lane + WAVE), ldw(lane + 2 * WAVE), ldw(lane + 3 * WAVE)};
-        for (u32 t0 = lane; t0 < trips; t0 += 4 * WAVE)
+        u32 wq[4] = {ldw(lane), ldw(lane + NT), ldw(lane + 2 * NT), ldw(lane + 3 * NT)};
+        for (u32 t0 = lane; t0 < trips; t0 += 4 * NT)
 #pragma unroll
         for (u32 qi = 0; qi < 4; qi++) {
-            const u32 t = t0 + qi * WAVE;
+            const u32 t = t0 + qi * NT;
             const u32 w = wq[qi];
-            wq[qi] = ldw(t + 4 * WAVE);
+            wq[qi] = ldw(t + 4 * NT);
             if (t >= trips) continue;
             u8 *o = out + (u64)out_per * t;
             if (per == 4) {
@@ -1712,12 +1938,12 @@ __device__ bool unpack(const u8 *data, u32 len, u8 *out, u32 out_len, u32 per, B
                 }
             }
         }
-        for (u32 i = trips * out_per + lane; i < out_len; i += WAVE)
+        for (u32 i = trips * out_per + lane; i < out_len; i += NT)
             out[i] = B.map[(data[i / per] >> ((i % per) * width)) & mask];
         return true;
     }
     const u32 ndw = out_len >> 2;
-    for (u32 w = lane; w < ndw; w += WAVE) {
+    for (u32 w = lane; w < ndw; w += NT) {
         u32 v = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -1734,7 +1960,9 @@ __device__ bool unpack(const u8 *data, u32 len, u8 *out, u32 out_len, u32 per, B
 // ---------------------------------------------------------------------------------------------
 // k_dec_back: CAT copies, un-RLE, un-PACK, final size and status (:1576-1629).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVE) void k_dec_back(BatchArgs a, DecWs ws, int base)
+// NT = 64: one wave per block (large batches); NT = BACK_THREADS: a workgroup per block (small batches).
+template <u32 NT>
+__global__ __launch_bounds__(NT) void k_dec_back(BatchArgs a, DecWs ws, int base)
 {
     __shared__ BackShared B;
     const u32 lane = threadIdx.x;
@@ -1747,7 +1975,7 @@ __global__ __launch_bounds__(WAVE) void k_dec_back(BatchArgs a, DecWs ws, int ba
         const u32 flags = D->flags;
         u8 *s1 = (u8 *)D->s1, *s2 = (u8 *)D->s2, *s3 = (u8 *)D->s3;
         u32 s1_size = D->s1_size;
-        if (D->cat_src) wave_copy(s1, (const u8 *)D->cat_src, D->cat_len, lane);
+        if (D->cat_src) group_copy<NT>(s1, (const u8 *)D->cat_src, D->cat_len, lane);
         if (flags & (X_PACK | X_RLE)) { wg_fence(); __syncthreads(); }
         u32 s2_size = s1_size;
         if (flags & X_RLE) {                                           // :1598-1613
@@ -1761,8 +1989,10 @@ __global__ __launch_bounds__(WAVE) void k_dec_back(BatchArgs a, DecWs ws, int ba
             }
             if (st == ST_OK) {
                 u32 produced = 0;
-                if (!rle_expand(s1, s1_size, meta + 1 + nsyms, mlen - (1 + nsyms), meta + 1, nsyms,
-                                s2, D->osz, produced, B, lane))
+                bool ok;
+                if constexpr (NT == WAVE) ok = rle_expand_wave(s1, s1_size, meta + 1 + nsyms, mlen - (1 + nsyms), meta + 1, nsyms, s2, D->osz, produced, B, lane);
+                else ok = rle_expand_wg(s1, s1_size, meta + 1 + nsyms, mlen - (1 + nsyms), meta + 1, nsyms, s2, D->osz, produced, B, lane);
+                if (!ok)
                     st = ST_RLE;
                 else
                     s2_size = produced;
@@ -1776,7 +2006,7 @@ __global__ __launch_bounds__(WAVE) void k_dec_back(BatchArgs a, DecWs ws, int ba
             __syncthreads();
             const u32 per = D->pack_per;
             const u32 unpacked = per == 1 ? s2_size : D->osz;
-            if (!unpack(s2, s2_size, s3, unpacked, per, B, lane)) st = ST_SIZE;
+            if (!unpack<NT>(s2, s2_size, s3, unpacked, per, B, lane)) st = ST_SIZE;
             size = unpacked;
         }
     }
@@ -2011,7 +2241,10 @@ extern "C" int r4x16_dec_residency(u32 nsym, int order, u32 bits, int *streams_p
 }
 extern "C" void r4x16_launch_dec_back(const BatchArgs *a, const DecWs *ws, int base, int nblk, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_dec_back, dim3(nblk), dim3(WAVE), 0, s, *a, *ws, base);
+    // few blocks: a workgroup per block (the run-length expansion of one wave per block is a fixed ~19 ms per MiB)
+    static const int wg_per_cu = getenv("R4X16_BACK_WG_PER_CU") ? atoi(getenv("R4X16_BACK_WG_PER_CU")) : 6;
+    if (nblk <= wg_per_cu * cu_count()) hipLaunchKernelGGL(k_dec_back<BACK_THREADS>, dim3(nblk), dim3(BACK_THREADS), 0, s, *a, *ws, base);
+    else hipLaunchKernelGGL(k_dec_back<WAVE>, dim3(nblk), dim3(WAVE), 0, s, *a, *ws, base);
 }
 
 // ---------------------------------------------------------------------------------------------
