@@ -257,7 +257,7 @@ struct EncItem {
     u32 ns;          // symbols per image row (a row is ns+1 u16)
     u32 img_bytes;   // bytes of the image (what must sit in LDS)
     u32 packed;      // 0: u16 rows, 1: rows are 11-bit bit streams (below), 2: 16-byte symbol records (further below)
-    u32 pad;
+    u32 affine;      // symbol records: c + 1 when compact index = byte - c for every byte of the data (no idx_of[] look-up), else 0
 };
 // Packed encoder rows: order-1 streams with 10-bit tables and 20..64 symbols (the quality alphabets).  Row r is a
 // bit stream of 11-bit entries cum[r][0..ns] (11 bits hold the total 1024), entry j at bit 11 j; W = ceil(11 (ns + 1)

@@ -10,6 +10,7 @@
 //   -> byte -> compact index (LDS)  ->  record (LDS)  ->  four state updates.
 // =============================================================================================
 #include <stdlib.h>
+#include <type_traits>
 #include "r4x16_dev.h"
 
 struct RecOut {
@@ -84,15 +85,28 @@ struct RecOut {
 
 // ORDER 1: chain k codes quarter k backwards, byte p in the context of byte p - 1, the quarter's first byte in context 0
 // (:794-839).  ORDER 0: step s codes group gtop - s, chain k its byte 4 g + k (:442-459).
-template <int ORDER>
-__device__ __forceinline__ u32 chain_encode_rec(const u8 *img_lds, u8 *ring, gcu8 *data, u32 n, u32 ns, gcu8 *safe,
+// AFF: compact index = byte - c for every byte of the data (EncItem.affine = c + 1): no idx_of[] look-up per symbol.
+// The pipelined look-ups also run for trips past a stream's end and for lanes without a stream; so that their record
+// addresses stay inside the image whatever bytes they see, trips past the end re-read the stream's own first bytes
+// (members of the alphabet) and lanes without a pipelined stream mask the index to 0.
+template <int ORDER, bool AFF>
+__device__ __forceinline__ u32 chain_encode_rec(const u8 *img_lds, u8 *ring, gcu8 *data, u32 n, u32 ns, u32 aff, gcu8 *safe,
                                                 gu8 *scratch_end, gu8 *dump, bool active, u32 lane)
 {
     const u32 k = lane & 3;
     const u32 idxa = (u32)(unsigned long)(LAS const u8 *)img_lds;
     const u32 reca = idxa + ENC_IMG_IDX;
     const u32 rowb = 16u * ns;
-    auto idxof = [&](u32 byte) -> u32 { return *(LAS const u8 *)(unsigned long)(idxa + byte); };
+    const u32 coff = aff - 1u;
+    auto idxof = [&](u32 byte) -> u32 {
+        if (AFF) return (byte - coff) & 0xffu;
+        return *(LAS const u8 *)(unsigned long)(idxa + byte);
+    };
+    u32 pmask = 0;                                            // AFF: 0xff on lanes whose stream takes the pipelined loop
+    auto idxof_pipe = [&](u32 byte) -> u32 {
+        if (AFF) return (byte - coff) & pmask;
+        return *(LAS const u8 *)(unsigned long)(idxa + byte);
+    };
     // record of symbol si in context ci (order 0: ci = 0)
     auto rec = [&](u32 ci, u32 si) -> u32x4 {
         const u32 a = (ORDER == 1 ? reca + __umul24(ci, rowb) : reca) + 16u * si;
@@ -123,55 +137,62 @@ __device__ __forceinline__ u32 chain_encode_rec(const u8 *img_lds, u8 *ring, gcu
         const u32 ntrip = 2 * npair;
         cur = (active && q) ? idxof(qbase[r0]) : 0u;
         if (wave_any(npair > 0)) {
+            pmask = npair ? 0xffu : 0u;
+            gcu8 *past = npair ? qbase : safe;       // what trips past the end read (the stream's own first eight bytes)
             auto load8 = [&](u32 j) -> u32x2 {       // bytes r0-8j-8 .. r0-8j-1: .y = contexts of trip 2j, .x = of trip 2j+1
-                gcu8 *p = j < npair ? qbase + (r0 - 8 * j) - 8 : safe;
+                gcu8 *p = j < npair ? qbase + (r0 - 8 * j) - 8 : past;
                 return *(GAS const u32x2_unaligned *)p;
             };
             struct I4 { u32 c0, c1, c2, c3; };
             struct R4 { u32x4 a, b, c, d; };
             auto idx4 = [&](u32 ww) -> I4 {
-                I4 r = {idxof(ww >> 24), idxof((ww >> 16) & 0xff), idxof((ww >> 8) & 0xff), idxof(ww & 0xff)};
+                I4 r = {idxof_pipe(ww >> 24), idxof_pipe((ww >> 16) & 0xff), idxof_pipe((ww >> 8) & 0xff), idxof_pipe(ww & 0xff)};
                 return r;
             };
             auto rec4 = [&](const I4 &c, u32 sym) -> R4 {     // symbol `sym` in context c0, c0 in c1, c1 in c2, c2 in c3
                 R4 r = {rec(c.c0, sym), rec(c.c1, c.c0), rec(c.c2, c.c1), rec(c.c3, c.c2)};
                 return r;
             };
-            u32 cur1;
-            I4 I1;                                   // indices of trip t+1's contexts
-            R4 P0;                                   // records of trip t
+            // Two sets of pipeline registers used in turn (trip t reads set t & 1 and fills the other): a rotation
+            // `P0 = Pn; I1 = In` at the end of a trip costs twenty register moves per four symbols.
+            I4 IA, IB;                               // contexts of the trip after the one in hand
+            R4 PA, PB;                               // records of the trip in hand
+            u32 curA;                                // symbol coded first in the next trip = last context of this one
             u32x2 Q0, Q1, Q2, Q3;                    // input pieces, piece j in Q[j % 4]
             {
                 Q0 = load8(0); Q1 = load8(1); Q2 = load8(2); Q3 = load8(3);
                 const I4 i0 = idx4(Q0.y);
-                I1 = idx4(Q0.x);
-                P0 = rec4(i0, cur);
-                cur1 = i0.c3;
+                IA = idx4(Q0.x);
+                PA = rec4(i0, cur);
+                curA = i0.c3;
             }
             u32 t = 0;
-            auto trip = [&](u32 wnext2) {
-                const bool live = t < ntrip;
-                const I4 In = idx4(wnext2);              // contexts of trip t+2
-                const R4 Pn = rec4(I1, cur1);            // records of trip t+1
+            // (the all-live / some-dead decision is taken once per eight trips, OUTSIDE the trips: a branch between a trip's
+            //  look-ups and its steps would end the basic block there, and the compiler's wait-count pass then waits for
+            //  everything in flight - the look-ups just issued - at the top of the steps: 240 cycles per trip, measured)
+            auto trip = [&](auto allc, u32 wnext2, const I4 &Icur, I4 &Inext, const R4 &Pcur, R4 &Pnext) {
+                constexpr bool ALL = decltype(allc)::value;
+                const bool live = ALL ? true : t < ntrip;
+                Inext = idx4(wnext2);                    // contexts of trip t+2
+                Pnext = rec4(Icur, curA);                // records of trip t+1
                 __builtin_amdgcn_sched_barrier(0);       // (the look-ups above belong to later trips: see chain_encode_o1_lds)
-                if (!wave_any(active && !live)) {
-                    o.step<true>(x, true, P0.a); o.step<true>(x, true, P0.b); o.step<true>(x, true, P0.c); o.step<true>(x, true, P0.d);
-                } else {
-                    o.step<false>(x, live, P0.a); o.step<false>(x, live, P0.b); o.step<false>(x, live, P0.c); o.step<false>(x, live, P0.d);
-                }
-                if (live) cur = cur1;
-                cur1 = I1.c3;
-                I1 = In; P0 = Pn;
+                o.step<ALL>(x, live, Pcur.a); o.step<ALL>(x, live, Pcur.b); o.step<ALL>(x, live, Pcur.c); o.step<ALL>(x, live, Pcur.d);
+                if (live) cur = curA;
+                curA = Icur.c3;
                 t++;
                 __builtin_amdgcn_sched_barrier(0);
             };
             // double-trip d: trip 2d looks up the contexts of trip 2d+2 (piece d+1, high dword), trip 2d+1 those of trip
             // 2d+3 (piece d+1, low dword); piece d+4 is requested into the slot of piece d
+            auto eight = [&](auto allc, u32 d) {
+                Q0 = load8(d + 4); o.flush_pipelined(); trip(allc, Q1.y, IA, IB, PA, PB); trip(allc, Q1.x, IB, IA, PB, PA);
+                Q1 = load8(d + 5); o.flush_pipelined(); trip(allc, Q2.y, IA, IB, PA, PB); trip(allc, Q2.x, IB, IA, PB, PA);
+                Q2 = load8(d + 6); o.flush_pipelined(); trip(allc, Q3.y, IA, IB, PA, PB); trip(allc, Q3.x, IB, IA, PB, PA);
+                Q3 = load8(d + 7); o.flush_pipelined(); trip(allc, Q0.y, IA, IB, PA, PB); trip(allc, Q0.x, IB, IA, PB, PA);
+            };
             for (u32 d = 0; wave_any(d < npair); d += 4) {
-                Q0 = load8(d + 4); o.flush_pipelined(); trip(Q1.y); trip(Q1.x);
-                Q1 = load8(d + 5); o.flush_pipelined(); trip(Q2.y); trip(Q2.x);
-                Q2 = load8(d + 6); o.flush_pipelined(); trip(Q3.y); trip(Q3.x);
-                Q3 = load8(d + 7); o.flush_pipelined(); trip(Q0.y); trip(Q0.x);
+                if (!wave_any(active && t + 8 > ntrip)) eight(std::true_type{}, d);
+                else eight(std::false_type{}, d);
             }
             o.flush_drain();
             o.flush();
@@ -207,9 +228,11 @@ __device__ __forceinline__ u32 chain_encode_rec(const u8 *img_lds, u8 *ring, gcu
         const u32 npair = Q >> 3;
         const u32 ntrip = 2 * npair;
         if (wave_any(npair > 0)) {
+            pmask = npair ? 0xffu : 0u;
+            gcu8 *past = npair ? data : safe;                 // (the stream's own first 32 bytes)
             struct DT { u32x4 a, b; };                        // the pieces of trips 2j and 2j+1
             auto load_dt = [&](u32 j) -> DT {
-                gcu8 *p = j < npair ? data + 4ull * (Q - 8 * j) - 32 : safe;
+                gcu8 *p = j < npair ? data + 4ull * (Q - 8 * j) - 32 : past;
                 DT r = {*(GAS const u32x4_unaligned *)(p + 16), *(GAS const u32x4_unaligned *)p};
                 return r;
             };
@@ -217,41 +240,41 @@ __device__ __forceinline__ u32 chain_encode_rec(const u8 *img_lds, u8 *ring, gcu
             struct R4 { u32x4 a, b, c, d; };
             const u32 sh = 8 * k;
             auto idx4 = [&](u32x4 v) -> I4 {                  // steps run from the highest group (v.w) down
-                I4 r = {idxof((v.w >> sh) & 0xff), idxof((v.z >> sh) & 0xff), idxof((v.y >> sh) & 0xff), idxof((v.x >> sh) & 0xff)};
+                I4 r = {idxof_pipe((v.w >> sh) & 0xff), idxof_pipe((v.z >> sh) & 0xff), idxof_pipe((v.y >> sh) & 0xff), idxof_pipe((v.x >> sh) & 0xff)};
                 return r;
             };
             auto rec4 = [&](const I4 &c) -> R4 {
                 R4 r = {rec(0, c.c0), rec(0, c.c1), rec(0, c.c2), rec(0, c.c3)};
                 return r;
             };
-            I4 I1;
-            R4 P0;
+            I4 IA, IB;
+            R4 PA, PB;
             DT Q0, Q1, Q2, Q3;
             {
                 Q0 = load_dt(0); Q1 = load_dt(1); Q2 = load_dt(2); Q3 = load_dt(3);
-                P0 = rec4(idx4(Q0.a));
-                I1 = idx4(Q0.b);
+                PA = rec4(idx4(Q0.a));
+                IA = idx4(Q0.b);
             }
             u32 t = 0;
-            auto trip = [&](u32x4 wnext2) {
-                const bool live = t < ntrip;
-                const I4 In = idx4(wnext2);                   // bytes of trip t+2
-                const R4 Pn = rec4(I1);                       // records of trip t+1
+            auto trip = [&](auto allc, u32x4 wnext2, const I4 &Icur, I4 &Inext, const R4 &Pcur, R4 &Pnext) {
+                constexpr bool ALL = decltype(allc)::value;
+                const bool live = ALL ? true : t < ntrip;
+                Inext = idx4(wnext2);                         // bytes of trip t+2
+                Pnext = rec4(Icur);                           // records of trip t+1
                 __builtin_amdgcn_sched_barrier(0);
-                if (!wave_any(active && !live)) {
-                    o.step<true>(x, true, P0.a); o.step<true>(x, true, P0.b); o.step<true>(x, true, P0.c); o.step<true>(x, true, P0.d);
-                } else {
-                    o.step<false>(x, live, P0.a); o.step<false>(x, live, P0.b); o.step<false>(x, live, P0.c); o.step<false>(x, live, P0.d);
-                }
-                I1 = In; P0 = Pn;
+                o.step<ALL>(x, live, Pcur.a); o.step<ALL>(x, live, Pcur.b); o.step<ALL>(x, live, Pcur.c); o.step<ALL>(x, live, Pcur.d);
                 t++;
                 __builtin_amdgcn_sched_barrier(0);
             };
+            auto eight = [&](auto allc, u32 d) {
+                Q0 = load_dt(d + 4); o.flush_pipelined(); trip(allc, Q1.a, IA, IB, PA, PB); trip(allc, Q1.b, IB, IA, PB, PA);
+                Q1 = load_dt(d + 5); o.flush_pipelined(); trip(allc, Q2.a, IA, IB, PA, PB); trip(allc, Q2.b, IB, IA, PB, PA);
+                Q2 = load_dt(d + 6); o.flush_pipelined(); trip(allc, Q3.a, IA, IB, PA, PB); trip(allc, Q3.b, IB, IA, PB, PA);
+                Q3 = load_dt(d + 7); o.flush_pipelined(); trip(allc, Q0.a, IA, IB, PA, PB); trip(allc, Q0.b, IB, IA, PB, PA);
+            };
             for (u32 d = 0; wave_any(d < npair); d += 4) {
-                Q0 = load_dt(d + 4); o.flush_pipelined(); trip(Q1.a); trip(Q1.b);
-                Q1 = load_dt(d + 5); o.flush_pipelined(); trip(Q2.a); trip(Q2.b);
-                Q2 = load_dt(d + 6); o.flush_pipelined(); trip(Q3.a); trip(Q3.b);
-                Q3 = load_dt(d + 7); o.flush_pipelined(); trip(Q0.a); trip(Q0.b);
+                if (!wave_any(active && t + 8 > ntrip)) eight(std::true_type{}, d);
+                else eight(std::false_type{}, d);
             }
             o.flush_drain();
             o.flush();
@@ -308,8 +331,15 @@ __global__ __launch_bounds__(WAVE) void k_enc_chain_rec(EncItem *items, const u3
         const u8 *im = lds + (u64)sl * lds_per_item;
         u8 *ring = lds + (u64)sl * lds_per_item + (lds_per_item - ENC_RING_BYTES);
         gu8 *dump = to_global(dump_) + 16u * ((blockIdx.x * blockDim.x + lane) & (ENC_DUMP_BYTES / 16u - 1u));
-        u32 pay = chain_encode_rec<1>(im, ring, data, n, ns, (gcu8 *)safe_, send, dump, order == 1, lane);
-        pay |= chain_encode_rec<0>(im, ring, data, n, ns, (gcu8 *)safe_, send, dump, order == 0, lane);
+        const u32 aff = active ? I->affine : 1u;
+        u32 pay;
+        if (!wave_any(aff == 0u)) {                           // every stream of the wave has an affine alphabet
+            pay = chain_encode_rec<1, true>(im, ring, data, n, ns, aff, (gcu8 *)safe_, send, dump, order == 1, lane);
+            pay |= chain_encode_rec<0, true>(im, ring, data, n, ns, aff, (gcu8 *)safe_, send, dump, order == 0, lane);
+        } else {
+            pay = chain_encode_rec<1, false>(im, ring, data, n, ns, 1u, (gcu8 *)safe_, send, dump, order == 1, lane);
+            pay |= chain_encode_rec<0, false>(im, ring, data, n, ns, 1u, (gcu8 *)safe_, send, dump, order == 0, lane);
+        }
         if (active && (lane & 3) == 0) I->pay_len = pay;
         __syncthreads();                                      // LDS is reused by the next share
     }

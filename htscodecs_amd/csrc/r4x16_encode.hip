@@ -949,6 +949,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
         ws.stat[b].run = 0;
         EncItem *I2 = &ws.items[2 * gridDim.x + b];                        // the order-1 table as an order-0 stream (k_enc_tables)
         I0->active = 0; I1->active = 0; I0->pay_len = 0; I1->pay_len = 0; I0->packed = 0; I1->packed = 0;
+        I0->affine = 0; I1->affine = 0; I2->affine = 0;
         I2->active = 0; I2->pay_len = 0; I2->packed = 0;
         I0->blk = b; I1->blk = b; I2->blk = b;
         D->cat = 0; D->rle_on = 0; D->tab_len = 0; D->hdr_len = 0; D->dlen = 0; D->tab = (u64)tab; D->nest_on = 0;
@@ -1210,6 +1211,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
             I0->data = (u64)data; I0->n = n; I0->image = (u64)img; I0->bits = O0_BITS; I0->order = 0;
             I0->ns = 256; I0->img_bytes = rec ? enc_rec_img_bytes(256u, 1u) : ENC_IMG_IDX + 2u * 257u;
             I0->packed = rec ? 2u : 0u;
+            I0->affine = rec ? 1u : 0u;                    // order 0: symbols index the records directly
             I0->scratch_end = (u64)scratch_end;
             I0->active = S.status == ST_OK;
         }
@@ -1410,6 +1412,16 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
         }
     }
     TPROF(5);
+    // symbol records: is the compact index an offset of the byte value?  (quality values are a run of consecutive bytes;
+    // byte 0, which every order-1 alphabet lists, must then not occur in the data unless the run starts right behind it)
+    u32 aff = 0;
+    if (recs && ns >= 2) {
+        const u32 c = (u32)S.alpha[1] - 1u;
+        bool ok = true;
+        for (u32 j = lane; j < ns; j += WAVE) if (j >= 1 && (u32)S.alpha[j] != j + c) ok = false;
+        if (c != 0) for (u32 r = lane; r < ns; r += WAVE) if (Fp[r * ns] != 0) ok = false;      // byte 0 coded somewhere
+        aff = __ballot(!ok) ? 0u : c + 1u;
+    }
     const u32 final_len = 1 + tlen;
     wsync();
     if (lane == 0) {
@@ -1417,6 +1429,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
         I0->data = (u64)data; I0->n = n; I0->image = (u64)img; I0->bits = bits; I0->order = 1;
         I0->ns = ns; I0->img_bytes = recs ? enc_rec_img_bytes(ns, ns) : packed ? enc_pk_img_bytes(ns) : ENC_IMG_IDX + 2u * ns * (ns + 1);
         I0->packed = recs ? 2u : packed ? 1u : 0u;
+        I0->affine = aff;
         I0->scratch_end = (u64)scratch_end;
         I0->active = 1;
     }
