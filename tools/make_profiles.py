@@ -79,5 +79,9 @@ with open(os.path.join(DST, f"{tag}_pmc_traffic.json"), "w") as f:
 os.makedirs(os.path.join(DST, "pmc"), exist_ok=True)
 shutil.copy(one("fetch/**/*counter_collection.csv"), os.path.join(DST, "pmc", f"{tag}_fetch_counter_collection.csv"))
 shutil.copy(one("write/**/*counter_collection.csv"), os.path.join(DST, "pmc", f"{tag}_write_counter_collection.csv"))
+for name, dst in (("batch_sweep.jsonl", f"{tag}_batch_sweep.jsonl"), ("shapes.jsonl", f"{tag}_shapes.jsonl"),
+                  ("sq_small_summary.txt", f"{tag}_sq_one_block.txt")):
+    if os.path.exists(os.path.join(SRC, name)):
+        shutil.copy(os.path.join(SRC, name), os.path.join(DST, dst))
 print(json.dumps({k: v for k, v in traffic["kernels"].items()}, indent=1))
 print(json.dumps(sq, indent=1))

@@ -1,15 +1,15 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): the bench line, the rocprofv3 kernel statistics of the same command, the two
 # PMC passes for HBM traffic and two SQ passes for the chain kernels' issue / LDS figures; everything lands under
-# gpurun_out/refresh/.  Afterwards, in the container: python3 tools/make_profiles.py r02  (summaries -> profiles/).
+# gpurun_out/refresh/.  Afterwards, in the container: python3 tools/make_profiles.py r03  (summaries -> profiles/).
 set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/refresh   # (delete the local copy first: gpurun merges new files into it)
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 $R/bench.py --no-cpu --no-host > $O/bench_prof.json 2> $O/bench_prof.err
-P="--steps 1 --warmup 1 --no-cpu --no-host"
+rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 $R/bench.py --no-cpu --no-host --no-configs4 > $O/bench_prof.json 2> $O/bench_prof.err
+P="--steps 1 --warmup 1 --no-cpu --no-host --no-configs4"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch --output-format csv -- python3 $R/bench.py $P > $O/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write --output-format csv -- python3 $R/bench.py $P > $O/write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY \
@@ -19,3 +19,8 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_ACTIVE_I
 # keep the merge small: only the CSVs the summaries need
 find $O -name "*agent_info.csv" -delete
 tail -n 1 $O/bench.json
+# round 3: the batch-size sweep (what a caller gets below one round of resident streams) and the other shapes
+python3 $R/tools/batch_sweep.py $O/batch_sweep.jsonl > $O/batch_sweep.log 2>&1
+bash $R/tools/shapes.sh > $O/shapes.jsonl 2> $O/shapes.err
+bash $R/tools/sq_probe.sh > $O/sq_small.txt 2>&1; cp $R/gpurun_out/sqp/summary.txt $O/sq_small_summary.txt
+tail -n 3 $O/batch_sweep.jsonl
