@@ -141,12 +141,15 @@ static size_t plan_chunk(rans4x16_hip_ctx *c, size_t n, size_t per_blk)
 // The side streams of a small batch's class launches (R4Fork, r4x16_dev.h); nullptr where the batch is not small or the
 // streams cannot be made.  R4X16_FORK=0 switches them off.
 extern "C" int r4x16_cu_count(void);
-// small: at most eight blocks per CU (R4X16_FORK_PER_CU) - such grids leave most of the chip idle whatever their classes.
-// (Sixteen per CU, measured on 4,096 blocks: mixed 64 KiB blocks 11.5 -> 9.1 ms and q8 with X_RLE 83 -> 77 ms, but 1 MiB
-//  q40 blocks 82 -> 90 ms: a payload class that fills the CUs' LDS does not share them with the nested-table class.)
+// small: at most TWO blocks per CU (R4X16_FORK_PER_CU).  Forked launches run side by side, the empty ones included, and a
+// batch whose main class needs all of the LDS at once - 1,024 q40 streams with direct rows are four workgroups of 40 KB
+// on every CU - loses workgroups to whatever else holds LDS at the moment it starts: they run as a second round
+// (measured: 1,024 x 1 MiB q40 decode 29 -> 63 ms with the fork at eight blocks per CU).  Two blocks per CU leave half of
+// the LDS free whatever the classes.  (Sixteen per CU, on 4,096 blocks: mixed 64 KiB blocks 11.5 -> 9.1 ms and q8 with
+// X_RLE 83 -> 77 ms, but 1 MiB q40 blocks 82 -> 90 ms.)
 static int fork_blocks()
 {
-    static const int per_cu = getenv("R4X16_FORK_PER_CU") ? atoi(getenv("R4X16_FORK_PER_CU")) : 8;
+    static const int per_cu = getenv("R4X16_FORK_PER_CU") ? atoi(getenv("R4X16_FORK_PER_CU")) : 2;
     return per_cu * r4x16_cu_count();
 }
 static const R4Fork *fork_for(rans4x16_hip_ctx *c, bool small)
@@ -297,7 +300,7 @@ extern "C" int rans4x16_hip_compress_dev(rans4x16_hip_ctx *c, int n,
         w.direct_budget = r4x16_enc_direct_budget(nb);       // few streams: LDS to spare, symbol records (r4x16_common.h)
         r4x16_launch_enc_front(&a, &w, (int)base, nb, s);
         r4x16_launch_enc_tables(&a, &w, (int)base, nb, s);
-        const R4Fork *fk = fork_for(c, nb <= fork_blocks());     // (made at first use: not inside the timed region)
+        const R4Fork *fk = fork_for(c, nb > 1 && nb <= fork_blocks());     // (made at first use: not inside the timed region; one block is one payload class)
         TimedLaunch t;
         if (c->timing) time_begin(c, 0, s, t);
         r4x16_launch_enc_chain(&w, 3 * nb, s, fk);
@@ -377,7 +380,7 @@ extern "C" int rans4x16_hip_uncompress_dev(rans4x16_hip_ctx *c, int n,
         const int nb = (int)((size_t)n - base < chunk ? (size_t)n - base : chunk);
         w.direct_budget = r4x16_dec_direct_budget(nb);       // few streams: LDS to spare, the short-step rows (r4x16_common.h)
         r4x16_launch_dec_front(&a, &w, (int)base, nb, s);
-        const R4Fork *fk = fork_for(c, nb <= fork_blocks());
+        const R4Fork *fk = fork_for(c, nb > 1 && nb <= fork_blocks());
         TimedLaunch t;
         if (c->timing) time_begin(c, 1, s, t);
         r4x16_launch_dec_chain(&w, 2 * nb, s, fk);

@@ -938,7 +938,10 @@ __device__ __forceinline__ void o0_front(ByteSrc &src, u32 pos, u32 len, u32 out
     if (S.status == ST_OK) {
         const u32 ns = S.nsym;
         for (u32 j = lane; j < ns; j += WAVE) ((u16 *)img)[j] = S.alpha[j];
-        const bool dir = ns <= DIR_MAX_NSYM && dir_img_bytes(ns, 1u, O0_BITS) + RING_BYTES <= dir_budget;      // (uniform)
+        // (direct rows pay a larger image - built here, copied into LDS by the chain kernel - for a shorter step: only
+        //  for streams with at least a step per 16 bytes of image)
+        const bool dir = ns <= DIR_MAX_NSYM && dir_img_bytes(ns, 1u, O0_BITS) + RING_BYTES <= dir_budget &&
+                         out_sz >= dir_img_bytes(ns, 1u, O0_BITS) / 4u;      // (uniform)
         u32 used = 0;
         if (dir) write_row_direct(img + img_alpha_bytes(ns), S, ns, false, O0_BITS, lane, used);
         else write_row(img + img_alpha_bytes(ns), S, ns, false, lane);
@@ -1052,7 +1055,8 @@ __device__ void o1_tables(const u8 *in, ByteSrc &src, const u8 *tbuf, bool compr
     // a batch that leaves LDS to spare takes the direct rows (the short step); else 10-bit tables of quality-sized
     // alphabets take the packed rows (smaller images: more streams per CU)
     // (table precisions other than 10 and 12 bits - damaged streams only - keep the u16 rows: the entry's 12-bit fields)
-    const bool direct = (bits == 10 || bits == 12) && nsym <= DIR_MAX_NSYM && dir_img_bytes(nsym, nsym, look) + RING_BYTES <= dir_budget;
+    const bool direct = (bits == 10 || bits == 12) && nsym <= DIR_MAX_NSYM && dir_img_bytes(nsym, nsym, look) + RING_BYTES <= dir_budget &&
+                        s1_size >= dir_img_bytes(nsym, nsym, look) / 4u;     // (a step per 16 bytes of image at least: see o0_front)
     u32 dir_used = 0;                                               // symbols (64 i + lane) that have a frequency in some row
     const bool packed = !direct && bits == 10 && nsym >= PK_MIN_NSYM && nsym <= PKW_MAX_NSYM;
     const u32 stride = direct ? dir_blk_bytes(nsym, look) : packed ? pk_row_bytes(nsym) : img_row_bytes(nsym);
@@ -2044,10 +2048,11 @@ static const struct { u32 bytes; int qpw; int lv; } DEC_CLASSES[] = {
     {40976, 1, 3}, {53648, 1, 3}, {64016, 1, 3},
     {22528, 1, 4}, {32768, 1, 4}, {53248, 1, 4}, {81920, 1, 4}, {163840, 1, 4},
     // direct blocks (level 6; only batches that leave LDS to spare make such images, r4x16_dec_direct_budget): four
-    // workgroups per CU - one wave per SIMD - with as many streams per wave as fit, then one stream per wave
-    {1296, 16, 6}, {2064, 16, 6}, {2576, 15, 6}, {3216, 12, 6}, {4112, 9, 6}, {5136, 7, 6}, {6672, 6, 6}, {8080, 5, 6},
-    {10128, 4, 6}, {13584, 3, 6}, {20368, 2, 6}, {25600, 1, 6}, {32000, 1, 6}, {40960, 1, 6}, {53760, 1, 6}, {81920, 1, 6},
-    {163840, 1, 6},
+    // workgroups per CU - one wave per SIMD - with as many streams per wave as fit, then one stream per wave.  Few
+    // classes on purpose: every class is a launch, classes with streams run one after the other, and a batch that mixes
+    // alphabets (q4 / q8 / q40) should not fall into more classes than it did with the compressed rows
+    {2576, 15, 6}, {4112, 9, 6}, {8080, 5, 6}, {13584, 3, 6}, {20368, 2, 6}, {32000, 1, 6}, {40960, 1, 6}, {53760, 1, 6},
+    {81920, 1, 6}, {163840, 1, 6},
 };
 // workgroups of `lds_bytes` each that one CU holds at once (1,280-byte LDS granules, 32 wave slots)
 static int resident_per_cu(size_t lds_bytes, int waves_per_wg)
@@ -2179,12 +2184,22 @@ static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitem
     static const int force_qpw = getenv("R4X16_DEC_QPW") ? atoi(getenv("R4X16_DEC_QPW")) : 0;   // tuning aids
     static const int force_small = getenv("R4X16_DEC_QPW_SMALL") ? atoi(getenv("R4X16_DEC_QPW_SMALL")) : 0;
     if (fk) fk->begin(s0);                     // a small batch: its classes run side by side (R4Fork, r4x16_dev.h)
-    u32 ci = 0, launched = 0;
-    for (const auto &c : DEC_CLASSES) {
+    // Forked launches run side by side - and so do the EMPTY ones: the host does not know which classes hold streams.
+    // An empty grid of workgroups that each ask for a whole CU's LDS (the 80 / 160 KB classes) competes for CUs with the
+    // class that does the work (measured: 1,024 q40 streams 29 -> 37-49 ms when such grids were started first, and
+    // erratic times when they ran beside it), so classes of more than FORK_LDS_MAX bytes per workgroup are never
+    // forked: they go out on the caller's stream after the join, in stream order.
+    constexpr size_t FORK_LDS_MAX = 40960;
+    u32 launched = 0;
+    for (int pass = 0; pass < (fk ? 2 : 1); pass++) {
+    if (fk && pass == 1) { s = s0; fk->end(s0); }
+    for (u32 ci = 0; ci < DEC_NCLS; ci++) {
+        const auto &c = DEC_CLASSES[ci];
         static const int force_pk = getenv("R4X16_DEC_QPW_PK") ? atoi(getenv("R4X16_DEC_QPW_PK")) : 0;
         const int qpw = (c.lv == 1 && force_pk && c.bytes == 3496) ? force_pk :
                         c.lv != 2 ? c.qpw : (force_qpw && c.bytes == 5360) ? force_qpw : (force_small && c.bytes < 5360) ? force_small : c.qpw;
         const size_t ldsb = (size_t)qpw * c.bytes;
+        if (fk && (ldsb > FORK_LDS_MAX) != (pass == 1)) continue;
         const int grid = r4x16_resident_grid(ldsb, 1, (nitems + qpw - 1) / qpw);
         void (*kern)(const DecItem *, DecDesc *, const u32 *, const u32 *, int, u32) =
             c.lv == 1 ? k_dec_chain<true, 1> : c.lv == 5 ? k_dec_chain<true, 5> : c.lv == 2 ? k_dec_chain<true, 2> : c.lv == 3 ? k_dec_chain<true, 3> :
@@ -2193,13 +2208,13 @@ static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitem
         const bool skip = (one_row_only && (c.lv == 1 || c.lv == 5 || c.lv == 6 || c.bytes > (c.lv == 4 ? 22528u : IMG_O0_BYTES + RING_BYTES + 128u))) ||
                           (c.lv == 6 && !ws->direct_budget);      // (no stream of this batch was given direct blocks)
         if (!skip) {
-            if (fk) s = fk->pick(s0, launched++);
+            if (fk && pass == 0) s = fk->pick(s0, launched++);
             hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), ldsb, s, items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci), qpw, c.bytes);
         }
-        ci++;
     }
+    }
+    const u32 ci = DEC_NCLS;
     s = s0;
-    if (fk) fk->end(s0);
     if (one_row_only) return;                 // (such an image always fits a class)
     // images that fit no LDS class: tables stay in global memory (L2)
     const int grid = (nitems + 15) / 16;

@@ -44,10 +44,11 @@ __device__ __forceinline__ void wsync()
 __device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
 // Side streams of a context for the chain kernels of a SMALL batch.  The chain kernels are launched once per LDS size
-// class, in stream order - so a batch that mixes alphabets (q4 / q8 / q40 blocks: three classes) pays one chain latency
-// per class, one after the other, although each launch leaves most of the chip idle.  A batch below one round of
-// resident streams forks its class launches over these streams and joins them again (events); a full batch never
-// does (persistent grids that share the CUs run far slower than back to back: DESIGN 6).
+// class, in stream order - so a batch that mixes alphabets (q4 / q8 / q40 blocks: several classes) pays one chain latency
+// per class, one after the other, although each launch leaves most of the chip idle.  A batch of at most two blocks per
+// CU forks its class launches over these streams and joins them again (events); larger ones never do: forked launches
+// run side by side, the empty ones included, and a class that needs all of the LDS at once loses workgroups - a second
+// round - to whatever holds LDS when it starts (r4x16_api.hip: fork_blocks).
 #define R4_FORK_STREAMS 3
 struct R4Fork {
     hipStream_t aux[R4_FORK_STREAMS];

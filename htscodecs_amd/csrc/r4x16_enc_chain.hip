@@ -24,8 +24,7 @@ static const u32 ENC_PK_CLASSES[] = {1168, 2064, 2832, 3536, 3728, 4752, 6416};
 // symbol records (kind 2, r4x16_enc_chain_rec.hip; only batches that leave LDS to spare make such images): one wave
 // per workgroup, {LDS bytes per stream, streams per wave}; four workgroups per CU, then fewer
 static const struct { u32 bytes; int qpw; } ENC_REC_CLASSES[] = {
-    {1296, 16}, {2064, 16}, {2576, 15}, {3216, 12}, {4112, 9}, {5136, 7}, {6672, 6}, {8080, 5}, {10128, 4}, {13584, 3}, {20368, 2},
-    {25600, 1}, {32000, 1}, {40960, 1}, {53760, 1}, {81920, 1}, {163840, 1},
+    {2576, 15}, {4112, 9}, {8080, 5}, {13584, 3}, {20368, 2}, {32000, 1}, {40960, 1}, {53760, 1}, {81920, 1}, {163840, 1},
 };
 #define ENC_REC_NCLS ((u32)(sizeof(ENC_REC_CLASSES) / sizeof(ENC_REC_CLASSES[0])))
 extern "C" void r4x16_enc_chain_rec_lds_limit(int bytes);
@@ -84,10 +83,15 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
     }
     if (fk) fk->begin(s0);                     // a small batch: its classes run side by side (R4Fork, r4x16_dev.h)
     u32 launched = 0;
-    u32 ci = 0;
     static const int force_qpw = getenv("R4X16_ENC_QPW") ? atoi(getenv("R4X16_ENC_QPW")) : 0;   // tuning aids
     static const int force_waves = getenv("R4X16_ENC_WAVES") ? atoi(getenv("R4X16_ENC_WAVES")) : 0;
-    for (u32 cls = 0; cls < ENC_NCLS + ENC_PK_NCLS; cls++) {
+    // class index ci = position in the classify table: u16 classes, packed classes, record classes
+    // (forked: classes of more than FORK_LDS_MAX bytes per workgroup wait for the join and go out in stream order -
+    //  an EMPTY grid of workgroups that each ask for most of a CU's LDS competes for CUs with the class that does the
+    //  work, see launch_dec_chain_of; pass 0 = the forked classes, pass 1 = the rest after the join)
+    constexpr size_t FORK_LDS_MAX = 40960;
+    int pass = 0;
+    auto launch_rows = [&](u32 cls) {
         const bool pk = cls >= ENC_NCLS;
         const u32 bytes = pk ? ENC_PK_CLASSES[cls - ENC_NCLS] : ENC_CLASSES[cls];
         const u32 tuned = pk ? 3536u : 4752u;                // the class of the 46-symbol quality tables
@@ -106,28 +110,33 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
         if (force_waves && bytes == tuned) waves = force_waves;
         const int spw = (qpw + waves - 1) / waves;
         const size_t ldsb = (size_t)(pk ? ENC_LRCP_PK_BYTES : ENC_LRCP_BYTES) + (size_t)qpw * bytes;
+        if (fk && (ldsb > FORK_LDS_MAX) != (pass == 1)) return;
         const int grid = r4x16_resident_grid(ldsb, waves, (nitems + qpw - 1) / qpw);
-        if (fk) s = fk->pick(s0, launched++);
+        if (fk && pass == 0) s = fk->pick(s0, launched++);
         if (pk)
             r4x16_enc_chain_pk_launch(grid, (int)(WAVE * waves), ldsb, s, ws->items, ws->rcptab, ws->dump, (const u32 *)ws->cls_list,
-                                      (const u32 *)(ws->cls_count + ci), qpw, spw, bytes);
+                                      (const u32 *)(ws->cls_count + cls), qpw, spw, bytes);
         else
             hipLaunchKernelGGL((k_enc_chain<true, false>), dim3(grid), dim3(WAVE * waves), ldsb, s,
-                               ws->items, ws->rcptab, ws->dump, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci), qpw, spw, bytes);
-        ci++;
+                               ws->items, ws->rcptab, ws->dump, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + cls), qpw, spw, bytes);
+    };
+    auto launch_rec = [&](u32 r) {
+        const auto &c = ENC_REC_CLASSES[r];
+        if (!ws->direct_budget) return;                       // (no stream of this batch was given records)
+        const size_t ldsb = (size_t)c.qpw * c.bytes;
+        if (fk && (ldsb > FORK_LDS_MAX) != (pass == 1)) return;
+        const int grid = r4x16_resident_grid(ldsb, 1, (nitems + c.qpw - 1) / c.qpw);
+        if (fk && pass == 0) s = fk->pick(s0, launched++);
+        r4x16_enc_chain_rec_launch(grid, ldsb, s, ws->items, ws->rcptab, ws->dump, (const u32 *)ws->cls_list,
+                                   (const u32 *)(ws->cls_count + ENC_NCLS + ENC_PK_NCLS + r), c.qpw, c.bytes);
+    };
+    for (pass = 0; pass < (fk ? 2 : 1); pass++) {
+        if (fk && pass == 1) { s = s0; fk->end(s0); }
+        for (u32 cls = 0; cls < ENC_NCLS + ENC_PK_NCLS; cls++) launch_rows(cls);
+        for (u32 r = 0; r < ENC_REC_NCLS; r++) launch_rec(r);
     }
-    for (const auto &c : ENC_REC_CLASSES) {
-        if (ws->direct_budget) {                              // (else no stream of this batch was given records)
-            const size_t ldsb = (size_t)c.qpw * c.bytes;
-            const int grid = r4x16_resident_grid(ldsb, 1, (nitems + c.qpw - 1) / c.qpw);
-            if (fk) s = fk->pick(s0, launched++);
-            r4x16_enc_chain_rec_launch(grid, ldsb, s, ws->items, ws->rcptab, ws->dump, (const u32 *)ws->cls_list,
-                                       (const u32 *)(ws->cls_count + ci), c.qpw, c.bytes);
-        }
-        ci++;
-    }
+    const u32 ci = ENC_NCLS + ENC_PK_NCLS + ENC_REC_NCLS;
     s = s0;
-    if (fk) fk->end(s0);
     const int grid = (nitems + 15) / 16;
     hipLaunchKernelGGL((k_enc_chain<false, false>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->rcptab, ws->dump,
                        (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci), 16, 16, 0u);

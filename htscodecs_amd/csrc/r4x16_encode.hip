@@ -1203,7 +1203,8 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
     if (lane == 0) H.status = ST_OK;
     wsync();
     if (ST->order == 0) {
-        const bool rec = enc_rec_img_bytes(256u, 1u) + ENC_RING_BYTES <= ws.direct_budget;      // (uniform)
+        // (records pay a larger image for a shorter step: only for streams with at least a step per 16 bytes of image)
+        const bool rec = enc_rec_img_bytes(256u, 1u) + ENC_RING_BYTES <= ws.direct_budget && n >= enc_rec_img_bytes(256u, 1u) / 4u;      // (uniform)
         enc_o0_tables(n, tab, img, S, lane, rec ? ws.rcptab : nullptr);
         if (lane == 0) {
             D->status = S.status;
@@ -1353,7 +1354,8 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
     for (u32 j = lane; j < 256; j += WAVE) img[j] = S.present[j] ? S.idx_of[j] : (u8)0;
     u16 *cumimg = (u16 *)(img + ENC_IMG_IDX);            // cum[r][0..ns]
     // a batch that leaves LDS to spare takes symbol records (the short step); else quality-sized 10-bit tables pack
-    const bool recs = enc_rec_img_bytes(ns, ns) + ENC_RING_BYTES <= ws.direct_budget && enc_rec_img_bytes(ns, ns) <= ENC_IMG_MAIN;
+    const bool recs = enc_rec_img_bytes(ns, ns) + ENC_RING_BYTES <= ws.direct_budget && enc_rec_img_bytes(ns, ns) <= ENC_IMG_MAIN &&
+                      n >= enc_rec_img_bytes(ns, ns) / 4u;
     const bool packed = !recs && bits == 10 && ns >= ENC_PK_MIN_NS && ns <= ENC_PK_MAX_NS;
     const u32 W = enc_pk_row_dwords(ns);
     // one context row per lane, serial over its ns entries (a row per wave with a scan per 64 entries and two
