@@ -47,6 +47,8 @@ static int stripe_compress_many(rans4x16_hip_ctx *, const std::vector<int> &, co
 static int stripe_uncompress_many(rans4x16_hip_ctx *, const std::vector<int> &, const unsigned char *const *, const unsigned int *,
                                   unsigned char *const *, unsigned int *, int *);
 
+static int stripe_many_dev(rans4x16_hip_ctx *, bool, const std::vector<int> &, const unsigned char *const *, const unsigned int *,
+                           unsigned char *const *, unsigned int *, const int *, int *);
 static int run_plain_batch(rans4x16_hip_ctx *c, int n, bool decode,
                            const unsigned char *const *in, const unsigned int *in_size,
                            unsigned char *const *out, unsigned int *out_size, const int *order, int *status);
@@ -73,7 +75,9 @@ int r4x16_run_host_batch(rans4x16_hip_ctx *c, int n, bool decode,
     }
     if (!striped.empty()) {
         std::vector<int> sst(striped.size(), 0);
-        const int rc = decode ? stripe_uncompress_many(c, striped, in, in_size, out, out_size, sst.data())
+        static const bool dev_route = !(getenv("R4X16_HOST_STRIPE_DEV") && atoi(getenv("R4X16_HOST_STRIPE_DEV")) == 0);
+        const int rc = dev_route ? stripe_many_dev(c, decode, striped, in, in_size, out, out_size, order, sst.data())
+                     : decode ? stripe_uncompress_many(c, striped, in, in_size, out, out_size, sst.data())
                               : stripe_compress_many(c, striped, in, in_size, out, out_size, order, sst.data());
         if (rc < 0) return -1;
         for (size_t k = 0; k < striped.size(); k++) {
@@ -768,6 +772,149 @@ static int var_get_host(const unsigned char *cp, const unsigned char *endp, u32 
     do { ch = *cp++; j = (j << 7) | (ch & 0x7f); } while ((ch & 0x80) && cp < endp);
     *v = j;
     return (int)(cp - op);
+}
+
+// ---------------------------------------------------------------------------------------------
+// X_STRIPE blocks of a host batch through the DEVICE-RESIDENT stripe route (r4x16_stripe.hip, round 3): the blocks are
+// staged like any others and the prepare / pick / join kernels do on the device what stripe_compress_many /
+// stripe_uncompress_many below do with a read-back of the plane sizes in the middle of the call (those stay as the
+// route of R4X16_HOST_STRIPE_DEV=0).  Encode: the device route takes one `order` per call (N and the candidate methods
+// follow from it), so the blocks are grouped by their order value - one call per value, nearly always one.  Decode:
+// the host has the streams, so it reads every block's plane count from its header and reserves the largest.
+// ---------------------------------------------------------------------------------------------
+static int stripe_many_dev(rans4x16_hip_ctx *c, bool decode, const std::vector<int> &which,
+                           const unsigned char *const *in, const unsigned int *in_size,
+                           unsigned char *const *out, unsigned int *out_size, const int *order, int *fail)
+{
+    const size_t nb = which.size();
+    std::vector<u8> ok(nb, 0);
+    std::vector<int> key(nb, 0);                             // encode: the order value; decode: 0
+    u32 max_planes = 0, max_ulen = 0;
+    for (size_t k = 0; k < nb; k++) {
+        const int i = which[k];
+        fail[k] = 1;
+        if (!decode) {
+            const int o = order ? order[i] : 0;
+            int N = o >> 8; if (N == 0) N = 4;
+            if (N > 255 || out_size[i] < r4x16_compress_bound(in_size[i], o)) continue;          // :1158
+            ok[k] = 1; key[k] = o;
+        } else {
+            // the checks the reference makes before it touches a plane (:1360-1400), on the host as before
+            const unsigned char *p = in[i], *end = p + in_size[i];
+            u32 ulen, hdr = 1;
+            hdr += var_get_host(p + hdr, end, &ulen);
+            if (hdr >= in_size[i]) continue;                               // :1367
+            const u32 N = p[hdr++];
+            if (ulen != out_size[i]) continue;                             // :1379 (caller sized the buffer)
+            if (N == 0) { if (ulen == 0) { fail[k] = 0; out_size[i] = 0; } continue; }   // the reference spins forever here
+            u64 ctot = 0;
+            bool good = true;
+            for (u32 j = 0; j < N; j++) {
+                u32 cl;
+                hdr += var_get_host(p + hdr, end, &cl);
+                ctot += cl;
+                if (hdr > in_size[i] || cl > in_size[i] || cl < 1) { good = false; break; }   // :1389
+            }
+            if (!good || hdr + ctot > in_size[i]) continue;                // :1398
+            ok[k] = 1;
+            if (N > max_planes) max_planes = N;
+            if (ulen > max_ulen) max_ulen = ulen;
+        }
+    }
+    // groups of equal key, in order of first appearance
+    std::vector<int> keys;
+    for (size_t k = 0; k < nb; k++)
+        if (ok[k] && std::find(keys.begin(), keys.end(), key[k]) == keys.end()) keys.push_back(key[k]);
+    hipStream_t s = c->stream;
+    for (const int kv : keys) {
+        std::vector<size_t> g;
+        for (size_t k = 0; k < nb; k++) if (ok[k] && key[k] == kv) g.push_back(k);
+        const int m = (int)g.size();
+        std::vector<u64> in_off(m), out_off(m);
+        std::vector<u32> isz(m), cap(m);
+        size_t in_tot = 0, out_tot = 0;
+        u32 max_in = 0, max_cap = 0;
+        for (int e = 0; e < m; e++) {
+            const int i = which[g[e]];
+            in_off[e] = in_tot; in_tot += align_up((size_t)in_size[i] + 16, 256);
+            isz[e] = in_size[i]; cap[e] = out_size[i];
+            out_off[e] = out_tot; out_tot += align_up((size_t)cap[e] + 16, 256);
+            if (isz[e] > max_in) max_in = isz[e];
+            if (cap[e] > max_cap) max_cap = cap[e];
+        }
+        const size_t arr = align_up((size_t)m * 8, 256);
+        if (r4x16_ensure_stage(c, in_tot + out_tot + 6 * arr) != 0) return -1;
+        u8 *d_in = c->stage, *d_out = d_in + in_tot, *meta = d_out + out_tot;
+        u64 *d_in_off = (u64 *)meta, *d_out_off = (u64 *)(meta + arr);
+        u32 *d_isz = (u32 *)(meta + 2 * arr), *d_cap = (u32 *)(meta + 3 * arr), *d_osz = (u32 *)(meta + 4 * arr);
+        i32 *d_st = (i32 *)(meta + 5 * arr);
+        for (int e = 0; e < m; e++)
+            HIPCHK(c, hipMemcpyAsync(d_in + in_off[e], in[which[g[e]]], isz[e], hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(d_in_off, in_off.data(), (size_t)m * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(d_out_off, out_off.data(), (size_t)m * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(d_isz, isz.data(), (size_t)m * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(d_cap, cap.data(), (size_t)m * 4, hipMemcpyHostToDevice, s));
+        int rc;
+        if (decode) {
+            const int keep_planes = c->dev_stripe_planes;
+            const unsigned int keep_out = c->dev_stripe_out;
+            c->dev_stripe_planes = (int)max_planes;
+            c->dev_stripe_out = max_ulen;
+            rc = rans4x16_hip_uncompress_dev(c, m, d_in, d_in_off, d_isz, d_out, d_out_off, d_cap, d_osz, d_st, max_in, max_cap, s);
+            c->dev_stripe_planes = keep_planes;
+            c->dev_stripe_out = keep_out;
+        } else
+            rc = rans4x16_hip_compress_dev(c, m, d_in, d_in_off, d_isz, d_out, d_out_off, d_cap, d_osz, d_st, kv, nullptr, max_in, s);
+        if (rc != 0) return -1;
+        std::vector<u32> osz(m);
+        std::vector<i32> st(m);
+        HIPCHK(c, hipMemcpyAsync(osz.data(), d_osz, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(st.data(), d_st, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+        // results: decode slots are full, so the slot region comes back as it is; encode results fill a fraction of
+        // their bound-sized slots and are first gathered into the (by now dead) input region by k_pack_results - one
+        // dense transfer instead of a DMA per block (1,000 blocks: 85 ms of driver calls)
+        std::vector<u8> host;
+        if (decode) { host.resize(out_tot); HIPCHK(c, hipMemcpyAsync(host.data(), d_out, out_tot, hipMemcpyDeviceToHost, s)); }
+        HIPCHK(c, hipStreamSynchronize(s));
+        std::vector<PackDesc> pk;
+        u64 T = 0;
+        if (!decode) {
+            for (int e = 0; e < m; e++) {
+                if (st[e] != 0 || !osz[e]) continue;
+                PackDesc d; d.src = out_off[e]; d.dst = T; d.len = osz[e]; d.pad = (u32)e;
+                pk.push_back(d);
+                T += ((u64)osz[e] + 63u) & ~(u64)63u;
+            }
+            const size_t pk_bytes = pk.size() * sizeof(PackDesc);
+            if (!pk.empty() && T <= in_tot && pk_bytes <= 6 * arr) {
+                // (the descriptors go where the offset / size arrays were: nothing reads those any more)
+                PackDesc *d_pk = (PackDesc *)meta;
+                HIPCHK(c, hipMemcpyAsync(d_pk, pk.data(), pk_bytes, hipMemcpyHostToDevice, s));
+                hipLaunchKernelGGL(k_pack_results, dim3((unsigned)pk.size()), dim3(256), 0, s, (const u8 *)d_out, d_in, (const PackDesc *)d_pk);
+                HIPCHK(c, hipGetLastError());
+                host.resize(T);
+                HIPCHK(c, hipMemcpyAsync(host.data(), d_in, T, hipMemcpyDeviceToHost, s));
+                HIPCHK(c, hipStreamSynchronize(s));
+            } else {
+                for (const PackDesc &d : pk) HIPCHK(c, hipMemcpyAsync(out[which[g[d.pad]]], d_out + d.src, d.len, hipMemcpyDeviceToHost, s));
+                HIPCHK(c, hipStreamSynchronize(s));
+                pk.clear();
+            }
+        }
+        for (int e = 0; e < m; e++) {
+            const size_t k = g[e];
+            const int i = which[k];
+            if (st[e] != 0) continue;                                          // fail[k] stays 1
+            if (decode) {
+                if (osz[e] != cap[e]) continue;
+                if (osz[e]) memcpy(out[i], host.data() + out_off[e], osz[e]);
+            }
+            out_size[i] = osz[e];
+            fail[k] = 0;
+        }
+        for (const PackDesc &d : pk) memcpy(out[which[g[d.pad]]], host.data() + d.dst, d.len);
+    }
+    return 0;
 }
 
 // returns 0 on success (out/out_size filled), 1 if the block failed, -1 on runtime errors
