@@ -700,8 +700,6 @@ struct FrontShared {
     u8  alpha[256];    // compact index -> byte        (order-1)
     u16 rankof[256];   // compact index -> its rank among the alphabet members that have a row entry, or 0xffff
     u32 Fk[256];       // order-1: frequencies of the row being parsed, by that rank
-    u16 cumnz[258];    // direct rows: starts of the symbols that have a frequency, by rank
-    u32 fbl[257];      // direct rows: their entries, staged for the copy behind the last one
     u32 np;            // number of ranked members
     u32 first;         // packed rows: index of the row's first symbol of non-zero frequency
     // scalars handed from lane 0 to the wave
@@ -835,6 +833,10 @@ __device__ void write_row_direct(u8 *blkp, FrontShared &S, u32 n, bool empty, u3
     u32 *fb = (u32 *)blkp;
     u32 *tab = (u32 *)(blkp + dir_fb_bytes(n));
     const u32 T = 1u << (look - 1u);
+    // staging in arrays that are dead once S.cum stands (n <= DIR_MAX_NSYM = 128: 129 entries at most): the entries in
+    // S.F (the row's frequencies by byte), the starts of the symbols with a frequency in S.Fk (the same by rank)
+    u32 *fbl = S.F;
+    u16 *cumnz = (u16 *)S.Fk;
     if (empty) {
         if (lane < 2) fb[lane] = dir_entry(0u, 1u << look, 0u, look, look == 10u ? DIR_EMPTY : 0u);   // x stays as it is
         for (u32 j = lane; j < T / 4u; j += WAVE) tab[j] = 0u;
@@ -847,23 +849,23 @@ __device__ void write_row_direct(u8 *blkp, FrontShared &S, u32 n, bool empty, u3
         const bool nz = e > b;
         const u64 mk = __ballot(nz);
         const u32 r = nnz + (u32)__popcll(mk & ((1ull << lane) - 1ull));
-        if (nz) { S.fbl[r] = dir_entry(b, e - b, c, look, 0u); S.cumnz[r] = (u16)b; used |= 1u << (c0 / WAVE); }
+        if (nz) { fbl[r] = dir_entry(b, e - b, c, look, 0u); cumnz[r] = (u16)b; used |= 1u << (c0 / WAVE); }
         nnz += (u32)__popcll(mk);
     }
     __syncthreads();
-    for (u32 r = lane; r <= nnz; r += WAVE) fb[r] = S.fbl[r < nnz ? r : nnz - 1u];     // (a valid row has nnz >= 1: its total is 1 << look)
+    for (u32 r = lane; r <= nnz; r += WAVE) fb[r] = fbl[r < nnz ? r : nnz - 1u];     // (a valid row has nnz >= 1: its total is 1 << look)
     // each lane fills T / 64 consecutive pairs: one binary search for its first slot, then a merge walk
     const u32 P = T / WAVE;
     u32 slot = 2u * P * lane;
     u32 lo = 0, hi = nnz;                                   // cumnz[lo] <= slot < cumnz[hi]  (cumnz[0] = 0, "cumnz[nnz]" = 1 << look)
-    while (hi - lo > 1u) { const u32 mid = (lo + hi) >> 1; if (S.cumnz[mid] <= slot) lo = mid; else hi = mid; }
+    while (hi - lo > 1u) { const u32 mid = (lo + hi) >> 1; if (cumnz[mid] <= slot) lo = mid; else hi = mid; }
     u32 r = lo;
-    u32 nxt = r + 1u < nnz ? S.cumnz[r + 1u] : 0xffffu;
+    u32 nxt = r + 1u < nnz ? cumnz[r + 1u] : 0xffffu;
     for (u32 q = 0; q < P; q += 4u) {
         u32 w = 0;
 #pragma unroll
         for (u32 k = 0; k < 4u; k++) {
-            while (nxt <= slot) { r++; nxt = r + 1u < nnz ? S.cumnz[r + 1u] : 0xffffu; }
+            while (nxt <= slot) { r++; nxt = r + 1u < nnz ? cumnz[r + 1u] : 0xffffu; }
             w |= r << (8u * k);
             slot += 2u;
         }
@@ -1579,7 +1581,6 @@ struct BackShared {
     u32 err;
     u8  map[16];
     u32 vals[WAVE];                    // (the one-wave route's exchange buffer)
-    u8  tile[BACK_THREADS * 68u];      // 64 literals per thread at a stride of 17 dwords (no two threads on one bank)
 };
 
 // exclusive prefix sum over the workgroup (every thread calls); *total = the sum
@@ -1719,9 +1720,12 @@ __device__ bool rle_expand_wg(const u8 *lit, u32 lit_len, const u8 *runs, u32 ru
 
     // The literals of a chunk come through LDS, 64 per thread at a time: four 16-byte loads in flight instead of one
     // dependent 8-byte load per eight literals (a thread's walk is a chain of memory latencies otherwise).
+    // (the tile lives in the workgroup route's kernel only: 17 KB of LDS in the one-wave kernel would cut its resident
+    //  blocks per CU from 32 to 8 - measured: 16,384 x 1 MiB q4 blocks with X_PACK|X_RLE 130 -> 145 ms per step)
+    __shared__ u8 tile[BACK_THREADS * 68u];               // 64 literals per thread at a stride of 17 dwords (no two threads on one bank)
     ByteSrc rs(runs);
     gcu8 *glit = to_global(lit);
-    u8 *slot = B.tile + tid * 68u;
+    u8 *slot = tile + tid * 68u;
     auto stage = [&](u32 i0) {                              // literals [i0, i0 + 64) of this thread's chunk into its slot
         u32x4 v[4];
 #pragma unroll
