@@ -1232,7 +1232,7 @@ __device__ void o1_tables(const u8 *in, ByteSrc &src, const u8 *tbuf, bool compr
 // itself an order-0 stream becomes a chain item (four lanes decoding ~3 KB inside this one-wave kernel were a third of
 // its time on 64 KiB quality blocks).  PHASE 1, after those items have run: the order-1 tables of their blocks.
 template <int PHASE>
-__global__ __launch_bounds__(WAVE) void k_dec_front(BatchArgs a, DecWs ws, int base)
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(PHASE ? 8 : 4))) void k_dec_front(BatchArgs a, DecWs ws, int base)
 {
     __shared__ FrontShared S;
     __shared__ struct {
