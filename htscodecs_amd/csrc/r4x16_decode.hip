@@ -1572,6 +1572,8 @@ __global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDes
 // that would start past the end of the run stream reads as 0 (varint.h:136), of any length otherwise.
 // ---------------------------------------------------------------------------------------------
 #define BACK_THREADS 256u
+#define BACK_FIFO 128u
+#define BACK_FEED 1024u
 struct BackShared {
     u8  is_rle[256];
     u32 scan_a[BACK_THREADS + 1];      // varint ends before each run chunk (+ total)
@@ -1580,7 +1582,6 @@ struct BackShared {
     u64 wave_tot64[8];
     u32 err;
     u8  map[16];
-    u32 vals[WAVE];                    // (the one-wave route's exchange buffer)
 };
 
 // exclusive prefix sum over the workgroup (every thread calls); *total = the sum
@@ -1789,106 +1790,217 @@ __device__ bool rle_expand_wg(const u8 *lit, u32 lit_len, const u8 *runs, u32 ru
 }
 
 // ---------------------------------------------------------------------------------------------
-// Run-length expansion, rle.c:142-187, by one wave (the route of LARGE batches: about 3.5 instruction issues per literal
-// and block, every block resident at once - with thousands of blocks that is as good as the wave slots allow).  64 literals per trip: the run varints of the
-// RLE-symbol literals are matched to them by rank (k-th RLE literal <-> k-th varint), lengths are
-// prefix-summed, and the output bytes are written balanced over the lanes (each output byte finds
-// its literal by binary search over the trip's 64 prefix sums).
+// Run-length expansion, rle.c:142-187, by one wave: the route of LARGE batches (every block resident at once; with
+// thousands of blocks the wave slots are full and what counts is instruction issues per literal).  64 literals per
+// trip.  Round 2's trip matched run lengths to literals straight from the run stream: a load whose address is this
+// trip's result (the cursor), two barriers, and a byte store per lane and run byte - 18.6 ms for 4,096 x 1 MiB q8 blocks,
+// 13.7 of them with the stores removed: the trip was a chain of memory latencies.  Round 3:
+//   producer  the run stream is decoded 60 bytes at a time, in stream order and whatever the literals are, into a ring of
+//             values in LDS (a varint's value is a function of its last five bytes: four bytes of history travel with
+//             each batch) - its loads have addresses known trips ahead and are requested two batches ahead;
+//   consumer  the k-th run-length literal takes the k-th value of the ring (varint.h:136: 0 once the stream has run out);
+//   output    by OUTPUT position, a dword per lane and 256 bytes per pass: the lanes mark where their literals start
+//             in an LDS tile, a prefix maximum over the marks names the literal every byte belongs to, ds_bpermute
+//             fetches the values; a pass without any mark lies inside one run and is a plain fill.  Up to three
+//             bytes that do not fill a dword wait for the next trip, so every store is a whole dword.
+// A trip with a run of 2^24 bytes or more (prefix sums beyond 32 bits; only a hostile stream or a giant block has one)
+// takes the plain route: byte stores, 64-bit sums.
 // ---------------------------------------------------------------------------------------------
-__device__ bool rle_expand_wave(const u8 *lit, u32 lit_len, const u8 *runs, u32 run_len, const u8 *syms,
-                           u32 nsyms, u8 *out, u32 cap, u32 &produced, BackShared &B, u32 lane)
+typedef u32 u32_unaligned __attribute__((aligned(1)));
+__device__ __forceinline__ u32 wave_incl_max(u32 v)
 {
+    v = max(v, dpp_row<0x111, 0xf>(v));
+    v = max(v, dpp_row<0x112, 0xf>(v));
+    v = max(v, dpp_row<0x114, 0xf>(v));
+    v = max(v, dpp_row<0x118, 0xf>(v));
+    v = max(v, dpp_row<0x142, 0xa>(v));
+    v = max(v, dpp_row<0x143, 0xc>(v));
+    return v;
+}
+__device__ __forceinline__ u32 wave_shr1(u32 v) { return dpp_row<0x138, 0xf>(v); }   // lane l reads lane l-1, lane 0 reads 0
+
+__device__ __forceinline__ u32 uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+template <class T> __device__ __forceinline__ T *uni_ptr(T *p)
+{
+    const u64 a = (u64)p;
+    return (T *)(((u64)uni((u32)(a >> 32)) << 32) | uni((u32)a));
+}
+
+__device__ bool rle_expand_wave(const u8 *lit_, u32 lit_len_, const u8 *runs_, u32 run_len_, const u8 *syms,
+                           u32 nsyms, u8 *out_, u32 cap_, u32 &produced, BackShared &B, u32 lane)
+{
+    // the arguments come out of the block's header, loaded by every lane: the compiler cannot know that they are the
+    // same in all of them, and would keep the cursors below in vector registers and every branch on the execution mask
+    // (and wait for the loads at their first use - inside the trip, where the wait also covers the trip's prefetches)
+    const u8 *lit = uni_ptr(lit_), *runs = uni_ptr(runs_);
+    u8 *out = uni_ptr(out_);
+    const u32 lit_len = uni(lit_len_), run_len = uni(run_len_), cap = uni(cap_);
     for (u32 j = lane; j < 256; j += WAVE) B.is_rle[j] = 0;
     __syncthreads();
     for (u32 j = lane; j < nsyms; j += WAVE) B.is_rle[syms[j]] = 1;
     __syncthreads();
 
-    u64 outp = 0;
-    u32 rp = 0;
-    bool err = false;
     const u64 lane_below = (1ull << lane) - 1ull;
-    // Both inputs are requested ahead of their use - the literals of the next two trips, the run bytes at the cursor as
-    // soon as the cursor moves - so that a trip does not begin with one or two dependent trips to memory (one wave per
-    // block: nothing else hides them; 6.3 ms for 4,096 x 1 MiB q4 blocks with X_PACK|X_RLE before).
     gcu8 *glit = to_global(lit), *gruns = to_global(runs);
-    u32 lit1 = lane < lit_len ? glit[lane] : 0u, lit2 = WAVE + lane < lit_len ? glit[WAVE + lane] : 0u;
-    u32 cnext = lane < run_len ? gruns[lane] : 0u;        // runs[rp + lane]
-    for (u32 base = 0; base < lit_len && !err; base += WAVE) {
+    gu8 *gout = to_global(out);
+    // (this route's buffers live in its own kernel only, like the workgroup route's tile)
+    __shared__ __attribute__((aligned(16))) u8 litbuf[BACK_FEED];        // the literals of sixteen trips
+    __shared__ __attribute__((aligned(16))) u8 rring[2 * BACK_FEED];     // the run stream around the producer's cursor
+    __shared__ u32 fifo[BACK_FIFO];                                      // run lengths decoded ahead of the literals
+    __shared__ u32 tile[WAVE];                                           // where literals start within 256 bytes of output
+    u8 *tile8 = (u8 *)tile;
+
+    // Both inputs reach the trips through LDS, a KiB at a time (sixteen bytes per lane, requested one refill ahead):
+    // a load per trip, however far ahead it is requested, makes the trip wait for ALL memory operations in flight at the
+    // first use of what it loaded - the counter is in order and the number of stores behind it is not known to the
+    // compiler - i.e. for the request it has just made (measured: 12.4 ms for the 4,096 q8 blocks that way).
+    auto load16 = [&](gcu8 *g, u32 at, u32 len) -> u32x4 {               // bytes [at + 16 lane, + 16) of a stream of len bytes
+        const u32 o = at + 16u * lane;
+        u32x4 v = {0, 0, 0, 0};
+        if (o + 16u <= len) v = *(GAS const u32x4_unaligned *)(g + o);
+        else if (o < len) {
+            u32 w[4] = {0, 0, 0, 0};
+            for (u32 c = 0; o + c < len; c++) w[c >> 2] |= (u32)g[o + c] << (8 * (c & 3));
+            v = u32x4{w[0], w[1], w[2], w[3]};
+        }
+        return v;
+    };
+
+    // producer: batch q covers run bytes [q - 4, q + 60); lanes 0-3 carry history (before the stream: "a varint ended here")
+    u32 rq = 0, made = 0, used = 0;                       // bytes decoded; values decoded / handed out
+    u32 rl = 0;                                           // run bytes in the ring
+    u32x4 rpre = load16(gruns, 0, run_len);
+    auto produce = [&]() {
+        if (rq + 60u > rl) {                              // (the half written held bytes before rq - 4)
+            *(u32x4 *)(rring + (rl & BACK_FEED) + 16u * lane) = rpre;
+            rl += BACK_FEED;
+            rpre = load16(gruns, rl, run_len);
+        }
+        const u32 p = rq + lane - 4u;
+        const bool have = p < run_len;
+        const u32 c = have ? (u32)rring[p & (2u * BACK_FEED - 1u)] : 0u;
+        const bool isend = (int)p < 0 || (have && (!(c & 0x80u) || p == run_len - 1u));
+        const u64 Eall = __ballot(isend);
+        const u64 prevE = Eall & lane_below;
+        const u32 start = prevE ? 64u - (u32)__clzll(prevE) : 0u;     // the lane of this varint's first byte
+        u32 v = c & 0x7fu, cd = c;
+#pragma unroll
+        for (int dd = 1; dd <= 4; dd++) {
+            cd = wave_shr1(cd);
+            if (lane >= start + (u32)dd) v |= (cd & 0x7fu) << (7 * dd);
+        }
+        const u64 E = Eall & ~0xfull;
+        if (isend && lane >= 4u) fifo[(made + (u32)__popcll(E & lane_below)) & (BACK_FIFO - 1u)] = v;
+        made += (u32)__popcll(E);
+        rq += 60u;
+    };
+
+    u64 outp = 0;                                         // bytes expanded so far
+    u32 cb = 0, carry_w = 0;                              // of which the last cb (< 4) wait in carry_w for their dword
+    bool err = false;
+    u32x4 lpre = load16(glit, 0, lit_len);
+    u32 bnext = 0, fnext = 0;                             // the next trip's literal and whether it is a run-length symbol
+    auto fetch = [&](u32 at) {                            // ... of the trip at literal `at` (< lit_len)
+        if ((at & (BACK_FEED - 1u)) == 0) {               // (everything read from the buffer so far has been read: one wave, LDS in order)
+            *(u32x4 *)(litbuf + 16u * lane) = lpre;
+            lpre = load16(glit, at + BACK_FEED, lit_len);
+        }
+        bnext = litbuf[(at & (BACK_FEED - 1u)) + lane];
+        fnext = B.is_rle[bnext];
+    };
+    if (lit_len) fetch(0);
+    for (u32 base = 0; base < lit_len; base += WAVE) {
         const u32 i = base + lane;
         const bool valid = i < lit_len;
-        const u32 bval = lit1;
-        lit1 = lit2;
-        lit2 = i + 2 * WAVE < lit_len ? glit[i + 2 * WAVE] : 0u;
-        const bool r = valid && B.is_rle[bval];
+        const u32 bval = bnext;
+        const bool r = valid && fnext;
+        if (base + WAVE < lit_len) fetch(base + WAVE);
         const u64 rmask = __ballot(r);
         const u32 nr = (u32)__popcll(rmask), myrank = (u32)__popcll(rmask & lane_below);
-        u32 got = 0, runval = 0;
-        while (got < nr && rp < run_len) {                 // past the end a varint reads as 0 (varint.h:136)
-            const u32 p = rp + lane;
-            const bool have = p < run_len;
-            const u32 c = cnext;
-            const bool isend = have && (!(c & 0x80u) || p == run_len - 1);
-            const u64 E = __ballot(isend);
-            if (!E) { err = true; break; }                 // a "varint" of 64+ bytes: never produced by an encoder
-            const u64 prevE = E & lane_below;
-            const u32 start = prevE ? 64u - (u32)__clzll(prevE) : 0u;
-            u32 v = c & 0x7fu;
-#pragma unroll
-            for (int dd = 1; dd <= 4; dd++) {
-                const u32 cd = __shfl_up(c, dd);
-                if (lane >= start + (u32)dd) v |= (cd & 0x7fu) << (7 * dd);
-            }
-            const u32 erank = (u32)__popcll(prevE);
-            const u32 navail = (u32)__popcll(E);
-            const u32 ntake = navail < nr - got ? navail : nr - got;
-            if (isend && erank < ntake) B.vals[erank] = v;
-            __syncthreads();
-            if (r && myrank >= got && myrank < got + ntake) runval = B.vals[myrank - got];
-            const u64 lastm = __ballot(isend && erank == ntake - 1);
-            rp += (u32)__ffsll((unsigned long long)lastm);   // index of that lane + 1
-            cnext = rp + lane < run_len ? gruns[rp + lane] : 0u;
-            got += ntake;
-            __syncthreads();
-        }
-        if (err) break;
-        const u64 len = valid ? 1ull + runval : 0ull;
-        // exclusive prefix of lengths (64-bit sums only when a run is long enough for sixty-four of them to pass 2^32: a
-        // hostile run can be 4 GiB)
-        u64 incl = len;
-        if (!__ballot(runval > 0x00ffffffu)) incl = wave_incl_scan((u32)len, lane);
-        else {
+        while (made - used < nr && rq < run_len) produce();            // (at most 63 values wait: 63 + 60 fit the ring)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");         // one wave: its LDS operations complete in order
+        const u32 avail = made - used;
+        const u32 runval = (r && myrank < avail) ? fifo[(used + myrank) & (BACK_FIFO - 1u)] : 0u;
+        used += nr < avail ? nr : avail;
+
+        if (__ballot(runval > 0x00ffffffu)) {
+            // ---- the plain route of a trip with a giant run
+            for (u32 k = lane; k < cb; k += WAVE) gout[outp - cb + k] = (u8)(carry_w >> (8 * k));
+            cb = 0;
+            const u64 len = valid ? 1ull + runval : 0ull;
+            u64 incl = len;
 #pragma unroll
             for (int dd = 1; dd < WAVE; dd <<= 1) {
                 const u64 tt = __shfl_up(incl, dd);
                 if (lane >= (u32)dd) incl += tt;
             }
+            const u64 excl = incl - len;
+            const u64 total = __shfl(incl, WAVE - 1);
+            const u64 oi = outp + excl;
+            const bool bad = valid && (oi >= cap || (runval && oi + runval >= cap));     // rle.c:165, :173
+            if (__ballot(bad)) { err = true; break; }
+            u8 *o = out + oi;
+            if (valid) o[0] = (u8)bval;
+            if (runval && runval <= 24u)
+                for (u32 k = 1; k <= runval; k++) o[k] = (u8)bval;
+            u64 longm = __ballot(runval > 24u);
+            while (longm) {
+                const int src = __ffsll((unsigned long long)longm) - 1;
+                longm &= longm - 1;
+                const u64 at = __shfl(excl, src);
+                const u32 len1 = (u32)__shfl((int)runval, src), bv = (u32)__shfl((int)bval, src);
+                u8 *ro = out + outp + at + 1;
+                for (u32 k = lane; k < len1; k += WAVE) ro[k] = (u8)bv;
+            }
+            outp += total;
+            continue;
         }
-        const u64 excl = incl - len;
-        const u64 total = __shfl(incl, WAVE - 1);
-        const u64 oi = outp + excl;
-        // rle.c:165, :173: every literal needs room, a run needs room for all of it
-        const bool bad = valid && (oi >= cap || (runval && oi + runval >= cap));
-        if (__ballot(bad)) { err = true; break; }
-        // Every lane writes its own literal and, when its run is short (nearly all are: quality data has runs of a few
-        // bytes), the run behind it; the few long runs are then filled by the whole wave, one after the other.
-        // (The first version balanced every output byte over the lanes by a binary search over the trip's prefix
-        //  sums: six dependent LDS reads per byte, ~85 % of this kernel on q4 with X_PACK|X_RLE.)
-        u8 *o = out + outp + excl;
-        const u32 rv = valid ? runval : 0u;
-        if (valid) o[0] = (u8)bval;
-        if (rv && rv <= 24u)
-            for (u32 k = 1; k <= rv; k++) o[k] = (u8)bval;
-        u64 longm = __ballot(rv > 24u);
-        while (longm) {
-            const int src = __ffsll((unsigned long long)longm) - 1;
-            longm &= longm - 1;
-            const u64 at = __shfl(excl, src);
-            const u32 len = (u32)__shfl((int)rv, src), bv = (u32)__shfl((int)bval, src);
-            u8 *ro = out + outp + at + 1;
-            for (u32 k = lane; k < len; k += WAVE) ro[k] = (u8)bv;
+
+        const u32 len = valid ? 1u + runval : 0u;
+        const u32 incl = wave_incl_scan(len, lane);
+        const u32 excl = incl - len;
+        const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
+        // rle.c:165, :173: every literal needs room, a run needs room for all of it.  Positions rise with the lane, so the
+        // trip's last byte decides for all of them (a literal at o needs o < cap, its run o + run < cap).
+        if (outp + total > cap) { err = true; break; }
+
+        // the trip's bytes behind the cb carried ones, as dwords from out + ob
+        gu8 *ob = gout + (outp - cb);
+        const u32 nbytes = cb + total, W = nbytes >> 2;
+        const u32 e = cb + excl;                           // where this lane's literal starts
+        const u32 keep = cb ? ~0u << (8 * cb) : ~0u;      // chunk 0, lane 0: the bytes that are new
+        u32 next_carry = 0;
+        for (u32 P0 = 0; P0 < nbytes; P0 += 256u) {
+            const u64 inm = __ballot(valid && e - P0 < 256u);
+            const u32 nbefore = (u32)__popcll(__ballot(valid && e < P0));        // (the valid lanes are the low ones, e rises with the lane)
+            u32 w;
+            if (!inm) w = (u32)__builtin_amdgcn_readlane((int)bval, (int)nbefore - 1) * 0x01010101u;   // inside one run
+            else {
+                tile[lane] = 0;
+                if (valid && e - P0 < 256u) tile8[e - P0] = (u8)(lane + 1u);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const u32 t = tile[lane];
+                u32 m0 = t & 0xffu, m1 = max(m0, (t >> 8) & 0xffu), m2 = max(m1, (t >> 16) & 0xffu), m3 = max(m2, t >> 24);
+                const u32 pre = max(wave_shr1(wave_incl_max(m3)), nbefore);
+                m0 = max(m0, pre); m1 = max(m1, pre); m2 = max(m2, pre); m3 = max(m3, pre);
+                const u32 v0 = (u32)__builtin_amdgcn_ds_bpermute((int)(m0 - 1u) << 2, (int)bval);
+                const u32 v1 = (u32)__builtin_amdgcn_ds_bpermute((int)(m1 - 1u) << 2, (int)bval);
+                const u32 v2 = (u32)__builtin_amdgcn_ds_bpermute((int)(m2 - 1u) << 2, (int)bval);
+                const u32 v3 = (u32)__builtin_amdgcn_ds_bpermute((int)(m3 - 1u) << 2, (int)bval);
+                w = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // the tile is rewritten by the next pass
+            }
+            if (P0 == 0 && lane == 0) w = (w & keep) | (carry_w & ~keep);
+            const u32 d = (P0 >> 2) + lane;
+            if (d < W) *(GAS u32_unaligned *)(ob + 4ull * d) = w;
+            if ((W >> 6) == (P0 >> 8)) next_carry = (u32)__builtin_amdgcn_readlane((int)w, (int)(W & 63u));
         }
+        carry_w = next_carry;
+        cb = nbytes & 3u;
         outp += total;
     }
+    if (!err)
+        for (u32 k = lane; k < cb; k += WAVE) gout[outp - cb + k] = (u8)(carry_w >> (8 * k));
     produced = (u32)outp;
     return !err;
 }

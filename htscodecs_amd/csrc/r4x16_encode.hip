@@ -105,6 +105,7 @@ struct EncShared {
     i32 status;
     u32 pk_n, pk_meta_len, pk_len;       // wg_pack results
     u32 rl_nsyms, rl_lits, rl_runs;      // wg_rle_split results
+    u32 sel4[16];        // wg_rle_split: v_perm selectors that move the bytes of a 4-bit mask to the bottom of a dword
 };
 
 // A block's order-1 pair counters in global memory (alphabets beyond the LDS limit count there; all are handed from
@@ -342,23 +343,46 @@ __device__ void enc_o0_front(const u8 *data, u32 n, u8 *tab, u8 *image, EncShare
 
 // `priv`: 16 x 256 scratch counters; threads spread over 16 private copies (tid & 15) so that the
 // few hot symbols of quality data do not serialise the LDS atomics of a whole wave.
-__device__ __forceinline__ void wg_hist8(const u8 *data, u32 n, u32 *Fout, u32 *priv, u32 tid)
+// 16-bit masks over a 16-byte piece (bit c = byte c), computed on the four dwords at once.
+// zero bytes of x -> bits 0..3
+__device__ __forceinline__ u32 zero_bytes4(u32 x)
+{
+    const u32 nz = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;   // bit 7 of every non-zero byte
+    const u32 t = (nz ^ 0x80808080u) >> 7;                                  // bits 0, 8, 16, 24 for the zero bytes
+    const u32 u = t | (t >> 7);
+    return (u | (u >> 14)) & 15u;
+}
+// bytes equal to the byte before them (`before` for byte 0; 256 and more: byte 0 has no predecessor)
+__device__ __forceinline__ u32 eq_prev_mask16(u32x4 v, u32 before)
+{
+    const u32 s0 = (v.x << 8) | (before & 0xffu), s1 = __builtin_amdgcn_alignbyte(v.y, v.x, 3),
+              s2 = __builtin_amdgcn_alignbyte(v.z, v.y, 3), s3 = __builtin_amdgcn_alignbyte(v.w, v.z, 3);
+    const u32 m = zero_bytes4(v.x ^ s0) | (zero_bytes4(v.y ^ s1) << 4) | (zero_bytes4(v.z ^ s2) << 8) | (zero_bytes4(v.w ^ s3) << 12);
+    return before > 255u ? m & ~1u : m;
+}
+template <bool REP>
+__device__ __forceinline__ void wg_hist8_t(const u8 *data, u32 n, u32 *Fout, u32 *Rout, u32 *priv, u32 tid)
 {
     // (copy stride 257 dwords: each copy starts one LDS bank further; with 256 all sixteen sat on the same banks)
-    for (u32 j = tid; j < 16 * 257; j += FRONT_THREADS) priv[j] = 0;
+    for (u32 j = tid; j < (REP ? 32 : 16) * 257; j += FRONT_THREADS) priv[j] = 0;
     __syncthreads();
     u32 *F = priv + 257 * (tid & 15);
+    u32 *R = F + 16 * 257;                               // REP: bytes that repeat the byte before them (rle.c:60-72)
     // 16-byte pieces, four in flight per thread (each is requested three pieces before it is counted: the
     // passes are memory-latency bound otherwise, eight waves per CU cannot hide an HBM round trip per piece)
     const u32 full = n >> 4;
-    auto ld = [&](u32 pi) -> u32x4 {
-        u32x4 v = {0, 0, 0, 0};
-        if (pi < full) v = *(GAS const u32x4_unaligned *)(to_global(data) + 16ull * pi);
-        return v;
+    struct Pc { u32x4 v; u32 before; };
+    auto ld = [&](u32 pi) -> Pc {
+        Pc r = {{0, 0, 0, 0}, 256u};
+        if (pi < full) {
+            r.v = *(GAS const u32x4_unaligned *)(to_global(data) + 16ull * pi);
+            if (REP && pi) r.before = to_global(data)[16ull * pi - 1];
+        }
+        return r;
     };
-    auto count = [&](u32x4 w, u32 pi) {
+    auto count = [&](const Pc &q, u32 pi) {
         if (pi >= full) return;
-        const u32 ww[4] = {w.x, w.y, w.z, w.w};
+        const u32 ww[4] = {q.v.x, q.v.y, q.v.z, q.v.w};
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             atomicAdd(&F[ww[c] & 0xff], 1u);
@@ -366,9 +390,15 @@ __device__ __forceinline__ void wg_hist8(const u8 *data, u32 n, u32 *Fout, u32 *
             atomicAdd(&F[(ww[c] >> 16) & 0xff], 1u);
             atomicAdd(&F[ww[c] >> 24], 1u);
         }
+        if (REP) {
+            const u32 eq = eq_prev_mask16(q.v, q.before);
+#pragma unroll
+            for (int c = 0; c < 16; c++)
+                if ((eq >> c) & 1u) atomicAdd(&R[(ww[c >> 2] >> (8 * (c & 3))) & 0xff], 1u);
+        }
     };
     const u32 T = FRONT_THREADS;
-    u32x4 q0 = ld(tid), q1 = ld(tid + T), q2 = ld(tid + 2 * T), q3 = ld(tid + 3 * T);
+    Pc q0 = ld(tid), q1 = ld(tid + T), q2 = ld(tid + 2 * T), q3 = ld(tid + 3 * T);
     for (u32 pi = tid; pi < full; pi += 4 * T) {
         count(q0, pi);         q0 = ld(pi + 4 * T);
         count(q1, pi + T);     q1 = ld(pi + 5 * T);
@@ -376,15 +406,24 @@ __device__ __forceinline__ void wg_hist8(const u8 *data, u32 n, u32 *Fout, u32 *
         count(q3, pi + 3 * T); q3 = ld(pi + 7 * T);
     }
     const u32 done = full * 16;
-    if (done + tid < n) atomicAdd(&F[data[done + tid]], 1u);
-    __syncthreads();
-    {
-        u32 t = 0;
-#pragma unroll
-        for (int c = 0; c < 16; c++) t += priv[257 * c + tid];
-        Fout[tid] = t;                                   // FRONT_THREADS == 256
+    if (done + tid < n) {
+        const u32 b = data[done + tid];
+        atomicAdd(&F[b], 1u);
+        if (REP && done + tid && data[done + tid - 1] == b) atomicAdd(&R[b], 1u);
     }
     __syncthreads();
+    {
+        u32 t = 0, r = 0;
+#pragma unroll
+        for (int c = 0; c < 16; c++) { t += priv[257 * c + tid]; if (REP) r += priv[257 * (16 + c) + tid]; }
+        Fout[tid] = t;                                   // FRONT_THREADS == 256
+        if (REP) Rout[tid] = r;
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void wg_hist8(const u8 *data, u32 n, u32 *Fout, u32 *priv, u32 tid)
+{
+    wg_hist8_t<false>(data, n, Fout, nullptr, priv, tid);
 }
 
 // present8 (utils.h:108-131): which byte values occur.  Order-1 needs only that of the byte histogram, and
@@ -704,9 +743,42 @@ struct ByteOut {
     }
     __device__ __forceinline__ void put_var(u32 v)          // var_put_u32, varint.h:85-104
     {
+        if (v < 128u) { put(v); return; }
         u32 groups = 1;
         for (u32 t = v >> 7; t; t >>= 7) groups++;
         for (u32 g = groups; g-- > 0; ) put(((v >> (7 * g)) & 0x7f) | (g ? 0x80u : 0u));
+    }
+};
+
+// The same stream fed up to four bytes at a time (wg_rle_split's literals: the bytes a 4-bit mask picks from a dword, already
+// moved to the bottom of `bytes`): twenty bytes in five registers, the newest in the top byte of a4; every move is a
+// v_perm_b32 of two neighbours with a computed selector - no loop over the bytes, the same instructions whatever the mask.
+struct PieceOut {
+    gu8 *p;
+    u32 a0, a1, a2, a3, a4;
+    u32 cnt;             // bytes not yet stored (< 16 between calls)
+    __device__ __forceinline__ void append(u32 bytes, u32 c)          // c <= 4
+    {
+        const u32 sel = 0x03020100u + c * 0x01010101u;                // bytes c .. c + 3 of a register pair
+        a0 = __builtin_amdgcn_perm(a1, a0, sel);
+        a1 = __builtin_amdgcn_perm(a2, a1, sel);
+        a2 = __builtin_amdgcn_perm(a3, a2, sel);
+        a3 = __builtin_amdgcn_perm(a4, a3, sel);
+        a4 = __builtin_amdgcn_perm(bytes, a4, sel);
+        cnt += c;
+        if (cnt >= 16u) {                                             // the oldest sixteen start at byte 20 - cnt (1 .. 4)
+            const u32 so = 0x03020100u + (20u - cnt) * 0x01010101u;
+            const u32x4 o = {__builtin_amdgcn_perm(a1, a0, so), __builtin_amdgcn_perm(a2, a1, so),
+                             __builtin_amdgcn_perm(a3, a2, so), __builtin_amdgcn_perm(a4, a3, so)};
+            *(GAS u32x4_unaligned *)p = o;
+            p += 16; cnt -= 16u;
+        }
+    }
+    __device__ __forceinline__ void flush()
+    {
+        const u32 w[5] = {a0, a1, a2, a3, a4};
+        for (u32 k = 0; k < cnt; k++) { const u32 at = 20u - cnt + k; p[k] = (u8)(w[at >> 2] >> (8u * (at & 3u))); }
+        p += cnt; cnt = 0;
     }
 };
 
@@ -719,23 +791,6 @@ __device__ __forceinline__ u32 var_put_g(gu8 *cp, u32 v)
     return groups;
 }
 
-// 16-bit masks over a 16-byte piece (bit c = byte c), computed on the four dwords at once.
-// zero bytes of x -> bits 0..3
-__device__ __forceinline__ u32 zero_bytes4(u32 x)
-{
-    const u32 nz = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;   // bit 7 of every non-zero byte
-    const u32 t = (nz ^ 0x80808080u) >> 7;                                  // bits 0, 8, 16, 24 for the zero bytes
-    const u32 u = t | (t >> 7);
-    return (u | (u >> 14)) & 15u;
-}
-// bytes equal to the byte before them (`before` for byte 0; 256 and more: byte 0 has no predecessor)
-__device__ __forceinline__ u32 eq_prev_mask16(u32x4 v, u32 before)
-{
-    const u32 s0 = (v.x << 8) | (before & 0xffu), s1 = __builtin_amdgcn_alignbyte(v.y, v.x, 3),
-              s2 = __builtin_amdgcn_alignbyte(v.z, v.y, 3), s3 = __builtin_amdgcn_alignbyte(v.w, v.z, 3);
-    const u32 m = zero_bytes4(v.x ^ s0) | (zero_bytes4(v.y ^ s1) << 4) | (zero_bytes4(v.z ^ s2) << 8) | (zero_bytes4(v.w ^ s3) << 12);
-    return before > 255u ? m & ~1u : m;
-}
 // bytes whose flag in an LDS table of 256 bytes is set
 __device__ __forceinline__ u32 flag_mask16(u32x4 v, const u8 *flags)
 {
@@ -751,45 +806,22 @@ __device__ __forceinline__ u32 byte_of16(u32x4 v, u32 c)
     return (((c & 8u) ? hi : lo) >> (8u * (c & 3u))) & 0xffu;
 }
 
-// rle_encode with automatic symbol choice, rle.c:48-138.  S.F holds the byte histogram.  The repeat
-// counts and the split are taken by all threads, each on its own chunk of the input.  `tiles`: 5 KB of LDS.
+// rle_encode with automatic symbol choice, rle.c:48-138.  S.F holds the byte histogram, S.T the repeats per symbol.  The repeat
+// counts and the split are taken by all threads, each on its own chunk of the input.  `tiles`: RLE_LDS_BYTES of LDS.
 // Results: S.rl_nsyms, S.rl_lits, S.rl_runs (bytes); symbols in S.alpha[0..nsyms).  Ends on a workgroup barrier.
-#define RLE_TILE 16384u
+#define RLE_SLOTS_AT 5120u
+#define RLE_SLOT_BYTES 80u
+#define RLE_LDS_BYTES (32u * 257u * 4u)                 // wg_hist8_t<true>'s counters; the split's slots need RLE_SLOTS_AT + 256 * RLE_SLOT_BYTES
 __device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, EncShared &S, u8 *tiles, u32 tid)
 {
     const u32 lane = tid & (WAVE - 1);
     PROF_INIT;
-    u32 *rep = S.T;                                      // repeats per symbol
-    rep[tid] = 0;                                        // FRONT_THREADS == 256
-    __syncthreads();
-    {
-        // rep[b] = positions whose byte repeats the one before: per 16-byte piece the mask of such positions, one LDS
-        // atomic per run of them (the first version walked the bytes one by one: 0.5 ms per MiB)
-        const u32 pieces = (n + 15) >> 4;
-        struct Pc { u32x4 v; u32 before; };
-        auto piece = [&](u32 pi) -> Pc {
-            Pc r = {{0, 0, 0, 0}, 256u};
-            const u32 off = pi * 16;
-            if (pi >= pieces) return r;
-            if (n - off >= 16) r.v = *(GAS const u32x4_unaligned *)(to_global(data) + off);
-            else { u32 w[4] = {0, 0, 0, 0}; for (u32 c = 0; c < n - off; c++) w[c >> 2] |= (u32)to_global(data)[off + c] << (8 * (c & 3)); r.v = u32x4{w[0], w[1], w[2], w[3]}; }
-            if (off) r.before = to_global(data)[off - 1];
-            return r;
-        };
-        Pc ahead = piece(tid);
-        for (u32 pi = tid; pi < pieces; pi += FRONT_THREADS) {
-            const u32 off = pi * 16;
-            const u32 cnt = n - off < 16 ? n - off : 16;
-            const Pc cur_p = ahead;
-            ahead = piece(pi + FRONT_THREADS);
-            u32 eq = eq_prev_mask16(cur_p.v, cur_p.before) & ((1u << cnt) - 1u);
-            while (eq) {
-                const u32 at = (u32)__ffs((int)eq) - 1u;
-                const u32 run = (u32)__ffs((int)~(eq >> at)) - 1u;            // ones from `at` on (at most 16)
-                atomicAdd(&rep[byte_of16(cur_p.v, at)], run);
-                eq &= ~(((1u << run) - 1u) << at);
-            }
-        }
+    const u32 *rep = S.T;                                // repeats per symbol: counted with the histogram (wg_hist8_t<true>)
+    if (tid < 16) {                                      // selector byte j = the j-th set bit of the mask (0x0c: a zero byte)
+        u32 sel = 0, j = 0;
+        for (u32 bit = 0; bit < 4; bit++) if ((tid >> bit) & 1u) sel |= bit << (8 * j++);
+        for (; j < 4; j++) sel |= 0x0cu << (8 * j);
+        S.sel4[tid] = sel;
     }
     __syncthreads();
     PROF(11);
@@ -817,31 +849,41 @@ __device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, 
     // lane on its own branch: 2.3 ms per MiB for both walks).
     // (The first version swept 16 KB LDS tiles from the top with five workgroup barriers per tile: 1.2 ms per 256 KiB.)
     u32 *cF = (u32 *)tiles, *cL = cF + 256, *cV = cL + 256, *cP = cV + 256, *cN = cP + 256;   // first / literals / run bytes / open run / next literal
+    u8 *slot = tiles + RLE_SLOTS_AT + tid * RLE_SLOT_BYTES;                           // this thread's 64 bytes of input (stride 80: no two of eight lanes on one bank)
     const u32 NONE = 0xffffffffu;
     const u32 csz = ((n + FRONT_THREADS - 1) / FRONT_THREADS + 15u) & ~15u;            // chunk bytes, a multiple of 16
     const u32 c0 = tid * csz < n ? tid * csz : n, c1 = c0 + csz < n ? c0 + csz : n;
     // one walk; EMIT = false: count, EMIT = true: write at (lp, vp).  `open` = position of the RLE-symbol literal whose run is running.
     auto walk = [&](auto emitc, u32 &nlit, u32 &first, u32 &vbytes, u32 &open, gu8 *lp, gu8 *vp) {
         constexpr bool EMIT = decltype(emitc)::value;
-        ByteOut lo{lp, {0, 0, 0, 0}, 0}, vo{vp, {0, 0, 0, 0}, 0};
+        PieceOut lo{lp, 0, 0, 0, 0, 0, 0};
+        ByteOut vo{vp, {0, 0, 0, 0}, 0};
         u32 prev = c0 ? to_global(data)[c0 - 1] : 256u;
-        // a thread's pieces are consecutive, so their loads are dependent round trips to memory unless the next one
-        // is requested before this one is looked at
-        auto piece = [&](u32 p0) -> u32x4 {
+        // A thread's pieces are consecutive: four at a time (64 bytes) come through the thread's own LDS slot, requested
+        // one refill before they are looked at.  (Round 2 requested the next piece at the top of every trip: with stores
+        // in flight behind it - their number unknown to the compiler, the counter in order - the first use of the piece
+        // in hand waited for everything, the request just made included: a trip to memory per 16 bytes, 1.3 ms per
+        // 1 MiB q8 block in the writing walk.)
+        auto piece = [&](u32 q) -> u32x4 {
             u32x4 v = {0, 0, 0, 0};
-            if (p0 + 16 <= c1) v = *(GAS const u32x4_unaligned *)(to_global(data) + p0);
-            else if (p0 < c1) {
+            if (q + 16 <= c1) v = *(GAS const u32x4_unaligned *)(to_global(data) + q);
+            else if (q < c1) {
                 u32 w[4] = {0, 0, 0, 0};
-                for (u32 c = 0; c < c1 - p0; c++) w[c >> 2] |= (u32)to_global(data)[p0 + c] << (8 * (c & 3));
+                for (u32 c = 0; c < c1 - q; c++) w[c >> 2] |= (u32)to_global(data)[q + c] << (8 * (c & 3));
                 v = u32x4{w[0], w[1], w[2], w[3]};
             }
             return v;
         };
-        u32x4 ahead = piece(c0);
+        u32x4 n0 = piece(c0), n1 = piece(c0 + 16), n2 = piece(c0 + 32), n3 = piece(c0 + 48);
         for (u32 p0 = c0; p0 < c1; p0 += 16) {
             const u32 cnt = c1 - p0 < 16 ? c1 - p0 : 16;
-            const u32x4 v = ahead;
-            ahead = piece(p0 + 16);
+            const u32 ph = (p0 - c0) & 63u;
+            if (ph == 0) {
+                u32x4 *sl = (u32x4 *)slot;
+                sl[0] = n0; sl[1] = n1; sl[2] = n2; sl[3] = n3;
+                n0 = piece(p0 + 64); n1 = piece(p0 + 80); n2 = piece(p0 + 96); n3 = piece(p0 + 112);
+            }
+            const u32x4 v = *(const u32x4 *)(slot + ph);
             const u32 valid = (1u << cnt) - 1u;
             const u32 P = flag_mask16(v, S.present);                       // positions holding an RLE symbol
             const u32 L = valid & ~(eq_prev_mask16(v, prev) & P);          // literals
@@ -855,15 +897,26 @@ __device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, 
                 vbytes += (u32)__popc(L & P & ~(1u << hi));                // runs that begin and end inside the piece: one byte each
                 open = ((P >> hi) & 1u) ? p0 + hi : NONE;
             } else {
-                u32 m = L;
+                // the literals: what L picks from each dword, moved to its bottom by a selector looked up under the
+                // four mask bits; the run stream: the run open at the piece's first literal ends there, every RLE-symbol
+                // literal but the piece's last has its run inside the piece (0 .. 14 repeats: one byte)
+                // (round 2 looped over the literals one by one, every lane on its own count: 1.35 of k_enc_front's
+                //  2.5 ms per 1 MiB q8 block)
+                const u32 f = (u32)__ffs((int)L) - 1u, hi = 31u - (u32)__clz((int)L);
+                if (open != NONE) vo.put_var(p0 + f - open - 1u);
+                const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const u32 Lk = (L >> (4 * k)) & 15u;
+                    lo.append(__builtin_amdgcn_perm(0u, w[k], S.sel4[Lk]), (u32)__popc(Lk));
+                }
+                u32 m = L & P & ~(1u << hi);
                 while (m) {
                     const u32 c = (u32)__ffs((int)m) - 1u;
                     m &= m - 1u;
-                    const u32 at = p0 + c;
-                    if (open != NONE) vo.put_var(at - open - 1u);          // the run behind `open` ends here
-                    open = ((P >> c) & 1u) ? at : NONE;
-                    lo.put(byte_of16(v, c));
+                    vo.put((u32)__ffs((int)(L >> (c + 1u))) - 1u);
                 }
+                open = ((P >> hi) & 1u) ? p0 + hi : NONE;
             }
         }
         if (EMIT) {
@@ -1029,7 +1082,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
             u8 *lits_end = ws.lits + (u64)b * ws.xf_stride + ws.xf_stride;
             u8 *meta_end = ws.meta + (u64)b * (ws.xf_stride + 768) + (ws.xf_stride + 768);
             PROF(3);
-            wg_hist8(data, n, S.F, (u32 *)dyn, tid);
+            wg_hist8_t<true>(data, n, S.F, S.T, (u32 *)dyn, tid);          // + per symbol, the bytes that repeat their predecessor
             PROF(4);
             wg_rle_split(data, n, lits_end, meta_end, S, dyn, tid);
             PROF(5);
@@ -1046,8 +1099,9 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
                 // the meta is coded as an order-0 stream by the chain kernel (item I1)
                 u8 *mtab = ws.metatab + (u64)b * META_TAB_BYTES;
                 u8 *imgm = img + ENC_IMG_META;
+                wg_hist8(m, mlen, S.F, (u32 *)dyn, tid);                   // (one wave counting ~170 KB of run lengths: 0.2 ms per 1 MiB q8 block)
                 if (w0) {
-                    enc_o0_front(m, mlen, mtab, imgm, S, lane);
+                    enc_o0_tables(mlen, mtab, imgm, S, lane);
                     if (lane == 0) {
                         D->rle_on = 1; D->rle_mlen = mlen; D->rle_lits = nlits;
                         D->rle_meta = (u64)m; D->meta_tab = (u64)mtab; D->meta_tab_len = S.tab_len;
@@ -1539,7 +1593,8 @@ extern "C" void r4x16_launch_enc_front(const BatchArgs *a, const EncWs *ws, int 
     // static + dynamic LDS exceeds the 64 KB default; gfx950 has 160 KB per CU
     if (r4x16_first_on_device(2u))
         (void)hipFuncSetAttribute((const void *)k_enc_front, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    static const u32 dynb = getenv("R4X16_FRONT_LDS") ? (u32)atoi(getenv("R4X16_FRONT_LDS")) : FRONT_DYN_LDS;   // tuning aid
+    static const u32 dynb0 = getenv("R4X16_FRONT_LDS") ? (u32)atoi(getenv("R4X16_FRONT_LDS")) : FRONT_DYN_LDS;  // tuning aid
+    static const u32 dynb = dynb0 < RLE_LDS_BYTES ? RLE_LDS_BYTES : dynb0 > 65536u - 8192u ? 65536u - 8192u : dynb0;   // (the run-length split's slots; wg_hist8's 16 x 257 counters are smaller)
     hipLaunchKernelGGL(k_enc_front, dim3(nblk), dim3(FRONT_THREADS), dynb, s, *a, *ws, base, dynb);
 }
 extern "C" void r4x16_launch_enc_tables(const BatchArgs *a, const EncWs *ws, int base, int nblk, hipStream_t s)
