@@ -2024,39 +2024,65 @@ __device__ bool unpack(const u8 *data, u32 len, u8 *out, u32 out_len, u32 per, B
         const u32 m4 = (u32)B.map[0] | ((u32)B.map[1] << 8) | ((u32)B.map[2] << 16) | ((u32)B.map[3] << 24);
         const u32 in_per = 4u, out_per = in_per * per;                       // bytes in / out per lane and trip
         const u32 trips = out_len / out_per;
-        // four packed dwords per lane in flight (one wave per block: a trip's load would otherwise wait alone)
+        // Four packed dwords per lane and trip; a trip's memory operations leave together at its top, behind an explicit
+        // wait: the unpacked bytes of the trip before, then the requests for the trip after, then the trip's own arithmetic
+        // on dwords that arrived during the last one.  (Loads and stores share one counter and the compiler takes them to
+        // complete in any order: a request and a store per dword made each dword's first use wait for the store just issued.)
         gcu8 *gdata = to_global(data);
+        gu8 *gout = to_global(out);
         auto ldw = [&](u32 t) -> u32 { return t < trips ? *(GAS const u32_unaligned *)(gdata + 4ull * t) : 0u; };
+        // byte b -> selector bytes (b & 3, b >> 2 & 3, b >> 4 & 3, b >> 6): nibbles to bits 0 and 16, then pairs
+        // to every byte (two shift-ors and two masks; the shifted copies never overlap)
+        auto sel4 = [](u32 b) -> u32 { const u32 x = (b | (b << 12)) & 0x000f000fu; return (x | (x << 6)) & 0x03030303u; };
+        auto expand4 = [&](u32 w) -> u32x4 {
+            u32x4 v;
+            v.x = __builtin_amdgcn_perm(m4, m4, sel4(w & 0xffu));
+            v.y = __builtin_amdgcn_perm(m4, m4, sel4((w >> 8) & 0xffu));
+            v.z = __builtin_amdgcn_perm(m4, m4, sel4((w >> 16) & 0xffu));
+            v.w = __builtin_amdgcn_perm(m4, m4, sel4(w >> 24));
+            return v;
+        };
+        // eight 1-bit codes per byte: two selector dwords per packed byte (b * 0x204081 spreads bits 0..3 to bytes)
+        auto expand8 = [&](u32 w, u32 half) -> u32x4 {       // packed bytes 2 half, 2 half + 1 -> sixteen output bytes
+            const u32 b0 = (w >> (16 * half)) & 0xffu, b1 = (w >> (16 * half + 8)) & 0xffu;
+            u32x4 v;
+            v.x = __builtin_amdgcn_perm(m4, m4, __umul24(b0 & 15u, 0x204081u) & 0x01010101u);
+            v.y = __builtin_amdgcn_perm(m4, m4, __umul24(b0 >> 4, 0x204081u) & 0x01010101u);
+            v.z = __builtin_amdgcn_perm(m4, m4, __umul24(b1 & 15u, 0x204081u) & 0x01010101u);
+            v.w = __builtin_amdgcn_perm(m4, m4, __umul24(b1 >> 4, 0x204081u) & 0x01010101u);
+            return v;
+        };
+        auto put = [&](u32 t, const u32x4 &lo, const u32x4 &hi) {
+            if (t >= trips) return;
+            gu8 *o = gout + (u64)out_per * t;
+            *(GAS u32x4_unaligned *)o = lo;
+            if (per == 8) *(GAS u32x4_unaligned *)(o + 16) = hi;
+        };
         u32 wq[4] = {ldw(lane), ldw(lane + NT), ldw(lane + 2 * NT), ldw(lane + 3 * NT)};
-        for (u32 t0 = lane; t0 < trips; t0 += 4 * NT)
+        u32x4 rl[4] = {}, rh[4] = {};
+        u32 rt = trips;                                      // the trip whose bytes wait in rl / rh (trips: none)
+        for (u32 t0 = lane; t0 < trips; t0 += 4 * NT) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0): wq[] is here, the last trip's stores are out
+            __builtin_amdgcn_sched_barrier(0);
+            if (rt < trips) {
 #pragma unroll
-        for (u32 qi = 0; qi < 4; qi++) {
-            const u32 t = t0 + qi * NT;
-            const u32 w = wq[qi];
-            wq[qi] = ldw(t + 4 * NT);
-            if (t >= trips) continue;
-            u8 *o = out + (u64)out_per * t;
-            if (per == 4) {
-                // byte b -> selector bytes (b & 3, b >> 2 & 3, b >> 4 & 3, b >> 6): nibbles to bits 0 and 16, then pairs
-                // to every byte (two shift-ors and two masks; the shifted copies never overlap)
-                auto sel4 = [](u32 b) -> u32 { const u32 x = (b | (b << 12)) & 0x000f000fu; return (x | (x << 6)) & 0x03030303u; };
-                u32x4 v;
-                v.x = __builtin_amdgcn_perm(m4, m4, sel4(w & 0xffu));
-                v.y = __builtin_amdgcn_perm(m4, m4, sel4((w >> 8) & 0xffu));
-                v.z = __builtin_amdgcn_perm(m4, m4, sel4((w >> 16) & 0xffu));
-                v.w = __builtin_amdgcn_perm(m4, m4, sel4(w >> 24));
-                *(u32x4_unaligned *)o = v;
-            } else {
-                // eight 1-bit codes per byte: two selector dwords per packed byte (b * 0x204081 spreads bits 0..3 to bytes)
-#pragma unroll
-                for (int bb = 0; bb < 4; bb++) {
-                    const u32 b = (w >> (8 * bb)) & 0xffu;
-                    u32x2 v;
-                    v.x = __builtin_amdgcn_perm(m4, m4, __umul24(b & 15u, 0x204081u) & 0x01010101u);
-                    v.y = __builtin_amdgcn_perm(m4, m4, __umul24(b >> 4, 0x204081u) & 0x01010101u);
-                    *(u32x2_unaligned *)(o + 8 * bb) = v;
-                }
+                for (u32 qi = 0; qi < 4; qi++) put(rt + qi * NT, rl[qi], rh[qi]);
             }
+            u32 nq[4];
+#pragma unroll
+            for (u32 qi = 0; qi < 4; qi++) nq[qi] = ldw(t0 + (4 + qi) * NT);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (u32 qi = 0; qi < 4; qi++) {
+                if (per == 4) rl[qi] = expand4(wq[qi]);
+                else { rl[qi] = expand8(wq[qi], 0); rh[qi] = expand8(wq[qi], 1); }
+                wq[qi] = nq[qi];
+            }
+            rt = t0;
+        }
+        if (rt < trips) {
+#pragma unroll
+            for (u32 qi = 0; qi < 4; qi++) put(rt + qi * NT, rl[qi], rh[qi]);
         }
         for (u32 i = trips * out_per + lane; i < out_len; i += NT)
             out[i] = B.map[(data[i / per] >> ((i % per) * width)) & mask];

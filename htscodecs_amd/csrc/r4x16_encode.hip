@@ -655,12 +655,16 @@ __device__ bool wg_pack(const u8 *data, u32 n, u8 *meta, u8 *out, EncShared &S, 
     //  below would wait for it; the next piece is requested before this one is packed)
     gu8 *gout = to_global(out);
     auto piece = [&](u32 pi) -> u32x4 { u32x4 v = {0, 0, 0, 0}; if (pi < pieces) v = *(GAS const u32x4_unaligned *)(to_global(data) + 16ull * pi); return v; };
-    u32x4 ahead = piece(tid);
-    for (u32 pi = tid; pi < pieces; pi += FRONT_THREADS) {
-        const u32x4 v = ahead;
-        ahead = piece(pi + FRONT_THREADS);
+    // Four pieces per thread and trip, and a trip's memory operations leave together at its top, behind an explicit wait:
+    // the packed results of the trip before, then the requests for the trip after - and only then the trip's own
+    // arithmetic, on pieces that arrived during the last one.  (Loads and stores share one counter and the compiler
+    // takes them to complete in any order: with a request and a store per piece, each piece's first use waited for
+    // everything in flight - the acknowledgement of the store just issued included: 271 of k_enc_front's 752 us per
+    // 1 MiB q4 block.)
+    const u32 T = FRONT_THREADS;
+    auto pack16 = [&](const u32x4 v) -> u64 {             // 16 symbols of `width` bits, first in the low bits
         const u32 w[4] = {v.x, v.y, v.z, v.w};
-        u64 acc = 0;                                      // 16 symbols of `width` bits, first in the low bits
+        u64 acc = 0;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const u32 i0 = S.idx_of[w[c] & 0xff], i1 = S.idx_of[(w[c] >> 8) & 0xff],
@@ -669,11 +673,29 @@ __device__ bool wg_pack(const u8 *data, u32 n, u8 *meta, u8 *out, EncShared &S, 
             acc |= four << (4 * width * c);
             seen |= i0 | i1 | i2 | i3;
         }
+        return acc;
+    };
+    auto put16 = [&](u32 pi, u64 acc) {
+        if (pi >= pieces) return;
         gu8 *o = gout + (u64)pi * (16 / per);
         if (per == 2)      *(GAS u64_unaligned *)o = acc;
         else if (per == 4) *(GAS u32_unaligned *)o = (u32)acc;
         else               *(GAS u16_unaligned *)o = (u16)acc;
+    };
+    u32x4 q0 = piece(tid), q1 = piece(tid + T), q2 = piece(tid + 2 * T), q3 = piece(tid + 3 * T);
+    u64 r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    u32 rpi = pieces;                                     // the trip whose results wait in r0..r3 (pieces: none)
+    for (u32 pi = tid; pi < pieces; pi += 4 * T) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);               // vmcnt(0): q0..q3 are here, the last trip's stores are out
+        __builtin_amdgcn_sched_barrier(0);
+        if (rpi < pieces) { put16(rpi, r0); put16(rpi + T, r1); put16(rpi + 2 * T, r2); put16(rpi + 3 * T, r3); }
+        const u32x4 n0 = piece(pi + 4 * T), n1 = piece(pi + 5 * T), n2 = piece(pi + 6 * T), n3 = piece(pi + 7 * T);
+        __builtin_amdgcn_sched_barrier(0);
+        r0 = pack16(q0); r1 = pack16(q1); r2 = pack16(q2); r3 = pack16(q3);
+        rpi = pi;
+        q0 = n0; q1 = n1; q2 = n2; q3 = n3;
     }
+    if (rpi < pieces) { put16(rpi, r0); put16(rpi + T, r1); put16(rpi + 2 * T, r2); put16(rpi + 3 * T, r3); }
     if (tid == 0) {                                       // the last n % 16 bytes
         const u32 nout = S.pk_len;
         for (u32 ob = (pieces * 16) / per; ob < nout; ob++) {
