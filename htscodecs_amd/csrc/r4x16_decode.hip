@@ -2399,7 +2399,7 @@ extern "C" int r4x16_dec_residency(u32 nsym, int order, u32 bits, int *streams_p
 extern "C" void r4x16_launch_dec_back(const BatchArgs *a, const DecWs *ws, int base, int nblk, hipStream_t s)
 {
     // few blocks: a workgroup per block (the run-length expansion of one wave per block is a fixed ~19 ms per MiB)
-    static const int wg_per_cu = getenv("R4X16_BACK_WG_PER_CU") ? atoi(getenv("R4X16_BACK_WG_PER_CU")) : 6;
+    const int wg_per_cu = getenv("R4X16_BACK_WG_PER_CU") ? atoi(getenv("R4X16_BACK_WG_PER_CU")) : 6;
     if (nblk <= wg_per_cu * cu_count()) hipLaunchKernelGGL(k_dec_back<BACK_THREADS>, dim3(nblk), dim3(BACK_THREADS), 0, s, *a, *ws, base);
     else hipLaunchKernelGGL(k_dec_back<WAVE>, dim3(nblk), dim3(WAVE), 0, s, *a, *ws, base);
 }

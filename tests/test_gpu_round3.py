@@ -226,3 +226,55 @@ def test_combiner_keeps_callers_apart(oracle):
     env = dict(os.environ, R4X16_COMBINE_MAX_MB="1", R4X16_COMBINE_MAX="8")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "isolated ok" in r.stdout, r.stdout + r.stderr
+
+
+def _runs(rs, n_runs, lens, syms):
+    """n_runs runs: lengths drawn from `lens`, symbols from `syms` (neighbours differ)."""
+    out, prev = [], -1
+    for _ in range(n_runs):
+        s = int(syms[rs.randint(len(syms))])
+        if s == prev:
+            s = int(syms[(list(syms).index(s) + 1) % len(syms)])
+        out.append(np.full(int(lens[rs.randint(len(lens))]), s, dtype=np.uint8))
+        prev = s
+    return np.concatenate(out)
+
+
+@pytest.mark.parametrize("route", ["0", "99999"], ids=["one-wave", "workgroup"])
+def test_run_length_shapes(H, oracle, monkeypatch, route):
+    """X_RLE both ways against the oracle, through both expansion kernels (R4X16_BACK_WG_PER_CU picks per call):
+      * run lengths around the varint sizes (127 / 128, 16,383 / 16,384, 2^21) and long stretches of two- and
+        three-byte varints (the one-wave route decodes the run stream 60 bytes at a time with four bytes of history);
+      * literal counts around the trip sizes (63 .. 65, 255 .. 257, 1,023 .. 1,025) and a run at the very end;
+      * a run of more than 2^24 bytes in a 20 MiB block (prefix sums beyond 32 bits per trip: the plain route);
+      * X_PACK in front (order 192 / 193) and quality-like data."""
+    monkeypatch.setenv("R4X16_BACK_WG_PER_CU", route)
+    rs = np.random.RandomState(4242)
+    datas, orders = [], []
+    def add(a, os_=(64, 65)):
+        for o in os_:
+            datas.append(np.ascontiguousarray(a).tobytes()); orders.append(o)
+    add(_runs(rs, 3000, [1, 2, 3, 126, 127, 128, 129, 130], [10, 11, 12, 13, 200]))
+    add(_runs(rs, 400, [16382, 16383, 16384, 16385, 300, 5000], [1, 2, 3]))
+    add(_runs(rs, 2000, list(range(129, 400)), [7, 8, 9, 10, 11, 12]))              # two-byte varints back to back
+    add(_runs(rs, 40, [1 << 21, (1 << 21) + 1, 70000], [5, 6]), os_=(64,))          # four-byte varints
+    for nlit in (63, 64, 65, 255, 256, 257, 1023, 1024, 1025):
+        a = _runs(rs, nlit, [1, 1, 1, 2, 5, 40], [20, 21, 22, 23, 24, 25, 26, 27])
+        add(a, os_=(65,))
+        add(np.concatenate([a, np.full(777, 99, np.uint8)]), os_=(64,))             # ... and a run at the very end
+    giant = np.concatenate([_runs(rs, 500, [1, 2, 3, 9], [1, 2, 3, 4]), np.full((1 << 24) + 1234567, 7, np.uint8),
+                            _runs(rs, 500, [1, 2, 3, 9], [1, 2, 3, 4])])
+    add(giant, os_=(64, 193))
+    add(_runs(rs, 50000, [1, 1, 2, 3, 4, 6, 9, 30], [0, 1, 2, 3]), os_=(192, 193))   # four symbols: X_PACK packs four per byte
+    add(datagen.tile("q4", 300001, 5), os_=(193, 65))
+    add(datagen.tile("q8", 299999, 6), os_=(65, 64))
+    enc, st = H.compress_batch(datas, orders)
+    assert all(s == 0 for s in st), st
+    want = [oracle.compress(d, o) for d, o in zip(datas, orders)]
+    bad = [(i, orders[i], len(datas[i])) for i in range(len(datas)) if enc[i] != want[i]]
+    assert not bad, bad
+    assert sum(1 for w in want if w[0] & 64) >= len(want) - 4, "X_RLE was dropped by the encoder for most cases"
+    dec, st = H.uncompress_batch(want, [len(d) for d in datas])
+    assert all(s == 0 for s in st), st
+    bad = [(i, orders[i], len(datas[i])) for i in range(len(datas)) if dec[i] != datas[i]]
+    assert not bad, bad
