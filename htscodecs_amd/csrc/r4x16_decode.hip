@@ -1572,7 +1572,8 @@ __global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDes
 // that would start past the end of the run stream reads as 0 (varint.h:136), of any length otherwise.
 // ---------------------------------------------------------------------------------------------
 #define BACK_THREADS 256u
-#define BACK_FIFO 128u
+#define BACK_FIFO 512u
+#define BACK_TRIP 256u
 #define BACK_FEED 1024u
 struct BackShared {
     u8  is_rle[256];
@@ -1844,11 +1845,12 @@ __device__ bool rle_expand_wave(const u8 *lit_, u32 lit_len_, const u8 *runs_, u
     gcu8 *glit = to_global(lit), *gruns = to_global(runs);
     gu8 *gout = to_global(out);
     // (this route's buffers live in its own kernel only, like the workgroup route's tile)
-    __shared__ __attribute__((aligned(16))) u8 litbuf[BACK_FEED];        // the literals of sixteen trips
+    __shared__ __attribute__((aligned(16))) u8 litbuf_[16 + 2 * BACK_FEED];   // the literals: the KiB of the trip in hand, the KiB
+    u8 *litbuf = litbuf_ + 16;                                                 // after it (and a byte in front that may be read)
     __shared__ __attribute__((aligned(16))) u8 rring[2 * BACK_FEED];     // the run stream around the producer's cursor
     __shared__ u32 fifo[BACK_FIFO];                                      // run lengths decoded ahead of the literals
-    __shared__ u32 tile[WAVE];                                           // where literals start within 256 bytes of output
-    u8 *tile8 = (u8 *)tile;
+    __shared__ __attribute__((aligned(8))) u32 tile[2 * WAVE];           // where literals start within 256 bytes of output (16-bit marks)
+    u16 *tile16 = (u16 *)tile;
 
     // Both inputs reach the trips through LDS, a KiB at a time (sixteen bytes per lane, requested one refill ahead):
     // a load per trip, however far ahead it is requested, makes the trip wait for ALL memory operations in flight at the
@@ -1899,101 +1901,133 @@ __device__ bool rle_expand_wave(const u8 *lit_, u32 lit_len_, const u8 *runs_, u
     u32 cb = 0, carry_w = 0;                              // of which the last cb (< 4) wait in carry_w for their dword
     bool err = false;
     u32x4 lpre = load16(glit, 0, lit_len);
-    u32 bnext = 0, fnext = 0;                             // the next trip's literal and whether it is a run-length symbol
+    // A trip is 256 literals, four consecutive ones per lane (the 64-literal trip of the first version spent 118 vector
+    // instructions per trip, most of them the same whatever the literals: two scans, the ring bookkeeping, a pass).
+    u32 wnext = 0, fnext = 0;                             // the next trip's literals of this lane, which of them are run-length symbols
     auto fetch = [&](u32 at) {                            // ... of the trip at literal `at` (< lit_len)
-        if ((at & (BACK_FEED - 1u)) == 0) {               // (everything read from the buffer so far has been read: one wave, LDS in order)
-            *(u32x4 *)(litbuf + 16u * lane) = lpre;
+        if ((at & (BACK_FEED - 1u)) == 0) {               // (into the half the trip in hand does not read: its passes still look literals up)
+            *(u32x4 *)(litbuf + (at & BACK_FEED) + 16u * lane) = lpre;
             lpre = load16(glit, at + BACK_FEED, lit_len);
         }
-        bnext = litbuf[(at & (BACK_FEED - 1u)) + lane];
-        fnext = B.is_rle[bnext];
+        wnext = *(const u32 *)(litbuf + (at & (2u * BACK_FEED - 1u)) + 4u * lane);
+        fnext = (u32)B.is_rle[wnext & 0xffu] | ((u32)B.is_rle[(wnext >> 8) & 0xffu] << 1) |
+                ((u32)B.is_rle[(wnext >> 16) & 0xffu] << 2) | ((u32)B.is_rle[wnext >> 24] << 3);
     };
     if (lit_len) fetch(0);
-    for (u32 base = 0; base < lit_len; base += WAVE) {
-        const u32 i = base + lane;
-        const bool valid = i < lit_len;
-        const u32 bval = bnext;
-        const bool r = valid && fnext;
-        if (base + WAVE < lit_len) fetch(base + WAVE);
-        const u64 rmask = __ballot(r);
-        const u32 nr = (u32)__popcll(rmask), myrank = (u32)__popcll(rmask & lane_below);
-        while (made - used < nr && rq < run_len) produce();            // (at most 63 values wait: 63 + 60 fit the ring)
+    for (u32 base = 0; base < lit_len; base += BACK_TRIP) {
+        const u32 i0 = base + 4u * lane;
+        const u32 nv = i0 >= lit_len ? 0u : (lit_len - i0 < 4u ? lit_len - i0 : 4u);     // this lane's literals in the trip
+        const u32 vmask = (1u << nv) - 1u;
+        const u32 w = wnext;
+        const u32 fl = fnext & vmask;
+        const u32 lb = base & (2u * BACK_FEED - 1u);      // the trip's literals are litbuf[lb .. lb + 256)
+        if (base + BACK_TRIP < lit_len) fetch(base + BACK_TRIP);
+        const u32 bv[4] = {w & 0xffu, (w >> 8) & 0xffu, (w >> 16) & 0xffu, w >> 24};
+        // the k-th run-length literal takes the k-th value of the ring
+        const u32 nrl = (u32)__popc(fl);
+        const u32 rincl = wave_incl_scan(nrl, lane);
+        const u32 nr = (u32)__builtin_amdgcn_readlane((int)rincl, WAVE - 1);
+        while (made - used < nr && rq < run_len) produce();            // (at most 255 values wait: 255 + 60 fit the ring)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");         // one wave: its LDS operations complete in order
         const u32 avail = made - used;
-        const u32 runval = (r && myrank < avail) ? fifo[(used + myrank) & (BACK_FIFO - 1u)] : 0u;
+        u32 rv[4];
+        {
+            u32 rk = rincl - nrl;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool is = (fl >> k) & 1u;
+                rv[k] = (is && rk < avail) ? fifo[(used + rk) & (BACK_FIFO - 1u)] : 0u;
+                rk += is ? 1u : 0u;
+            }
+        }
         used += nr < avail ? nr : avail;
 
-        if (__ballot(runval > 0x00ffffffu)) {
-            // ---- the plain route of a trip with a giant run
+        if (__ballot((rv[0] | rv[1] | rv[2] | rv[3]) > 0x00ffffffu)) {
+            // ---- the plain route of a trip with a giant run: 64-bit sums, byte stores, the wave fills long runs together
             for (u32 k = lane; k < cb; k += WAVE) gout[outp - cb + k] = (u8)(carry_w >> (8 * k));
             cb = 0;
-            const u64 len = valid ? 1ull + runval : 0ull;
-            u64 incl = len;
+            u64 len[4], sum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { len[k] = ((vmask >> k) & 1u) ? 1ull + rv[k] : 0ull; sum += len[k]; }
+            u64 incl = sum;
 #pragma unroll
             for (int dd = 1; dd < WAVE; dd <<= 1) {
                 const u64 tt = __shfl_up(incl, dd);
                 if (lane >= (u32)dd) incl += tt;
             }
-            const u64 excl = incl - len;
             const u64 total = __shfl(incl, WAVE - 1);
-            const u64 oi = outp + excl;
-            const bool bad = valid && (oi >= cap || (runval && oi + runval >= cap));     // rle.c:165, :173
-            if (__ballot(bad)) { err = true; break; }
-            u8 *o = out + oi;
-            if (valid) o[0] = (u8)bval;
-            if (runval && runval <= 24u)
-                for (u32 k = 1; k <= runval; k++) o[k] = (u8)bval;
-            u64 longm = __ballot(runval > 24u);
-            while (longm) {
-                const int src = __ffsll((unsigned long long)longm) - 1;
-                longm &= longm - 1;
-                const u64 at = __shfl(excl, src);
-                const u32 len1 = (u32)__shfl((int)runval, src), bv = (u32)__shfl((int)bval, src);
-                u8 *ro = out + outp + at + 1;
-                for (u32 k = lane; k < len1; k += WAVE) ro[k] = (u8)bv;
+            if (outp + total > cap) { err = true; break; }              // rle.c:165, :173 (see below)
+            u64 at = outp + incl - sum;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const bool v = (vmask >> k) & 1u;
+                u8 *o = out + at;
+                if (v) o[0] = (u8)bv[k];
+                if (v && rv[k] && rv[k] <= 24u)
+                    for (u32 j = 1; j <= rv[k]; j++) o[j] = (u8)bv[k];
+                u64 longm = __ballot(v && rv[k] > 24u);
+                while (longm) {
+                    const int src = __ffsll((unsigned long long)longm) - 1;
+                    longm &= longm - 1;
+                    const u64 from = __shfl(at, src);
+                    const u32 len1 = (u32)__shfl((int)rv[k], src), b1 = (u32)__shfl((int)bv[k], src);
+                    u8 *ro = out + from + 1;
+                    for (u32 j = lane; j < len1; j += WAVE) ro[j] = (u8)b1;
+                }
+                at += len[k];
             }
             outp += total;
             continue;
         }
 
-        const u32 len = valid ? 1u + runval : 0u;
-        const u32 incl = wave_incl_scan(len, lane);
-        const u32 excl = incl - len;
+        u32 len[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) len[k] = ((vmask >> k) & 1u) ? 1u + rv[k] : 0u;
+        const u32 sum = len[0] + len[1] + len[2] + len[3];
+        const u32 incl = wave_incl_scan(sum, lane);
         const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
-        // rle.c:165, :173: every literal needs room, a run needs room for all of it.  Positions rise with the lane, so the
+        // rle.c:165, :173: every literal needs room, a run needs room for all of it.  Positions rise with the literal, so the
         // trip's last byte decides for all of them (a literal at o needs o < cap, its run o + run < cap).
         if (outp + total > cap) { err = true; break; }
 
-        // the trip's bytes behind the cb carried ones, as dwords from out + ob
+        // the trip's bytes behind the cb carried ones, as dwords from out + ob; e[k]: where this lane's k-th literal starts
         gu8 *ob = gout + (outp - cb);
         const u32 nbytes = cb + total, W = nbytes >> 2;
-        const u32 e = cb + excl;                           // where this lane's literal starts
-        const u32 keep = cb ? ~0u << (8 * cb) : ~0u;      // chunk 0, lane 0: the bytes that are new
+        u32 e[4];
+        e[0] = cb + incl - sum; e[1] = e[0] + len[0]; e[2] = e[1] + len[1]; e[3] = e[2] + len[2];
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (!((vmask >> k) & 1u)) e[k] = 0xffffffffu;       // (never inside a pass, never before one)
+        const u32 keep = cb ? ~0u << (8 * cb) : ~0u;      // pass 0, lane 0: the bytes that are new
         u32 next_carry = 0;
         for (u32 P0 = 0; P0 < nbytes; P0 += 256u) {
-            const u64 inm = __ballot(valid && e - P0 < 256u);
-            const u32 nbefore = (u32)__popcll(__ballot(valid && e < P0));        // (the valid lanes are the low ones, e rises with the lane)
-            u32 w;
-            if (!inm) w = (u32)__builtin_amdgcn_readlane((int)bval, (int)nbefore - 1) * 0x01010101u;   // inside one run
+            const bool in0 = e[0] - P0 < 256u, in1 = e[1] - P0 < 256u, in2 = e[2] - P0 < 256u, in3 = e[3] - P0 < 256u;
+            const u64 inm = __ballot(in0 || in1 || in2 || in3);
+            // literals that start before the pass (they are the trip's first: positions rise with the literal)
+            const u32 nbefore = (u32)__popcll(__ballot(e[0] < P0)) + (u32)__popcll(__ballot(e[1] < P0)) +
+                                (u32)__popcll(__ballot(e[2] < P0)) + (u32)__popcll(__ballot(e[3] < P0));
+            u32 wout;
+            if (!inm) wout = (u32)litbuf[lb + nbefore - 1u] * 0x01010101u;                // inside one run
             else {
-                tile[lane] = 0;
-                if (valid && e - P0 < 256u) tile8[e - P0] = (u8)(lane + 1u);
+                *(u32x2 *)(tile + 2u * lane) = u32x2{0u, 0u};
+                const u32 id = 4u * lane + 1u;                                            // literal index in the trip + 1
+                if (in0) tile16[e[0] - P0] = (u16)id;
+                if (in1) tile16[e[1] - P0] = (u16)(id + 1u);
+                if (in2) tile16[e[2] - P0] = (u16)(id + 2u);
+                if (in3) tile16[e[3] - P0] = (u16)(id + 3u);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                const u32 t = tile[lane];
-                u32 m0 = t & 0xffu, m1 = max(m0, (t >> 8) & 0xffu), m2 = max(m1, (t >> 16) & 0xffu), m3 = max(m2, t >> 24);
+                const u32x2 t = *(const u32x2 *)(tile + 2u * lane);
+                u32 m0 = t.x & 0xffffu, m1 = max(m0, t.x >> 16), m2 = max(m1, t.y & 0xffffu), m3 = max(m2, t.y >> 16);
                 const u32 pre = max(wave_shr1(wave_incl_max(m3)), nbefore);
                 m0 = max(m0, pre); m1 = max(m1, pre); m2 = max(m2, pre); m3 = max(m3, pre);
-                const u32 v0 = (u32)__builtin_amdgcn_ds_bpermute((int)(m0 - 1u) << 2, (int)bval);
-                const u32 v1 = (u32)__builtin_amdgcn_ds_bpermute((int)(m1 - 1u) << 2, (int)bval);
-                const u32 v2 = (u32)__builtin_amdgcn_ds_bpermute((int)(m2 - 1u) << 2, (int)bval);
-                const u32 v3 = (u32)__builtin_amdgcn_ds_bpermute((int)(m3 - 1u) << 2, (int)bval);
-                w = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // the tile is rewritten by the next pass
+                // (m = 0: a carried byte in front of the trip's first literal - read whatever is there, lane 0 replaces it)
+                const u8 *lv = litbuf + lb - 1u;
+                wout = (u32)lv[m0] | ((u32)lv[m1] << 8) | ((u32)lv[m2] << 16) | ((u32)lv[m3] << 24);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                    // the tile is rewritten by the next pass
             }
-            if (P0 == 0 && lane == 0) w = (w & keep) | (carry_w & ~keep);
+            if (P0 == 0 && lane == 0) wout = (wout & keep) | (carry_w & ~keep);
             const u32 d = (P0 >> 2) + lane;
-            if (d < W) *(GAS u32_unaligned *)(ob + 4ull * d) = w;
-            if ((W >> 6) == (P0 >> 8)) next_carry = (u32)__builtin_amdgcn_readlane((int)w, (int)(W & 63u));
+            if (d < W) *(GAS u32_unaligned *)(ob + 4ull * d) = wout;
+            if ((W >> 6) == (P0 >> 8)) next_carry = (u32)__builtin_amdgcn_readlane((int)wout, (int)(W & 63u));
         }
         carry_w = next_carry;
         cb = nbytes & 3u;
