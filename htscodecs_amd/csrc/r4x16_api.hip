@@ -147,6 +147,7 @@ extern "C" int r4x16_cu_count(void);
 // (measured: 1,024 x 1 MiB q40 decode 29 -> 63 ms with the fork at eight blocks per CU).  Two blocks per CU leave half of
 // the LDS free whatever the classes.  (Sixteen per CU, on 4,096 blocks: mixed 64 KiB blocks 11.5 -> 9.1 ms and q8 with
 // X_RLE 83 -> 77 ms, but 1 MiB q40 blocks 82 -> 90 ms.)
+#define FORK_ONE_BLOCK_BYTES (256u << 10)
 static int fork_blocks()
 {
     static const int per_cu = getenv("R4X16_FORK_PER_CU") ? atoi(getenv("R4X16_FORK_PER_CU")) : 2;
@@ -300,7 +301,9 @@ extern "C" int rans4x16_hip_compress_dev(rans4x16_hip_ctx *c, int n,
         w.direct_budget = r4x16_enc_direct_budget(nb);       // few streams: LDS to spare, symbol records (r4x16_common.h)
         r4x16_launch_enc_front(&a, &w, (int)base, nb, s);
         r4x16_launch_enc_tables(&a, &w, (int)base, nb, s);
-        const R4Fork *fk = fork_for(c, nb > 1 && nb <= fork_blocks());     // (made at first use: not inside the timed region; one block is one payload class)
+        // (made at first use: not inside the timed region.  One small block is one payload class and a call of 0.4 ms; one
+        //  large block with X_RLE is two long streams - literals, run lengths - of different classes: 15.7 -> 12.0 ms per MiB of q8)
+        const R4Fork *fk = fork_for(c, (nb > 1 || max_in_size >= FORK_ONE_BLOCK_BYTES) && nb <= fork_blocks());
         TimedLaunch t;
         if (c->timing) time_begin(c, 0, s, t);
         r4x16_launch_enc_chain(&w, 3 * nb, s, fk);
@@ -380,7 +383,7 @@ extern "C" int rans4x16_hip_uncompress_dev(rans4x16_hip_ctx *c, int n,
         const int nb = (int)((size_t)n - base < chunk ? (size_t)n - base : chunk);
         w.direct_budget = r4x16_dec_direct_budget(nb);       // few streams: LDS to spare, the short-step rows (r4x16_common.h)
         r4x16_launch_dec_front(&a, &w, (int)base, nb, s);
-        const R4Fork *fk = fork_for(c, nb > 1 && nb <= fork_blocks());
+        const R4Fork *fk = fork_for(c, (nb > 1 || max_out_cap >= FORK_ONE_BLOCK_BYTES) && nb <= fork_blocks());   // (one large block: 28.2 -> 19.8 ms per MiB of q8 with X_RLE)
         TimedLaunch t;
         if (c->timing) time_begin(c, 1, s, t);
         r4x16_launch_dec_chain(&w, 2 * nb, s, fk);

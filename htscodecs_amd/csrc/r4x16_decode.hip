@@ -2432,8 +2432,11 @@ extern "C" int r4x16_dec_residency(u32 nsym, int order, u32 bits, int *streams_p
 }
 extern "C" void r4x16_launch_dec_back(const BatchArgs *a, const DecWs *ws, int base, int nblk, hipStream_t s)
 {
-    // few blocks: a workgroup per block (the run-length expansion of one wave per block is a fixed ~19 ms per MiB)
-    const int wg_per_cu = getenv("R4X16_BACK_WG_PER_CU") ? atoi(getenv("R4X16_BACK_WG_PER_CU")) : 6;
+    // One wave per block at every batch size since its trips became 256 literals of LDS-fed work (64 x 1 MiB q8 blocks with
+    // X_RLE: step 38.0 ms either way; 1,024: 53.5 against 55.6; 2,048: 56.2 against 64.6); the workgroup-per-block
+    // kernel, round 3's first answer to the old trip's fixed ~19 ms per MiB, stays selectable: R4X16_BACK_WG_PER_CU=N
+    // takes it up to N blocks per CU.
+    const int wg_per_cu = getenv("R4X16_BACK_WG_PER_CU") ? atoi(getenv("R4X16_BACK_WG_PER_CU")) : 0;
     if (nblk <= wg_per_cu * cu_count()) hipLaunchKernelGGL(k_dec_back<BACK_THREADS>, dim3(nblk), dim3(BACK_THREADS), 0, s, *a, *ws, base);
     else hipLaunchKernelGGL(k_dec_back<WAVE>, dim3(nblk), dim3(WAVE), 0, s, *a, *ws, base);
 }
