@@ -242,6 +242,7 @@ static size_t enc_ws_layout(u8 *base, size_t nblk, u64 scratch_stride, u64 xf_st
     w->xf_stride = xf_stride;
     w->scratch2_stride = scratch2_stride;
     w->direct_budget = 0;
+    w->meta_records = 0;
     w->pad = 0;
     return align_up(cv.off, 256);
 }
@@ -299,11 +300,12 @@ extern "C" int rans4x16_hip_compress_dev(rans4x16_hip_ctx *c, int n,
     for (size_t base = 0; base < (size_t)n; base += chunk) {
         const int nb = (int)((size_t)n - base < chunk ? (size_t)n - base : chunk);
         w.direct_budget = r4x16_enc_direct_budget(nb);       // few streams: LDS to spare, symbol records (r4x16_common.h)
-        r4x16_launch_enc_front(&a, &w, (int)base, nb, s);
-        r4x16_launch_enc_tables(&a, &w, (int)base, nb, s);
         // (made at first use: not inside the timed region.  One small block is one payload class and a call of 0.4 ms; one
         //  large block with X_RLE is two long streams - literals, run lengths - of different classes: 15.7 -> 12.0 ms per MiB of q8)
         const R4Fork *fk = fork_for(c, (nb > 1 || max_in_size >= FORK_ONE_BLOCK_BYTES) && nb <= fork_blocks());
+        w.meta_records = fk == nullptr;
+        r4x16_launch_enc_front(&a, &w, (int)base, nb, s);
+        r4x16_launch_enc_tables(&a, &w, (int)base, nb, s);
         TimedLaunch t;
         if (c->timing) time_begin(c, 0, s, t);
         r4x16_launch_enc_chain(&w, 3 * nb, s, fk);

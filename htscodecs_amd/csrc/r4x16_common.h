@@ -241,7 +241,8 @@ struct DecDesc {
 #define ENC_IMG_O0     1024u                                      // 256 + 2*257, rounded
 #define ENC_IMG_NESTED ENC_IMG_MAIN                               // offset of the nested-table image
 #define ENC_IMG_META   (ENC_IMG_NESTED + ENC_IMG_O0)              // offset of the RLE-meta image
-#define ENC_IMG_BYTES  (ENC_IMG_META + ENC_IMG_O0)                // 134,144 per block
+#define ENC_IMG_META_BYTES 4352u                                  // one cumulative row, or 256 symbol records (enc_rec_img_bytes(256, 1))
+#define ENC_IMG_BYTES  (ENC_IMG_META + ENC_IMG_META_BYTES)        // 137,472 per block
 #define RCPTAB_ENTRIES 4097u
 
 struct EncItem {
@@ -307,7 +308,8 @@ struct EncDesc {
 // Device workspace carved per chunk of blocks by r4x16_api.hip.
 // ---------------------------------------------------------------------------------------------
 #define TBUF_BYTES     204800u                          // an un-nested order-1 table (257*257*3 = 198147 max)
-#define DEC_IMG_SLOT   (IMG_MAX_BYTES + 2u * IMG_O0_BYTES)   // payload image, nested-table image, RLE-meta image
+#define IMG_META_BYTES 2832u                      // the RLE-meta image: one order-0 row, or its direct rows (dir_img_bytes(128, 1, 12) = 2,820)
+#define DEC_IMG_SLOT   (IMG_MAX_BYTES + IMG_O0_BYTES + IMG_META_BYTES)   // payload image, nested-table image, RLE-meta image
 #define TAB_BYTES      198656u                          // >= 1 + 257*257*3 (assert at rANS_static4x16pr.c:784)
 
 #define CLS_MAX  64u
@@ -368,6 +370,8 @@ struct EncWs {
     u64 xf_stride, scratch2_stride;
     u32 *cls, *cls_list, *cls_count;   // streams grouped by LDS size class (as in DecWs)
     u32 direct_budget;  // LDS bytes a stream of this batch may take for symbol records (0: never); set per chunk by the host
+    u32 meta_records;   // the RLE-meta streams take records too (set where the class launches go out in stream order: a wave then
+                        // walks a block's literals and its run lengths together; side by side they are better off in two kernels)
     u32 pad;
 };
 #define META_TAB_BYTES 1024u

@@ -1379,14 +1379,19 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(PHASE ? 8 
 
     if (H.meta_nested) {
         // the RLE meta is itself an order-0 stream: it becomes a second item for the chain kernel
+        // (with LDS to spare it takes the short-step rows like any order-0 payload: the run lengths of a 1 MiB q8 block
+        //  are a stream of ~170,000 symbols - 10.5 ms at three look-ups per step on 4,096 such blocks)
         u8 *imgm = img + IMG_MAX_BYTES + IMG_O0_BYTES;
-        o0_front(src, H.meta_pos, H.meta_slen, H.meta_len, imgm, S, lane);
+        __shared__ u32 meta_direct;
+        o0_front(src, H.meta_pos, H.meta_slen, H.meta_len, imgm, S, lane, ws.direct_budget, &meta_direct);
         if (S.status != ST_OK) { if (lane == 0) D->status = S.status; return; }
         if (lane == 0) {
             I1->words = (u64)(in + S.words_pos);
             I1->words_len = H.meta_pos + H.meta_slen - S.words_pos;
             I1->out = (u64)metabuf; I1->out_sz = H.meta_len; I1->image = (u64)imgm;
-            I1->img_bytes = img_bytes(S.nsym, 1); I1->nsym = S.nsym;
+            I1->img_bytes = meta_direct ? dir_img_bytes(S.nsym, 1u, O0_BITS) : img_bytes(S.nsym, 1); I1->nsym = S.nsym;
+            I1->packed = meta_direct ? 2u : 0u;
+            I1->affine = meta_direct ? meta_direct - 1u : 0u;
             I1->look = O0_BITS; I1->order = 0;
             for (int k = 0; k < 4; k++) I1->R[k] = S.R[k];
             I1->active = H.meta_len != 0;
@@ -2229,6 +2234,11 @@ static const struct { u32 bytes; int qpw; int lv; } DEC_CLASSES[] = {
     // alphabets (q4 / q8 / q40) should not fall into more classes than it did with the compressed rows
     {2576, 15, 6}, {4112, 9, 6}, {8080, 5, 6}, {13584, 3, 6}, {20368, 2, 6}, {32000, 1, 6}, {40960, 1, 6}, {53760, 1, 6},
     {81920, 1, 6}, {163840, 1, 6},
+    // the same for order-0 streams (level 7 = level 6's kernel; images of at most 2,820 bytes).  A wave walks its order-1
+    // quads, then its order-0 quads: the run lengths of a block with X_RLE in a launch of their own run beside the
+    // block's literals where launches run side by side (one 1 MiB q8 block: 25.0 -> 18.7 ms), not behind them in the
+    // same wave (only where launches do run side by side, DecClassTab.split_o0)
+    {2576, 15, 7}, {4112, 9, 7},
 };
 // workgroups of `lds_bytes` each that one CU holds at once (1,280-byte LDS granules, 32 wave slots)
 static int resident_per_cu(size_t lds_bytes, int waves_per_wg)
@@ -2278,7 +2288,7 @@ extern "C" int r4x16_resident_grid(size_t lds_bytes, int waves_per_wg, int wante
 // ---- streams -> classes, on the device ---------------------------------------------------------
 // class ids: index into DEC_CLASSES, then one catch-all per tree depth (images too large for LDS)
 #define DEC_NCLS ((u32)(sizeof(DEC_CLASSES) / sizeof(DEC_CLASSES[0])))
-struct DecClassTab { u32 n; u32 bytes[CLS_MAX]; u32 lv[CLS_MAX]; };
+struct DecClassTab { u32 n; u32 split_o0; u32 bytes[CLS_MAX]; u32 lv[CLS_MAX]; };
 // (per-class counts go through LDS first: a whole batch is usually one class, and 30,000 atomics on one global word
 //  took 0.18 ms)
 __global__ __launch_bounds__(256) void k_dec_classify(const DecItem *items, int nitems, DecClassTab tab, u32 *cls, u32 *count)
@@ -2291,7 +2301,7 @@ __global__ __launch_bounds__(256) void k_dec_classify(const DecItem *items, int 
         const DecItem *I = &items[i];
         u32 c = CLS_NONE;
         if (I->active) {
-            const u32 need = I->img_bytes + RING_BYTES, lv = item_levels(I->nsym, I->packed);
+            const u32 need = I->img_bytes + RING_BYTES, lv0 = item_levels(I->nsym, I->packed), lv = (lv0 == 6u && I->order == 0 && tab.split_o0) ? 7u : lv0;
             c = tab.n + ((lv < 2u || lv > 4u) ? 0u : lv - 2u);  // catch-all of this depth (packed levels 1 and 5 always fit a class)
             for (u32 k = 0; k < tab.n; k++)
                 if (tab.lv[k] == lv && need <= tab.bytes[k]) { c = k; break; }   // classes of a depth ascend
@@ -2344,6 +2354,7 @@ static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitem
     {
         DecClassTab tab;
         tab.n = DEC_NCLS;
+        tab.split_o0 = fk != nullptr;           // (launches in stream order: a wave takes both kinds, 4,096 x 1 MiB q8 with X_RLE 26.7 against 28.2 ms)
         for (u32 k = 0; k < DEC_NCLS; k++) { tab.bytes[k] = DEC_CLASSES[k].bytes; tab.lv[k] = (u32)DEC_CLASSES[k].lv; }
         r4x16_launch_cls_zero(ws->cls_count, s);
         hipLaunchKernelGGL(k_dec_classify, dim3((nitems + 255) / 256), dim3(256), 0, s, items, nitems, tab, ws->cls, ws->cls_count);
@@ -2379,10 +2390,10 @@ static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitem
         const int grid = r4x16_resident_grid(ldsb, 1, (nitems + qpw - 1) / qpw);
         void (*kern)(const DecItem *, DecDesc *, const u32 *, const u32 *, int, u32) =
             c.lv == 1 ? k_dec_chain<true, 1> : c.lv == 5 ? k_dec_chain<true, 5> : c.lv == 2 ? k_dec_chain<true, 2> : c.lv == 3 ? k_dec_chain<true, 3> :
-            c.lv == 6 ? k_dec_chain<true, 6> : k_dec_chain<true, 4>;
+            (c.lv == 6 || c.lv == 7) ? k_dec_chain<true, 6> : k_dec_chain<true, 4>;
         // (an order-0 image: at most IMG_O0_BYTES; depth 4 only as the lone row of an alphabet beyond 150 symbols)
-        const bool skip = (one_row_only && (c.lv == 1 || c.lv == 5 || c.lv == 6 || c.bytes > (c.lv == 4 ? 22528u : IMG_O0_BYTES + RING_BYTES + 128u))) ||
-                          (c.lv == 6 && !ws->direct_budget);      // (no stream of this batch was given direct blocks)
+        const bool skip = (one_row_only && (c.lv == 1 || c.lv >= 5 || c.bytes > (c.lv == 4 ? 22528u : IMG_O0_BYTES + RING_BYTES + 128u))) ||
+                          (c.lv >= 6 && !ws->direct_budget);      // (no stream of this batch was given direct blocks)
         if (!skip) {
             if (fk && pass == 0) s = fk->pick(s0, launched++);
             hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), ldsb, s, items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci), qpw, c.bytes);

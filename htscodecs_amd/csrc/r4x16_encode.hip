@@ -1122,14 +1122,17 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
                 u8 *mtab = ws.metatab + (u64)b * META_TAB_BYTES;
                 u8 *imgm = img + ENC_IMG_META;
                 wg_hist8(m, mlen, S.F, (u32 *)dyn, tid);                   // (one wave counting ~170 KB of run lengths: 0.2 ms per 1 MiB q8 block)
+                const bool mrec = ws.meta_records && enc_rec_img_bytes(256u, 1u) + ENC_RING_BYTES <= ws.direct_budget &&
+                                  mlen >= enc_rec_img_bytes(256u, 1u) / 4u;                        // (uniform)
                 if (w0) {
-                    enc_o0_tables(mlen, mtab, imgm, S, lane);
+                    enc_o0_tables(mlen, mtab, imgm, S, lane, mrec ? ws.rcptab : nullptr);
                     if (lane == 0) {
                         D->rle_on = 1; D->rle_mlen = mlen; D->rle_lits = nlits;
                         D->rle_meta = (u64)m; D->meta_tab = (u64)mtab; D->meta_tab_len = S.tab_len;
                         if (S.status != ST_OK) D->status = S.status;
                         I1->data = (u64)m; I1->n = mlen; I1->image = (u64)imgm; I1->bits = O0_BITS; I1->order = 0;
-                        I1->ns = 256; I1->img_bytes = ENC_IMG_IDX + 2u * 257u;
+                        I1->ns = 256; I1->img_bytes = mrec ? enc_rec_img_bytes(256u, 1u) : ENC_IMG_IDX + 2u * 257u;
+                        I1->packed = mrec ? 2u : 0u; I1->affine = mrec ? 1u : 0u;
                         I1->scratch_end = (u64)(ws.scratch2 + (u64)b * ws.scratch2_stride + ws.scratch2_stride);
                         I1->active = S.status == ST_OK;
                     }

@@ -111,7 +111,12 @@ if __name__ == "__main__":
         emit(run(dc, 1024, 1 << 20, "q8", 1))
         emit(run(dc, 1024, 1 << 20, "q4", 193))
         emit(run(dc, 1024, 1 << 20, "q40+dir", 0))
+        emit(run(dc, 4096, 1 << 20, "q4", 193))                 # configs[3]'s flags on a batch (X_PACK | X_RLE | order 1)
+        emit(run(dc, 4096, 1 << 20, "q8", 65))                  # X_RLE without X_PACK: two long streams per block
+        emit(run(dc, 64, 1 << 20, "q8", 65))
+        emit(run(dc, 1, 1 << 20, "q8", 65))
     del dc
     torch.cuda.empty_cache()
     emit(single_call())
     emit(single_call(65536))
+    emit(single_call(1 << 20, "q8", 65))
