@@ -105,6 +105,7 @@ struct EncShared {
     i32 status;
     u32 pk_n, pk_meta_len, pk_len;       // wg_pack results
     u32 rl_nsyms, rl_lits, rl_runs;      // wg_rle_split results
+    u32 wtmp[12];        // wg_rle_split: per-wave partial results of its scans
     u32 sel4[16];        // wg_rle_split: v_perm selectors that move the bytes of a 4-bit mask to the bottom of a dword
 };
 
@@ -847,14 +848,18 @@ __device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, 
     }
     __syncthreads();
     PROF(11);
-    if (tid == 0) {
-        u32 ns = 0;
-        for (u32 j = 0; j < 256; j++) {
-            const bool use = 2 * (u64)rep[j] > (u64)S.F[j];
-            S.present[j] = use;
-            if (use) S.alpha[ns++] = (u8)j;
-        }
-        S.rl_nsyms = ns;
+    {
+        // rle.c:74-84: a symbol is run-length coded if more than half of its occurrences repeat the byte before them; the
+        // symbols in ascending order (FRONT_THREADS == 256: a thread per byte value)
+        const bool use = 2 * (u64)rep[tid] > (u64)S.F[tid];
+        const u64 um = __ballot(use);
+        if (lane == 0) S.wtmp[tid / WAVE] = (u32)__popcll(um);
+        S.present[tid] = use;
+        __syncthreads();
+        u32 at = (u32)__popcll(um & ((1ull << lane) - 1ull)), all = 0;
+        for (u32 w2 = 0; w2 < FRONT_THREADS / WAVE; w2++) { const u32 c = S.wtmp[w2]; if (w2 < tid / WAVE) at += c; all += c; }
+        if (use) S.alpha[at] = (u8)tid;
+        if (tid == 0) S.rl_nsyms = all;
     }
     __syncthreads();
 
@@ -952,17 +957,33 @@ __device__ void wg_rle_split(const u8 *data, u32 n, u8 *lits_end, u8 *runs_end, 
     cF[tid] = first; cL[tid] = nlit; cV[tid] = vbytes; cP[tid] = open;
     __syncthreads();
     PROF(13);
-    if (tid == 0) {
-        u32 nx = n;                                                            // next literal after the chunk
-        for (int t = FRONT_THREADS - 1; t >= 0; t--) { cN[t] = nx; if (cF[t] != NONE) nx = cF[t]; }
-        u32 al = 0, av = 0;
-        for (u32 t = 0; t < FRONT_THREADS; t++) {
-            const u32 v = cV[t] + (cP[t] != NONE ? var_len(cN[t] - cP[t] - 1) : 0u);
-            const u32 l = cL[t];
-            cL[t] = al; cV[t] = av;                                            // exclusive sums
-            al += l; av += v;
+    {
+        // by all threads (one thread walking the 256 chunks twice: 39 us per block)
+        // next literal after each chunk: the first of the later chunks' first literals (NONE is the largest value)
+        const u32 wv = tid / WAVE;
+        u32 v = first;
+#pragma unroll
+        for (int d = 1; d < WAVE; d <<= 1) { const u32 o = __shfl_down(v, d); if (lane + (u32)d < WAVE) v = v < o ? v : o; }
+        if (lane == 0) S.wtmp[wv] = v;                                         // min over the wave's chunks
+        u32 nx = __shfl_down(v, 1);
+        if (lane == WAVE - 1) nx = NONE;
+        __syncthreads();
+        for (u32 w2 = wv + 1; w2 < FRONT_THREADS / WAVE; w2++) { const u32 o = S.wtmp[w2]; nx = nx < o ? nx : o; }
+        if (nx == NONE) nx = n;
+        cN[tid] = nx;
+        // where each chunk's literals and run bytes go: exclusive sums
+        const u32 l = nlit, vb = vbytes + (open != NONE ? var_len(nx - open - 1u) : 0u);
+        const u32 li = wave_incl_scan(l, lane), vi = wave_incl_scan(vb, lane);
+        if (lane == WAVE - 1) { S.wtmp[4 + wv] = li; S.wtmp[8 + wv] = vi; }
+        __syncthreads();
+        u32 lbase = 0, vbase = 0, lall = 0, vall = 0;
+        for (u32 w2 = 0; w2 < FRONT_THREADS / WAVE; w2++) {
+            const u32 a = S.wtmp[4 + w2], c = S.wtmp[8 + w2];
+            if (w2 < wv) { lbase += a; vbase += c; }
+            lall += a; vall += c;
         }
-        S.rl_lits = al; S.rl_runs = av;
+        cL[tid] = lbase + li - l; cV[tid] = vbase + vi - vb;
+        if (tid == 0) { S.rl_lits = lall; S.rl_runs = vall; }
     }
     __syncthreads();
     {
