@@ -14,3 +14,5 @@ run q4 193 1048576 16384
 run mixed 1 65536 32768            # configs[4]: one GPU's share
 run mixed 1 65536 98304
 run q40+dir 1 65536 61440          # small q40 blocks
+run q8 65 1048576 4096             # X_RLE without X_PACK
+run q8 65 1048576 16384
