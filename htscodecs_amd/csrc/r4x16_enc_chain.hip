@@ -17,7 +17,10 @@ extern "C" bool r4x16_first_on_device(u32 bit);                                 
 // fit beside the shared reciprocal table, up to 64 (four waves); 1,280-byte allocation granules.
 // (sizes are 16 mod 128: consecutive streams start four LDS banks apart, so that the eight streams of a
 // 32-lane access group do not all hit the same bank when they touch the same offset)
-static const u32 ENC_CLASSES[] = {656, 1296, 2576, 4752, 6416, 12816, 33296, 73616, 147344};
+// (round 3: the steps above 12,816 were 33,296 and 73,616 - the 13 KB image of a 79-symbol alphabet, what X_PACK|X_RLE
+//  makes of four-letter quality values, sat in the 33 KB class at four streams per CU: 11.8 ms for 4,096 such streams.
+//  Now every count of streams per CU from nine to one has its class: 147,344 bytes beside the reciprocal table / k.)
+static const u32 ENC_CLASSES[] = {656, 1296, 2576, 4752, 6416, 12816, 16272, 24464, 36752, 49040, 73616, 147344};
 // packed rows (20..64 symbols, 10-bit tables): 46 symbols need 3,532 bytes -> 45 streams per CU beside the small
 // reciprocal table (3,536 is 80 mod 128: consecutive streams start 20 banks apart)
 static const u32 ENC_PK_CLASSES[] = {1168, 2064, 2832, 3536, 3728, 4752, 6416};
