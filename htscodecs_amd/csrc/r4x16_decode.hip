@@ -1809,8 +1809,8 @@ __device__ bool rle_expand_wg(const u8 *lit, u32 lit_len, const u8 *runs, u32 ru
 //             in an LDS tile, a prefix maximum over the marks names the literal every byte belongs to, ds_bpermute
 //             fetches the values; a pass without any mark lies inside one run and is a plain fill.  Up to three
 //             bytes that do not fill a dword wait for the next trip, so every store is a whole dword.
-// A trip with a run of 2^24 bytes or more (prefix sums beyond 32 bits; only a hostile stream or a giant block has one)
-// takes the plain route: byte stores, 64-bit sums.
+// A trip with a run of 2^22 bytes or more (256 of them would take a trip's prefix sums beyond 32 bits; only a hostile
+// stream or a giant block has one) takes the plain route: byte stores, 64-bit sums.
 // ---------------------------------------------------------------------------------------------
 typedef u32 u32_unaligned __attribute__((aligned(1)));
 __device__ __forceinline__ u32 wave_incl_max(u32 v)
@@ -1947,7 +1947,7 @@ __device__ bool rle_expand_wave(const u8 *lit_, u32 lit_len_, const u8 *runs_, u
         }
         used += nr < avail ? nr : avail;
 
-        if (__ballot((rv[0] | rv[1] | rv[2] | rv[3]) > 0x00ffffffu)) {
+        if (__ballot((rv[0] | rv[1] | rv[2] | rv[3]) > 0x003fffffu)) {           // (256 lengths of up to 2^22 + 1 bytes: sums below 2^31)
             // ---- the plain route of a trip with a giant run: 64-bit sums, byte stores, the wave fills long runs together
             for (u32 k = lane; k < cb; k += WAVE) gout[outp - cb + k] = (u8)(carry_w >> (8 * k));
             cb = 0;

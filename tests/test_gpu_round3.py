@@ -246,7 +246,8 @@ def test_run_length_shapes(H, oracle, monkeypatch, route):
       * run lengths around the varint sizes (127 / 128, 16,383 / 16,384, 2^21) and long stretches of two- and
         three-byte varints (the one-wave route decodes the run stream 60 bytes at a time with four bytes of history);
       * literal counts around the trip sizes (63 .. 65, 255 .. 257, 1,023 .. 1,025) and a run at the very end;
-      * a run of more than 2^24 bytes in a 20 MiB block (prefix sums beyond 32 bits per trip: the plain route);
+      * runs around 2^22 bytes (where a trip leaves its 32-bit sums for the plain route) and one of more than 2^24 in
+        a 20 MiB block;
       * X_PACK in front (order 192 / 193) and quality-like data."""
     monkeypatch.setenv("R4X16_BACK_WG_PER_CU", route)
     rs = np.random.RandomState(4242)
@@ -258,6 +259,7 @@ def test_run_length_shapes(H, oracle, monkeypatch, route):
     add(_runs(rs, 400, [16382, 16383, 16384, 16385, 300, 5000], [1, 2, 3]))
     add(_runs(rs, 2000, list(range(129, 400)), [7, 8, 9, 10, 11, 12]))              # two-byte varints back to back
     add(_runs(rs, 40, [1 << 21, (1 << 21) + 1, 70000], [5, 6]), os_=(64,))          # four-byte varints
+    add(_runs(rs, 6, [(1 << 22) - 1, 1 << 22, (1 << 22) + 1], [5, 6]), os_=(64,))   # either side of the plain route's threshold
     for nlit in (63, 64, 65, 255, 256, 257, 1023, 1024, 1025):
         a = _runs(rs, nlit, [1, 1, 1, 2, 5, 40], [20, 21, 22, 23, 24, 25, 26, 27])
         add(a, os_=(65,))
