@@ -2229,16 +2229,20 @@ static const struct { u32 bytes; int qpw; int lv; } DEC_CLASSES[] = {
     {40976, 1, 3}, {53648, 1, 3}, {64016, 1, 3},
     {22528, 1, 4}, {32768, 1, 4}, {53248, 1, 4}, {81920, 1, 4}, {163840, 1, 4},
     // direct blocks (level 6; only batches that leave LDS to spare make such images, r4x16_dec_direct_budget): four
-    // workgroups per CU - one wave per SIMD - with as many streams per wave as fit, then one stream per wave.  Few
+    // workgroups per CU and more - a wave per SIMD at least - with up to eight streams per wave, then one stream per wave.  Few
     // classes on purpose: every class is a launch, classes with streams run one after the other, and a batch that mixes
     // alphabets (q4 / q8 / q40) should not fall into more classes than it did with the compressed rows
-    {2576, 15, 6}, {4112, 9, 6}, {8080, 5, 6}, {13584, 3, 6}, {20368, 2, 6}, {32000, 1, 6}, {40960, 1, 6}, {53760, 1, 6},
+    // (at most eight streams per wave: the step of this loop is LDS round trips, and a wave with more than 32 live
+    //  lanes pays for both halves - 4,096 x 1 MiB q8 literal streams: 481 cycles per step at nine streams per wave,
+    //  372 at eight; the compressed rows' loop gains 2 % from the same change.  Seven per wave and five workgroups per CU
+    //  - 35 streams instead of 32 - put two waves on one SIMD: 26.1 ms again, and 8,192 q8 streams 39.5 instead of 33.5)
+    {2576, 8, 6}, {4112, 8, 6}, {8080, 5, 6}, {13584, 3, 6}, {20368, 2, 6}, {32000, 1, 6}, {40960, 1, 6}, {53760, 1, 6},
     {81920, 1, 6}, {163840, 1, 6},
     // the same for order-0 streams (level 7 = level 6's kernel; images of at most 2,820 bytes).  A wave walks its order-1
     // quads, then its order-0 quads: the run lengths of a block with X_RLE in a launch of their own run beside the
     // block's literals where launches run side by side (one 1 MiB q8 block: 25.0 -> 18.7 ms), not behind them in the
     // same wave (only where launches do run side by side, DecClassTab.split_o0)
-    {2576, 15, 7}, {4112, 9, 7},
+    {2576, 8, 7}, {4112, 8, 7},
 };
 // workgroups of `lds_bytes` each that one CU holds at once (1,280-byte LDS granules, 32 wave slots)
 static int resident_per_cu(size_t lds_bytes, int waves_per_wg)
@@ -2383,8 +2387,10 @@ static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitem
     for (u32 ci = 0; ci < DEC_NCLS; ci++) {
         const auto &c = DEC_CLASSES[ci];
         static const int force_pk = getenv("R4X16_DEC_QPW_PK") ? atoi(getenv("R4X16_DEC_QPW_PK")) : 0;
-        const int qpw = (c.lv == 1 && force_pk && c.bytes == 3496) ? force_pk :
+        int qpw = (c.lv == 1 && force_pk && c.bytes == 3496) ? force_pk :
                         c.lv != 2 ? c.qpw : (force_qpw && c.bytes == 5360) ? force_qpw : (force_small && c.bytes < 5360) ? force_small : c.qpw;
+        static const int force_dir = getenv("R4X16_DEC_QPW_DIR") ? atoi(getenv("R4X16_DEC_QPW_DIR")) : 0;
+        if (c.lv >= 6 && force_dir > 0 && qpw > force_dir) qpw = force_dir;
         const size_t ldsb = (size_t)qpw * c.bytes;
         if (fk && (ldsb > FORK_LDS_MAX) != (pass == 1)) continue;
         const int grid = r4x16_resident_grid(ldsb, 1, (nitems + qpw - 1) / qpw);

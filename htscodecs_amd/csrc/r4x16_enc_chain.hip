@@ -126,12 +126,14 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
     auto launch_rec = [&](u32 r) {
         const auto &c = ENC_REC_CLASSES[r];
         if (!ws->direct_budget) return;                       // (no stream of this batch was given records)
-        const size_t ldsb = (size_t)c.qpw * c.bytes;
+        static const int force_rec = getenv("R4X16_ENC_QPW_REC") ? atoi(getenv("R4X16_ENC_QPW_REC")) : 0;   // tuning aid
+        const int qpw = (force_rec > 0 && c.qpw > force_rec) ? force_rec : c.qpw;
+        const size_t ldsb = (size_t)qpw * c.bytes;
         if (fk && (ldsb > FORK_LDS_MAX) != (pass == 1)) return;
-        const int grid = r4x16_resident_grid(ldsb, 1, (nitems + c.qpw - 1) / c.qpw);
+        const int grid = r4x16_resident_grid(ldsb, 1, (nitems + qpw - 1) / qpw);
         if (fk && pass == 0) s = fk->pick(s0, launched++);
         r4x16_enc_chain_rec_launch(grid, ldsb, s, ws->items, ws->rcptab, ws->dump, (const u32 *)ws->cls_list,
-                                   (const u32 *)(ws->cls_count + ENC_NCLS + ENC_PK_NCLS + r), c.qpw, c.bytes);
+                                   (const u32 *)(ws->cls_count + ENC_NCLS + ENC_PK_NCLS + r), qpw, c.bytes);
     };
     for (pass = 0; pass < (fk ? 2 : 1); pass++) {
         if (fk && pass == 1) { s = s0; fk->end(s0); }
