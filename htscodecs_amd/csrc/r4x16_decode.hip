@@ -556,8 +556,20 @@ __device__ __forceinline__ u32 chain_decode_dir(const u8 *img_lds, u32 nsym, u8 
     if (ORDER == 1 && !AFF && count) bad = *(LAS const u16 *)(unsigned long)imga;
     auto to_bytes = [&](u32 a) -> u32 { return AFF ? (a & 0x7f7f7f7fu) + c4 : a; };
 
+    u32 oq0 = 0, oq1 = 0, oq_t = 0;                         // order 0: the dwords of the last full trip, not yet stored
+    bool oq_have = false;
+    auto oq_flush = [&]() {
+        if (ORDER == 0 && oq_have) {
+            if (active) {
+                *(gu32_unaligned *)(out + 4 * (u64)(oq_t + k)) = oq0;
+                *(gu32_unaligned *)(out + 4 * (u64)(oq_t + 4u + k)) = oq1;
+            }
+            oq_have = false;
+        }
+    };
     auto trip = [&](auto fastc) {
         constexpr bool FAST = decltype(fastc)::value;
+        oq_flush();
 #pragma unroll
         for (int u = 0; u < TRIP_STEPS; u++) {
             const u32 T = t + (u32)u;
@@ -642,7 +654,10 @@ __device__ __forceinline__ u32 chain_decode_dir(const u8 *img_lds, u32 nsym, u8 
                         const u32 sel = k | ((4u + k) << 8);
                         const u32 p01 = __builtin_amdgcn_perm(A1, A0, sel), p23 = __builtin_amdgcn_perm(A3, A2, sel);
                         const u32 dw = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
-                        if (active) *(gu32_unaligned *)(out + 4 * (u64)(T - 3u + k)) = dw;
+                        // (held back until the top of the next trip: a store issued here is what the ring refill behind
+                        //  this trip would wait for - loads and stores share the counter - at the price of its whole
+                        //  round trip: order-0 streams took ~590 cycles per step on this loop, order-1 ones 372)
+                        if (u < 4) oq0 = dw; else oq1 = dw;
                     }
                 } else {
                     if (AFF) byte0 = ((byte0 & 0x7fu) + c4) & 0xffu;
@@ -654,8 +669,10 @@ __device__ __forceinline__ u32 chain_decode_dir(const u8 *img_lds, u32 nsym, u8 
                 }
             }
         }
+        if (ORDER == 0 && FAST) { oq_t = t; oq_have = true; }
         t += TRIP_STEPS;
     };
+    static_assert(TRIP_STEPS == 8, "order 0 holds two dwords per trip back");
     while (wave_any(t < count)) {
         const bool slow = active && (t + TRIP_STEPS > count || cursor + 4 * TRIP_STEPS > nwords);
         if (!wave_any(slow)) trip(std::true_type{});
@@ -672,6 +689,7 @@ __device__ __forceinline__ u32 chain_decode_dir(const u8 *img_lds, u32 nsym, u8 
             __syncthreads();
         }
     }
+    oq_flush();
     if (ORDER == 1 && count) {
         // t steps ran (see chain_decode_lds).  !AFF: a chain whose count equals t still has its last byte in hdr.
         // AFF: acc already holds every symbol decoded (the live ones only), the newest in its top byte.
