@@ -280,3 +280,29 @@ def test_run_length_shapes(H, oracle, monkeypatch, route):
     assert all(s == 0 for s in st), st
     bad = [(i, orders[i], len(datas[i])) for i in range(len(datas)) if dec[i] != datas[i]]
     assert not bad, bad
+
+
+def test_pack_widths(H, oracle):
+    """X_PACK both ways against the oracle for every code width (1, 2, 4 bits and the copy case), alphabets at the edges
+    of each (2, 3, 4, 5, 8, 16, 17 symbols), lengths around the sixteen-byte trips of the unpacking loops, with and
+    without X_RLE and order 1 behind it."""
+    rs = np.random.RandomState(99)
+    datas, orders = [], []
+    for nsym in (1, 2, 3, 4, 5, 8, 15, 16, 17):
+        syms = rs.choice(256, nsym, replace=False).astype(np.uint8)
+        for n in (15, 16, 17, 31, 33, 4095, 4096, 4097, 70001):
+            a = syms[rs.randint(0, nsym, n)]
+            for o in (128, 129, 192, 193):
+                datas.append(a.tobytes()); orders.append(o)
+    for name in ("q8", "q4"):
+        for o in (128, 129, 193):
+            datas.append(np.ascontiguousarray(datagen.tile(name, 300003, 7)).tobytes()); orders.append(o)
+    enc, st = H.compress_batch(datas, orders)
+    assert all(s == 0 for s in st), st
+    want = [oracle.compress(d, o) for d, o in zip(datas, orders)]
+    bad = [(i, orders[i], len(datas[i])) for i in range(len(datas)) if enc[i] != want[i]]
+    assert not bad, bad[:8]
+    dec, st = H.uncompress_batch(want, [len(d) for d in datas])
+    assert all(s == 0 for s in st), st
+    bad = [(i, orders[i], len(datas[i])) for i in range(len(datas)) if dec[i] != datas[i]]
+    assert not bad, bad[:8]
