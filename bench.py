@@ -285,6 +285,135 @@ def configs4_leg(torch, H, dc, dev, dist, red_dev, shard, rank, world, steps=3, 
             "ms_per_step": round(elapsed / steps * 1e3, 3), "steps": steps, "warmup": warmup}
 
 
+HETERO_ORDERS = (0, 1, 65, 193)
+
+
+def hetero_plan(total_bytes, seed=2024, lo=4096, hi=1 << 20, uniform=None, first_block=0):
+    """Block sizes, texts and orders of the heterogeneous batch (host arithmetic only): sizes log-uniform in
+    [lo, hi] - or all `uniform` bytes for the equal-bytes, equal-mix comparison batch -, text q4 / q8 / q40+dir by
+    b mod 3, order drawn from HETERO_ORDERS.  The shape of the reference's real callers: token columns of any size
+    (htscodecs/tokenise_name3.c:1246-1300), a short last block (tests/rANS_static4x16pr_test.c:139-176)."""
+    rs = np.random.RandomState(seed)
+    if uniform:
+        n = max(1, int(total_bytes // uniform))
+        sizes = np.full(n, uniform, dtype=np.int64)
+    else:
+        mean = (hi - lo) / np.log(hi / lo)
+        draw = np.exp(rs.uniform(np.log(lo), np.log(hi), size=int(total_bytes / mean * 1.3) + 64)).astype(np.int64)
+        n = int(np.searchsorted(np.cumsum(draw), total_bytes)) + 1
+        sizes = draw[:n]
+    orders = np.asarray(HETERO_ORDERS, dtype=np.int32)[rs.randint(0, len(HETERO_ORDERS), size=n)]
+    text = (np.arange(n) + first_block) % 3
+    return sizes, orders, text
+
+
+HETERO_TEXTS = ("q4", "q8", "q40+dir")
+
+
+def hetero_batch(torch, dev, sizes, text):
+    """The batch in HBM: the blocks of one text are consecutive slices of its cyclic repetition, the three texts'
+    regions follow each other; block b lies at in_off[b].  Returns (d_in, in_off, in_size, text_off) - text_off[b] is
+    the block's position in its text's repetition (for the host copy)."""
+    import datagen
+    n = len(sizes)
+    in_off = np.zeros(n, dtype=np.int64)
+    text_off = np.zeros(n, dtype=np.int64)
+    parts, base_at = [], 0
+    for t, nm in enumerate(HETERO_TEXTS):
+        idx = np.nonzero(text == t)[0]
+        sz = sizes[idx]
+        starts = np.concatenate([[0], np.cumsum(sz)[:-1]]) if len(sz) else np.zeros(0, dtype=np.int64)
+        tot = int(sz.sum())
+        base = datagen.base_text(nm)
+        d_base = torch.from_numpy(np.ascontiguousarray(base)).to(dev)
+        parts.append(d_base.repeat(tot // len(base) + 2)[:tot])
+        in_off[idx] = base_at + starts
+        text_off[idx] = starts
+        base_at += tot
+    d_in = torch.cat(parts)
+    return d_in, torch.from_numpy(in_off).to(dev), torch.from_numpy(sizes.astype(np.int32)).to(dev), text_off
+
+
+def hetero_block(sizes, text, text_off, b):
+    import datagen
+    return np.ascontiguousarray(datagen.tile(HETERO_TEXTS[int(text[b])], int(sizes[b]), 0, offset=int(text_off[b])))
+
+
+def hetero_run(torch, H, dc, dev, total_bytes, uniform=None, reps=2, check=64, seed=2024, first_block=0):
+    """One heterogeneous (or comparison) batch through rans4x16_hip_{compress,uncompress}_dev with per-block orders:
+    best-of-`reps` HIP-event times of each direction, every block round-tripped, `check` blocks byte-compared with
+    the CPU checker."""
+    sizes, orders, text = hetero_plan(total_bytes, seed=seed, uniform=uniform, first_block=first_block)
+    n = len(sizes)
+    d_in, in_off, in_size, text_off = hetero_batch(torch, dev, sizes, text)
+    L = H.load()
+    caps = np.fromiter((L.rans_compress_bound_4x16(int(s), int(o)) for s, o in zip(sizes, orders)), dtype=np.int64, count=n)
+    slots = (caps + 255) // 256 * 256
+    comp_off_h = np.concatenate([[0], np.cumsum(slots)[:-1]])
+    d_comp = torch.zeros(int(slots.sum()), dtype=torch.uint8, device=dev)
+    comp_off = torch.from_numpy(comp_off_h).to(dev)
+    comp_cap = torch.from_numpy(caps.astype(np.int32)).to(dev)
+    d_order = torch.from_numpy(orders).to(dev)
+    comp_size = torch.zeros(n, dtype=torch.int32, device=dev)
+    st_e = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    d_back = torch.zeros_like(d_in)
+    back_size = torch.zeros(n, dtype=torch.int32, device=dev)
+    st_d = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    max_in, max_cap = int(sizes.max()), int(caps.max())
+
+    def enc():
+        dc.compress(d_in, in_off, in_size, d_comp, comp_off, comp_cap, comp_size, st_e, 0, max_in, d_order=d_order,
+                    total_in_size=int(sizes.sum()))
+
+    def dec():
+        dc.uncompress(d_comp, comp_off, comp_size, d_back, in_off, in_size, back_size, st_d, max_cap, max_in,
+                      total_out_cap=int(sizes.sum()))
+
+    enc(); dec(); torch.cuda.synchronize()                  # warm: workspace, side streams
+    te, td = [], []
+    for _ in range(reps):
+        d_back.zero_(); back_size.zero_(); comp_size.zero_(); st_e.fill_(-1); st_d.fill_(-1)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record(); enc(); e1.record(); dec(); e2.record()
+        torch.cuda.synchronize()
+        te.append(e0.elapsed_time(e1)); td.append(e1.elapsed_time(e2))
+    ok = int((st_e != 0).sum()) == 0 and int((st_d != 0).sum()) == 0 and bool(torch.equal(back_size, in_size)) \
+        and bool(torch.equal(d_back, d_in))
+    import cpu_libs
+    chk = cpu_libs.oracle()
+    csz = comp_size.cpu().numpy()
+    rs = np.random.RandomState(5)
+    big, small = int(np.argmax(sizes)), int(np.argmin(sizes))
+    sample = sorted(set([0, n - 1, big, small] + [int(x) for x in rs.randint(0, n, size=max(0, check - 4))]))
+    same = 0
+    for b in sample:
+        want = chk.compress(hetero_block(sizes, text, text_off, b).tobytes(), int(orders[b]))
+        got = d_comp[int(comp_off_h[b]):int(comp_off_h[b]) + int(csz[b])].cpu().numpy().tobytes()
+        assert got == want, f"hetero leg: block {b} (size {sizes[b]}, order {orders[b]}) differs from the CPU checker"
+        same += 1
+    tot = int(sizes.sum())
+    be, bd = min(te), min(td)
+    return {"blocks": n, "bytes": tot, "sizes": "uniform %d" % uniform if uniform else "log-uniform 4096..1048576",
+            "texts": "q4/q8/q40+dir by b mod 3", "orders": "drawn from %s" % (HETERO_ORDERS,),
+            "enc_ms": round(be, 3), "dec_ms": round(bd, 3),
+            "enc_GBps": round(tot / be / 1e6, 2), "dec_GBps": round(tot / bd / 1e6, 2),
+            "both_GBps": round(tot / (be + bd) / 1e6, 2), "ratio": round(float(csz.sum()) / tot, 4),
+            "roundtrip_ok": ok, "bytes_equal_cpu_blocks": same, "workspace_GB": round(dc.workspace_bytes() / 2**30, 2)}
+
+
+def hetero_leg(torch, H, dc, dev, total_bytes=16 << 30, first_block=0):
+    """a batch whose blocks differ in length, alphabet and order, beside an equal-bytes, equal-mix
+    batch of uniform 64 KiB blocks."""
+    het = hetero_run(torch, H, dc, dev, total_bytes, first_block=first_block)
+    assert het["roundtrip_ok"], "hetero leg: round trip"
+    torch.cuda.empty_cache()
+    uni = hetero_run(torch, H, dc, dev, total_bytes, uniform=65536, first_block=first_block)
+    assert uni["roundtrip_ok"], "hetero leg (uniform 64 KiB): round trip"
+    torch.cuda.empty_cache()
+    return {"hetero": het, "uniform_64KiB": uni,
+            "enc_ratio": round(het["enc_GBps"] / uni["enc_GBps"], 3), "dec_ratio": round(het["dec_GBps"] / uni["dec_GBps"], 3)}
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script (fresh processes; this parent
     never initialises the GPU), wait for them, pass rank 0's output through."""

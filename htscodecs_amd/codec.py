@@ -122,6 +122,16 @@ class _Ctx:
     def error(self):
         return self.L.rans4x16_hip_last_error(self.h).decode()
 
+    def set_option(self, name, value):
+        if self.L.rans4x16_hip_set_option(self.h, name.encode(), int(value)) != 0:
+            raise KeyError(f"unknown option {name!r}")
+
+    def get_option(self, name):
+        v = C.c_long(0)
+        if self.L.rans4x16_hip_get_option(self.h, name.encode(), C.byref(v)) != 0:
+            raise KeyError(f"unknown option {name!r}")
+        return v.value
+
 
 _tls = threading.local()
 
@@ -133,6 +143,28 @@ def _thread_ctx():
     if ctx is None:
         ctx = _tls.ctx = _Ctx()
     return ctx
+
+
+def set_option(name, value):
+    """rans4x16_hip_set_option on the calling thread's context (the one the host-batch helpers below use)."""
+    _thread_ctx().set_option(name, value)
+
+
+def get_option(name):
+    return _thread_ctx().get_option(name)
+
+
+def get_default_option(name):
+    v = C.c_long(0)
+    if _lib.load().rans4x16_hip_get_option(None, name.encode(), C.byref(v)) != 0:
+        raise KeyError(f"unknown option {name!r}")
+    return v.value
+
+
+def set_default_option(name, value):
+    """Process-wide default (ctx == NULL): contexts created from now on, and the combiner if it has not started."""
+    if _lib.load().rans4x16_hip_set_option(None, name.encode(), int(value)) != 0:
+        raise KeyError(f"unknown option {name!r}")
 
 
 def _host_batch(blocks, decode, orders=None, caps=None):
@@ -264,6 +296,12 @@ class DeviceCodec:
     def timing(self, enable=True):
         self.L.rans4x16_hip_timing(self.ctx.h, 1 if enable else 0)
 
+    def set_option(self, name, value):
+        self.ctx.set_option(name, value)
+
+    def get_option(self, name):
+        return self.ctx.get_option(name)
+
     def timing_read(self, which, reset=True):
         ms = C.c_double(0)
         k = C.c_int(0)
@@ -287,29 +325,29 @@ class DeviceCodec:
         return C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
 
     def compress(self, d_in, in_off, in_size, d_out, out_off, out_cap, out_size, status, order,
-                 max_in_size, d_order=None):
+                 max_in_size, d_order=None, total_in_size=0):
         t = self.torch
         assert d_in.dtype == t.uint8 and d_out.dtype == t.uint8
         assert in_off.dtype == t.int64 and out_off.dtype == t.int64
         assert in_size.dtype == t.int32 and out_cap.dtype == t.int32
         assert out_size.dtype == t.int32 and status.dtype == t.int32
         n = in_off.numel()
-        rc = self.L.rans4x16_hip_compress_dev(
+        rc = self.L.rans4x16_hip_compress_dev_sized(
             self.ctx.h, n, d_in.data_ptr(), in_off.data_ptr(), in_size.data_ptr(),
             d_out.data_ptr(), out_off.data_ptr(), out_cap.data_ptr(), out_size.data_ptr(),
             status.data_ptr(), int(order), d_order.data_ptr() if d_order is not None else None,
-            int(max_in_size), self._stream())
+            int(max_in_size), int(total_in_size), self._stream())
         if rc != 0:
             raise RuntimeError("compress_dev: " + self.ctx.error())
 
     def uncompress(self, d_in, in_off, in_size, d_out, out_off, out_cap, out_size, status,
-                   max_in_size, max_out_cap):
+                   max_in_size, max_out_cap, total_out_cap=0):
         t = self.torch
         assert d_in.dtype == t.uint8 and d_out.dtype == t.uint8
         n = in_off.numel()
-        rc = self.L.rans4x16_hip_uncompress_dev(
+        rc = self.L.rans4x16_hip_uncompress_dev_sized(
             self.ctx.h, n, d_in.data_ptr(), in_off.data_ptr(), in_size.data_ptr(),
             d_out.data_ptr(), out_off.data_ptr(), out_cap.data_ptr(), out_size.data_ptr(),
-            status.data_ptr(), int(max_in_size), int(max_out_cap), self._stream())
+            status.data_ptr(), int(max_in_size), int(max_out_cap), int(total_out_cap), self._stream())
         if rc != 0:
             raise RuntimeError("uncompress_dev: " + self.ctx.error())

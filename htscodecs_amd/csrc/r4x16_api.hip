@@ -5,7 +5,99 @@
 // r4x16_encode.hip / r4x16_decode.hip; there is no CPU code path to fall back to.
 #include "r4x16_host.h"
 
-extern "C" const char *rans4x16_hip_version(void) { return "rans4x16_hip 0.1 (gfx950)"; }
+extern "C" const char *rans4x16_hip_version(void) { return "rans4x16_hip 0.2 (gfx950)"; }
+
+// ---------------------------------------------------------------------------------------------
+// Options (include/rans4x16_hip.h part 2b).  {name, environment variable that provides the default, built-in default}.
+// ---------------------------------------------------------------------------------------------
+static const struct { const char *name, *env; long dflt; } OPT_TAB[OPT_COUNT] = {
+    /* OPT_DEC_DIRECT        */ {"dec_direct", "R4X16_DEC_DIRECT", 1},
+    /* OPT_ENC_DIRECT        */ {"enc_direct", "R4X16_ENC_DIRECT", 1},
+    /* OPT_BACK_WG_PER_CU    */ {"back_wg_per_cu", "R4X16_BACK_WG_PER_CU", 0},
+    /* OPT_SCHED_SORT        */ {"sched_sort", "R4X16_SCHED_SORT", 1},
+    /* OPT_SCHED_CLAIM       */ {"sched_claim", "R4X16_SCHED_CLAIM", 1},
+    /* OPT_SCHED_CONCURRENT  */ {"sched_concurrent", "R4X16_SCHED_CONCURRENT", 1},
+    /* OPT_MAX_WS_MB         */ {"max_workspace_mb", "R4X16_MAX_WS_MB", 96 << 10},
+    /* OPT_HOST_STRIPE_DEV   */ {"host_stripe_dev", "R4X16_HOST_STRIPE_DEV", 1},
+    /* OPT_HOST_PIPE_MB      */ {"host_pipe_mb", "R4X16_HOST_PIPE_MB", 64},
+    /* OPT_HOST_THREADS      */ {"host_threads", "R4X16_HOST_THREADS", 8},
+    /* OPT_HOST_LANES        */ {"host_lanes", "R4X16_HOST_LANES", 2},
+    /* OPT_HOST_SLAB_MIN_MB  */ {"host_slab_min_mb", "R4X16_HOST_SLAB_MIN_MB", 32},
+    /* OPT_HOST_DEC_SLABS    */ {"host_dec_slabs", "R4X16_HOST_DEC_SLABS", 1},
+    /* OPT_HOST_ENC_SLABS    */ {"host_enc_slabs", "R4X16_HOST_ENC_SLABS", 1},
+    /* OPT_HOST_PACK         */ {"host_pack", "R4X16_HOST_PACK", 1},
+    /* OPT_HOST_TRACE        */ {"host_trace", "R4X16_HOST_TRACE", 0},
+    /* OPT_DEC_QPW           */ {"dec_qpw", "R4X16_DEC_QPW", 0},
+    /* OPT_DEC_QPW_SMALL     */ {"dec_qpw_small", "R4X16_DEC_QPW_SMALL", 0},
+    /* OPT_DEC_QPW_PK        */ {"dec_qpw_pk", "R4X16_DEC_QPW_PK", 0},
+    /* OPT_DEC_QPW_DIR       */ {"dec_qpw_dir", "R4X16_DEC_QPW_DIR", 0},
+    /* OPT_ENC_QPW           */ {"enc_qpw", "R4X16_ENC_QPW", 0},
+    /* OPT_ENC_WAVES         */ {"enc_waves", "R4X16_ENC_WAVES", 0},
+    /* OPT_ENC_QPW_REC       */ {"enc_qpw_rec", "R4X16_ENC_QPW_REC", 0},
+    /* OPT_ENC_QPW_CAP       */ {"enc_qpw_cap", "R4X16_ENC_QPW_CAP", 64},
+    /* OPT_FRONT_LDS         */ {"front_lds", "R4X16_FRONT_LDS", 0},
+    // process-wide (set with ctx == NULL before the first single-block call / multi-device call)
+    /* OPT_COMBINE           */ {"combine", "R4X16_COMBINE", 1},
+    /* OPT_COMBINE_WINDOW_US */ {"combine_window_us", "R4X16_COMBINE_WINDOW_US", -1},
+    /* OPT_COMBINE_MAX       */ {"combine_max", "R4X16_COMBINE_MAX", 256},
+    /* OPT_COMBINE_WORKERS   */ {"combine_workers", "R4X16_COMBINE_WORKERS", 1},
+    /* OPT_COMBINE_MAX_MB    */ {"combine_max_mb", "R4X16_COMBINE_MAX_MB", 2048},
+    /* OPT_NUMA              */ {"numa", "R4X16_NUMA", 1},
+};
+// the process-wide defaults: the environment is read here, once, and nowhere else
+static std::mutex g_opts_mu;
+static R4Opts *opts_defaults_rw()
+{
+    static R4Opts d;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (int i = 0; i < OPT_COUNT; i++) {
+            const char *e = getenv(OPT_TAB[i].env);
+            d.v[i] = e && *e ? atol(e) : OPT_TAB[i].dflt;
+        }
+    });
+    return &d;
+}
+extern "C" const R4Opts *r4x16_opts_defaults(void) { return opts_defaults_rw(); }
+static int opt_index(const char *name)
+{
+    if (!name) return -1;
+    for (int i = 0; i < OPT_COUNT; i++) if (!strcmp(name, OPT_TAB[i].name)) return i;
+    return -1;
+}
+extern "C" int rans4x16_hip_set_option(rans4x16_hip_ctx *c, const char *name, long value)
+{
+    const int i = opt_index(name);
+    if (i < 0) return -1;
+    if (!c) {                                                    // the defaults of contexts created from now on, the contexts
+        R4Opts *d = opts_defaults_rw();                           // behind the five drop-in symbols, and the process-wide options
+        std::lock_guard<std::mutex> g(g_opts_mu);
+        d->v[i] = value;
+        return 0;
+    }
+    c->opts.v[i] = value;
+    if (i == OPT_MAX_WS_MB) c->max_ws = value > 0 ? (size_t)value << 20 : (size_t)96 << 30;
+    return 0;
+}
+// a consistent copy of the process-wide defaults (contexts at creation; the drop-in symbols' contexts at every call)
+static void opts_snapshot(rans4x16_hip_ctx *c)
+{
+    const R4Opts *d = r4x16_opts_defaults();
+    std::lock_guard<std::mutex> g(g_opts_mu);
+    c->opts = *d;
+    c->max_ws = d->v[OPT_MAX_WS_MB] > 0 ? (size_t)d->v[OPT_MAX_WS_MB] << 20 : (size_t)96 << 30;
+}
+extern "C" int rans4x16_hip_get_option(const rans4x16_hip_ctx *c, const char *name, long *value)
+{
+    const int i = opt_index(name);
+    if (i < 0 || !value) return -1;
+    if (c) { *value = c->opts.v[i]; return 0; }
+    const R4Opts *d = r4x16_opts_defaults();
+    std::lock_guard<std::mutex> g(g_opts_mu);
+    *value = d->v[i];
+    return 0;
+}
+extern "C" const char *rans4x16_hip_option_name(int index) { return index >= 0 && index < OPT_COUNT ? OPT_TAB[index].name : nullptr; }
 
 extern "C" rans4x16_hip_ctx *rans4x16_hip_create(int device)
 {
@@ -19,6 +111,7 @@ extern "C" rans4x16_hip_ctx *rans4x16_hip_create(int device)
     if (device >= ndev) return nullptr;
     rans4x16_hip_ctx *c = new rans4x16_hip_ctx();
     c->device = device;
+    opts_snapshot(c);
     if (hipSetDevice(device) != hipSuccess) { delete c; return nullptr; }
     // log(1024+k), log(4096+k) from the host libm: the same values the reference's compute_shift
     // obtains at rANS_static4x16pr.c:651-652 on this machine.
@@ -43,6 +136,9 @@ extern "C" rans4x16_hip_ctx *rans4x16_hip_create(int device)
         rans4x16_hip_destroy(c);
         return nullptr;
     }
+    for (int w = 0; w < 2; w++)
+        if (hipHostMalloc((void **)&c->hint[w].work, CLS_MAX * sizeof(u64), hipHostMallocDefault) == hipSuccess) memset(c->hint[w].work, 0, CLS_MAX * sizeof(u64));
+        else c->hint[w].work = nullptr;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         c->stream = nullptr;
         rans4x16_hip_destroy(c);
@@ -63,6 +159,7 @@ extern "C" void rans4x16_hip_destroy(rans4x16_hip_ctx *c)
         for (int i = 0; i < R4_FORK_STREAMS; i++) if (c->fork.aux[i]) { (void)hipStreamSynchronize(c->fork.aux[i]); (void)hipStreamDestroy(c->fork.aux[i]); }
         for (int i = 0; i <= R4_FORK_STREAMS; i++) if (c->fork.ev[i]) (void)hipEventDestroy(c->fork.ev[i]);
     }
+    for (int w = 0; w < 2; w++) if (c->hint[w].work) (void)hipHostFree(c->hint[w].work);
     if (c->ws_done) (void)hipEventDestroy(c->ws_done);
     if (c->ws) (void)hipFree(c->ws);
     if (c->xs) (void)hipFree(c->xs);
@@ -121,9 +218,11 @@ static int ensure_ws(rans4x16_hip_ctx *c, size_t bytes)
     return 0;
 }
 
-// Blocks per workspace chunk: as many as the cap allows (a fixed ceiling, and three quarters of what the device has
+// Blocks per workspace chunk: as many as the cap allows (the context's ceiling, and three quarters of what the device has
 // free right now - other contexts and other processes share the card), in equal chunks rather than full ones and a rest.
-static size_t plan_chunk(rans4x16_hip_ctx *c, size_t n, size_t per_blk)
+// bytes(nb) = workspace of a chunk of nb blocks, monotone in nb.
+template <class F>
+static size_t plan_chunk(rans4x16_hip_ctx *c, size_t n, F bytes)
 {
     size_t cap = c->max_ws;
     size_t free_b = 0, total_b = 0;
@@ -131,39 +230,28 @@ static size_t plan_chunk(rans4x16_hip_ctx *c, size_t n, size_t per_blk)
         const size_t room = (free_b + c->ws_bytes) / 4 * 3;
         if (room < cap) cap = room;
     }
-    size_t chunk = cap / per_blk;
-    if (chunk < 1) chunk = 1;
-    if (chunk > n) chunk = n;
-    const size_t rounds = (n + chunk - 1) / chunk;
+    if (bytes(n) <= cap) return n;
+    size_t lo = 1, hi = n;                         // the largest chunk that fits: bytes(lo) <= cap < bytes(hi)
+    while (lo + 1 < hi) {
+        const size_t mid = lo + (hi - lo) / 2;
+        if (bytes(mid) <= cap) lo = mid; else hi = mid;
+    }
+    const size_t rounds = (n + lo - 1) / lo;
     return (n + rounds - 1) / rounds;
 }
 
-// The side streams of a small batch's class launches (R4Fork, r4x16_dev.h); nullptr where the batch is not small or the
-// streams cannot be made.  R4X16_FORK=0 switches them off.
+// The side streams of the chain kernels' class launches (R4Fork, r4x16_dev.h); nullptr where they are switched off
+// (option sched_concurrent = 0), cannot be made, or the context is a lane of the host pipeline.
 extern "C" int r4x16_cu_count(void);
-// small: at most TWO blocks per CU (R4X16_FORK_PER_CU).  Forked launches run side by side, the empty ones included, and a
-// batch whose main class needs all of the LDS at once - 1,024 q40 streams with direct rows are four workgroups of 40 KB
-// on every CU - loses workgroups to whatever else holds LDS at the moment it starts: they run as a second round
-// (measured: 1,024 x 1 MiB q40 decode 29 -> 63 ms with the fork at eight blocks per CU).  Two blocks per CU leave half of
-// the LDS free whatever the classes.  (Sixteen per CU, on 4,096 blocks: mixed 64 KiB blocks 11.5 -> 9.1 ms and q8 with
-// X_RLE 83 -> 77 ms, but 1 MiB q40 blocks 82 -> 90 ms.)
 #define FORK_ONE_BLOCK_BYTES (256u << 10)
-static int fork_blocks()
+static const R4Fork *fork_for(rans4x16_hip_ctx *c)
 {
-    static const int per_cu = getenv("R4X16_FORK_PER_CU") ? atoi(getenv("R4X16_FORK_PER_CU")) : 2;
-    return per_cu * r4x16_cu_count();
-}
-static const R4Fork *fork_for(rans4x16_hip_ctx *c, bool small)
-{
-    static const bool enabled = !(getenv("R4X16_FORK") && atoi(getenv("R4X16_FORK")) == 0);
-    if (!small || !enabled || c->no_fork) return nullptr;
+    if (!c->opts.v[OPT_SCHED_CONCURRENT] || c->no_fork) return nullptr;
     if (!c->fork_made) {
         c->fork_made = true;
-        // Streams of one priority may share a hardware queue, which serialises their kernels (the host pipeline's
-        // lanes): the side streams take the priorities around the caller's - high, low, then normal.
         int lo = 0, hi = 0, n = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);          // lo: least priority (largest number), hi: greatest
-        const int prio[R4_FORK_STREAMS] = {hi, lo, (lo + hi) / 2};
+        const int prio[R4_FORK_STREAMS] = {hi, lo, hi, lo, (lo + hi) / 2};
         for (; n < R4_FORK_STREAMS; n++)
             if (hipStreamCreateWithPriority(&c->fork.aux[n], hipStreamNonBlocking, prio[n]) != hipSuccess) { c->fork.aux[n] = nullptr; break; }
         for (int i = 0; i <= n; i++)
@@ -205,6 +293,15 @@ struct Carver {
     }
 };
 
+static void sched_layout(Carver &cv, size_t nitems, SchedWs *w)
+{
+    w->key = cv.take<u32>(nitems);
+    w->list = cv.take<u32>(nitems);
+    w->cnt = cv.take<u32>(SCHED_CNT_WORDS);
+    w->bins = cv.take<u32>(2 * SCHED_BINS);
+    w->work = cv.take<u64>(CLS_MAX);
+}
+
 static void time_begin(rans4x16_hip_ctx *c, int which, hipStream_t s, TimedLaunch &t)
 {
     (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b);
@@ -220,7 +317,8 @@ static void time_end(rans4x16_hip_ctx *c, int which, hipStream_t s, TimedLaunch 
 // ---------------------------------------------------------------------------------------------
 // device-resident batches
 // ---------------------------------------------------------------------------------------------
-static size_t enc_ws_layout(u8 *base, size_t nblk, u64 scratch_stride, u64 xf_stride, u64 scratch2_stride, EncWs *w)
+// var_bytes: the blocks' staging regions for X_PACK / X_RLE together (0: the batch cannot use the transforms)
+static size_t enc_ws_layout(u8 *base, size_t nblk, u64 scratch_stride, u64 var_bytes, EncWs *w)
 {
     Carver cv(base);
     w->desc = cv.take<EncDesc>(nblk);
@@ -229,18 +327,13 @@ static size_t enc_ws_layout(u8 *base, size_t nblk, u64 scratch_stride, u64 xf_st
     w->tab = cv.take<u8>(nblk, TAB_BYTES);
     w->scratch = cv.take<u8>(nblk, scratch_stride);
     w->scratch_stride = scratch_stride;
-    w->packed = cv.take<u8>(nblk, xf_stride);
-    w->lits = cv.take<u8>(nblk, xf_stride);
-    w->meta = cv.take<u8>(nblk, xf_stride ? xf_stride + 768 : 0);
-    w->metatab = cv.take<u8>(nblk, xf_stride ? META_TAB_BYTES : 0);
-    w->scratch2 = cv.take<u8>(nblk, scratch2_stride);
+    w->var = var_bytes ? cv.take<u8>(var_bytes) : nullptr;
+    w->voff = var_bytes ? cv.take<u64>(nblk + 1) : nullptr;
+    w->var_bytes = var_bytes;
+    w->metatab = cv.take<u8>(nblk, var_bytes ? META_TAB_BYTES : 0);
     w->stat = cv.take<EncStat>(nblk);
     w->dump = cv.take<u8>(1, ENC_DUMP_BYTES);
-    w->cls = cv.take<u32>(3 * nblk);
-    w->cls_list = cv.take<u32>(3 * nblk);
-    w->cls_count = cv.take<u32>(3 * CLS_MAX);
-    w->xf_stride = xf_stride;
-    w->scratch2_stride = scratch2_stride;
+    sched_layout(cv, 3 * nblk, &w->sched);
     w->direct_budget = 0;
     w->meta_records = 0;
     w->pad = 0;
@@ -254,6 +347,18 @@ extern "C" int rans4x16_hip_compress_dev(rans4x16_hip_ctx *c, int n,
                                          const uint32_t *d_out_cap, uint32_t *d_out_size,
                                          int32_t *d_status, int order, const int32_t *d_order,
                                          uint32_t max_in_size, void *stream)
+{
+    return rans4x16_hip_compress_dev_sized(c, n, d_in, d_in_off, d_in_size, d_out, d_out_off, d_out_cap, d_out_size, d_status,
+                                           order, d_order, max_in_size, 0, stream);
+}
+
+extern "C" int rans4x16_hip_compress_dev_sized(rans4x16_hip_ctx *c, int n,
+                                               const unsigned char *d_in, const uint64_t *d_in_off,
+                                               const uint32_t *d_in_size,
+                                               unsigned char *d_out, const uint64_t *d_out_off,
+                                               const uint32_t *d_out_cap, uint32_t *d_out_size,
+                                               int32_t *d_status, int order, const int32_t *d_order,
+                                               uint32_t max_in_size, uint64_t total_in_size, void *stream)
 {
     if (!c) return -1;
     if (n < 0 || (n && (!d_in || !d_in_off || !d_in_size || !d_out || !d_out_off || !d_out_cap || !d_out_size || !d_status))) {
@@ -271,24 +376,25 @@ extern "C" int rans4x16_hip_compress_dev(rans4x16_hip_ctx *c, int n,
         return r4x16_stripe_compress_dev(c, n, sa, order, max_in_size, s);
     }
 
-    // backward-write area per block: the order-1 bound of the largest block (covers the nested
-    // table coder and the RLE meta stream as well)
-    const u64 scratch_stride = align_up(std::max((size_t)r4x16_compress_bound(max_in_size, 0xc1) + 64, (size_t)ENC_F_BYTES), 256);
-    // X_PACK / X_RLE staging only when some block may ask for it (per-block orders: assume yes)
+    // Per block the workspace holds fixed-size records, tables and images, 256 KB for the pair counters and the nested
+    // table stream, and - only for blocks that ask for X_PACK / X_RLE - a staging region sized from the block's own length
+    // and laid out on the device (enc_var_layout).  The payload itself is written into the caller's slot (k_enc_tables).
+    // The host only needs a bound for the staging regions together: from total_in_size when the caller gave it, from
+    // n x max_in_size otherwise (per-block orders: every block may ask).
+    const u64 scratch_stride = ENC_F_BYTES;
     const bool xf = d_order != nullptr || (order & (X_PACK | X_RLE));
-    const u64 xf_stride = xf ? align_up((size_t)max_in_size + 64, 256) : 0;
-    const u64 scratch2_stride = xf ? align_up((size_t)r4x16_compress_bound(max_in_size + 768, 0) + 64, 256) : 0;
+    const u64 total_in = total_in_size ? total_in_size : (u64)n * max_in_size;
+    auto var_for = [&](size_t nb) -> u64 { return xf ? enc_var_bound(nb, std::min<u64>(total_in, (u64)nb * max_in_size)) : 0; };
     EncWs w;
-    const size_t per_blk = enc_ws_layout(nullptr, 1, scratch_stride, xf_stride, scratch2_stride, &w) + 4096;
-    size_t chunk = plan_chunk(c, (size_t)n, per_blk);
+    size_t chunk = plan_chunk(c, (size_t)n, [&](size_t nb) { return enc_ws_layout(nullptr, nb, scratch_stride, var_for(nb), &w) + 4096; });
     if (ws_order_begin(c, s) != 0) return -1;
     for (;;) {                                     // out of memory: walk the batch in smaller chunks
-        const size_t need = enc_ws_layout(nullptr, chunk, scratch_stride, xf_stride, scratch2_stride, &w);
+        const size_t need = enc_ws_layout(nullptr, chunk, scratch_stride, var_for(chunk), &w);
         if (ensure_ws(c, need) == 0) break;
         if (chunk == 1) return -1;
         chunk = (chunk + 1) / 2;
     }
-    enc_ws_layout(c->ws, chunk, scratch_stride, xf_stride, scratch2_stride, &w);
+    enc_ws_layout(c->ws, chunk, scratch_stride, var_for(chunk), &w);
     w.logtab = c->logtab;
     w.rcptab = c->rcptab;
 
@@ -299,16 +405,17 @@ extern "C" int rans4x16_hip_compress_dev(rans4x16_hip_ctx *c, int n,
 
     for (size_t base = 0; base < (size_t)n; base += chunk) {
         const int nb = (int)((size_t)n - base < chunk ? (size_t)n - base : chunk);
-        w.direct_budget = r4x16_enc_direct_budget(nb);       // few streams: LDS to spare, symbol records (r4x16_common.h)
-        // (made at first use: not inside the timed region.  One small block is one payload class and a call of 0.4 ms; one
-        //  large block with X_RLE is two long streams - literals, run lengths - of different classes: 15.7 -> 12.0 ms per MiB of q8)
-        const R4Fork *fk = fork_for(c, (nb > 1 || max_in_size >= FORK_ONE_BLOCK_BYTES) && nb <= fork_blocks());
+        w.direct_budget = r4x16_enc_direct_budget(nb, &c->opts);       // few streams: LDS to spare, symbol records (r4x16_common.h)
+        // (made at first use: not inside the timed region.  One small block is one payload class and a call of 0.4 ms: it
+        //  stays on the caller's stream; one large block with X_RLE is two long streams - literals, run lengths - of
+        //  different classes: 15.7 -> 12.0 ms per MiB of q8)
+        const R4Fork *fk = (nb > 1 || max_in_size >= FORK_ONE_BLOCK_BYTES) ? fork_for(c) : nullptr;
         w.meta_records = fk == nullptr;
-        r4x16_launch_enc_front(&a, &w, (int)base, nb, s);
+        r4x16_launch_enc_front(&a, &w, (int)base, nb, s, &c->opts);
         r4x16_launch_enc_tables(&a, &w, (int)base, nb, s);
         TimedLaunch t;
         if (c->timing) time_begin(c, 0, s, t);
-        r4x16_launch_enc_chain(&w, 3 * nb, s, fk);
+        r4x16_launch_enc_chain(&w, 3 * nb, s, fk, &c->opts, &c->hint[0]);
         if (c->timing) time_end(c, 0, s, t);
         r4x16_launch_enc_finish(&a, &w, (int)base, nb, s);
     }
@@ -316,7 +423,8 @@ extern "C" int rans4x16_hip_compress_dev(rans4x16_hip_ctx *c, int n,
     return ws_order_end(c, s);
 }
 
-static size_t dec_ws_layout(u8 *base, size_t nblk, u64 tmp_stride, u64 meta_stride, DecWs *w)
+// var_bytes: the staging regions of the blocks that carry X_PACK / X_RLE, together (0: the batch has none)
+static size_t dec_ws_layout(u8 *base, size_t nblk, u64 var_bytes, u32 max_out_cap, DecWs *w)
 {
     Carver cv(base);
     w->desc = cv.take<DecDesc>(nblk);
@@ -324,13 +432,12 @@ static size_t dec_ws_layout(u8 *base, size_t nblk, u64 tmp_stride, u64 meta_stri
     w->resume = cv.take<DecResume>(nblk);
     w->images = cv.take<u8>(nblk, (size_t)DEC_IMG_SLOT);
     w->tbuf = cv.take<u8>(nblk, TBUF_BYTES);
-    w->tmp = cv.take<u8>(nblk, tmp_stride);
-    w->meta = cv.take<u8>(nblk, meta_stride);
-    w->tmp_stride = tmp_stride;
-    w->meta_stride = meta_stride;
-    w->cls = cv.take<u32>(2 * nblk);
-    w->cls_list = cv.take<u32>(2 * nblk);
-    w->cls_count = cv.take<u32>(3 * CLS_MAX);
+    w->var = var_bytes ? cv.take<u8>(var_bytes) : nullptr;
+    w->voff = var_bytes ? cv.take<u64>(nblk + 1) : nullptr;
+    w->var_bytes = var_bytes;
+    w->max_out_cap = max_out_cap;
+    w->pad2 = 0;
+    sched_layout(cv, 2 * nblk, &w->sched);
     w->direct_budget = 0;
     w->pad = 0;
     return align_up(cv.off, 256);
@@ -343,6 +450,18 @@ extern "C" int rans4x16_hip_uncompress_dev(rans4x16_hip_ctx *c, int n,
                                            const uint32_t *d_out_cap, uint32_t *d_out_size,
                                            int32_t *d_status, uint32_t max_in_size, uint32_t max_out_cap,
                                            void *stream)
+{
+    return rans4x16_hip_uncompress_dev_sized(c, n, d_in, d_in_off, d_in_size, d_out, d_out_off, d_out_cap, d_out_size, d_status,
+                                             max_in_size, max_out_cap, 0, stream);
+}
+
+extern "C" int rans4x16_hip_uncompress_dev_sized(rans4x16_hip_ctx *c, int n,
+                                                 const unsigned char *d_in, const uint64_t *d_in_off,
+                                                 const uint32_t *d_in_size,
+                                                 unsigned char *d_out, const uint64_t *d_out_off,
+                                                 const uint32_t *d_out_cap, uint32_t *d_out_size,
+                                                 int32_t *d_status, uint32_t max_in_size, uint32_t max_out_cap,
+                                                 uint64_t total_out_cap, void *stream)
 {
     if (!c) return -1;
     if (n < 0 || (n && (!d_in || !d_in_off || !d_in_size || !d_out || !d_out_off || !d_out_cap || !d_out_size || !d_status))) {
@@ -360,21 +479,22 @@ extern "C" int rans4x16_hip_uncompress_dev(rans4x16_hip_ctx *c, int n,
         return r4x16_stripe_uncompress_dev(c, n, sa, max_in_size, max_out_cap, c->dev_stripe_out, s);
     }
 
-    // PACK / RLE staging: one buffer of the output size, and room for the decoded run-length meta
-    // (rANS_static4x16pr.c:1273: at most in_size + 257 bytes)
-    const u64 tmp_stride = align_up((size_t)max_out_cap + 64, 256);
-    const u64 meta_stride = align_up((size_t)max_out_cap + 512, 256);
+    // PACK / RLE staging, only for the blocks whose flag byte asks for it: a buffer of the block's output size and room
+    // for the decoded run-length meta (rANS_static4x16pr.c:1273: at most in_size + 257 bytes), laid out on the device
+    // (dec_var_bytes, k_dec_voff).  The host bounds their sum: from total_out_cap when the caller gave it, from
+    // n x max_out_cap otherwise; max_out_cap == 0 says the batch has no such block.
+    const u64 total_out = total_out_cap ? total_out_cap : (u64)n * max_out_cap;
+    auto var_for = [&](size_t nb) -> u64 { return max_out_cap ? dec_var_bound(nb, std::min<u64>(total_out, (u64)nb * max_out_cap)) : 0; };
     DecWs w;
-    const size_t per_blk = dec_ws_layout(nullptr, 1, tmp_stride, meta_stride, &w) + 4096;
-    size_t chunk = plan_chunk(c, (size_t)n, per_blk);
+    size_t chunk = plan_chunk(c, (size_t)n, [&](size_t nb) { return dec_ws_layout(nullptr, nb, var_for(nb), max_out_cap, &w) + 4096; });
     if (ws_order_begin(c, s) != 0) return -1;
     for (;;) {                                     // out of memory: walk the batch in smaller chunks
-        const size_t need = dec_ws_layout(nullptr, chunk, tmp_stride, meta_stride, &w);
+        const size_t need = dec_ws_layout(nullptr, chunk, var_for(chunk), max_out_cap, &w);
         if (ensure_ws(c, need) == 0) break;
         if (chunk == 1) return -1;
         chunk = (chunk + 1) / 2;
     }
-    dec_ws_layout(c->ws, chunk, tmp_stride, meta_stride, &w);
+    dec_ws_layout(c->ws, chunk, var_for(chunk), max_out_cap, &w);
 
     BatchArgs a;
     a.in = d_in; a.in_off = d_in_off; a.in_size = d_in_size;
@@ -383,14 +503,14 @@ extern "C" int rans4x16_hip_uncompress_dev(rans4x16_hip_ctx *c, int n,
 
     for (size_t base = 0; base < (size_t)n; base += chunk) {
         const int nb = (int)((size_t)n - base < chunk ? (size_t)n - base : chunk);
-        w.direct_budget = r4x16_dec_direct_budget(nb);       // few streams: LDS to spare, the short-step rows (r4x16_common.h)
-        r4x16_launch_dec_front(&a, &w, (int)base, nb, s);
-        const R4Fork *fk = fork_for(c, (nb > 1 || max_out_cap >= FORK_ONE_BLOCK_BYTES) && nb <= fork_blocks());   // (one large block: 28.2 -> 19.8 ms per MiB of q8 with X_RLE)
+        w.direct_budget = r4x16_dec_direct_budget(nb, &c->opts);       // few streams: LDS to spare, the short-step rows (r4x16_common.h)
+        r4x16_launch_dec_front(&a, &w, (int)base, nb, s, &c->opts);
+        const R4Fork *fk = (nb > 1 || max_out_cap >= FORK_ONE_BLOCK_BYTES) ? fork_for(c) : nullptr;   // (one large block: 28.2 -> 19.8 ms per MiB of q8 with X_RLE)
         TimedLaunch t;
         if (c->timing) time_begin(c, 1, s, t);
-        r4x16_launch_dec_chain(&w, 2 * nb, s, fk);
+        r4x16_launch_dec_chain(&w, 2 * nb, s, fk, &c->opts, &c->hint[1]);
         if (c->timing) time_end(c, 1, s, t);
-        r4x16_launch_dec_back(&a, &w, (int)base, nb, s);
+        r4x16_launch_dec_back(&a, &w, (int)base, nb, s, &c->opts);
     }
     HIPCHK(c, hipGetLastError());
     return ws_order_end(c, s);
@@ -453,6 +573,7 @@ static rans4x16_hip_ctx *thread_ctx()
     struct Holder { rans4x16_hip_ctx *c = nullptr; ~Holder() { rans4x16_hip_destroy(c); } };
     static thread_local Holder h;
     if (!h.c) h.c = rans4x16_hip_create(-1);
+    if (h.c) opts_snapshot(h.c);                   // no context argument: these calls follow the process-wide options
     return h.c;
 }
 
@@ -467,9 +588,10 @@ static rans4x16_hip_ctx *thread_ctx()
 // memory, a runtime error) is re-run block by block, so one hostile or oversized request cannot fail its neighbours;
 // a batch gathers at most R4X16_COMBINE_MAX_MB of buffers; a worker that cannot start marks its direction dead and
 // callers fall back to their own per-thread context.
-//   R4X16_COMBINE=0           calls go straight to a per-thread context
-//   R4X16_COMBINE_WINDOW_US   a fixed gathering window instead of the adaptive one
-//   R4X16_COMBINE_MAX         blocks per batch (default 256)      R4X16_COMBINE_MAX_MB  buffer bytes per batch (default 2048)
+// Process-wide options (rans4x16_hip_set_option(NULL, ..) before the first single-block call; defaults from R4X16_COMBINE*):
+//   combine = 0               calls go straight to a per-thread context
+//   combine_window_us         a fixed gathering window instead of the adaptive one
+//   combine_max               blocks per batch (default 256)      combine_max_mb  buffer bytes per batch (default 2048)
 // ---------------------------------------------------------------------------------------------
 #include <condition_variable>
 #include <deque>
@@ -540,6 +662,7 @@ struct Combiner {
             std::vector<unsigned int> isz(n), osz(n);
             std::vector<int> ord(n), st(n, 0), rcs(n, 0);
             for (int i = 0; i < n; i++) { in[i] = batch[i]->in; out[i] = batch[i]->out; isz[i] = batch[i]->in_size; osz[i] = batch[i]->cap; ord[i] = batch[i]->order; }
+            opts_snapshot(c);                  // the drop-in symbols have no context argument: they follow the process-wide options
             const int rc = r4x16_run_host_batch(c, n, dir == 1, in.data(), isz.data(), out.data(), osz.data(), dir == 0 ? ord.data() : nullptr, st.data());
             if (rc < 0 && n > 1) {
                 // The batch failed as a whole (staging refused for one hostile size field, out of memory, a runtime
@@ -567,12 +690,11 @@ struct Combiner {
         std::unique_lock<std::mutex> lk(mu);
         if (!started) {
             started = true;
-            const char *w = getenv("R4X16_COMBINE_WINDOW_US"), *m = getenv("R4X16_COMBINE_MAX"), *k = getenv("R4X16_COMBINE_WORKERS"),
-                       *mb = getenv("R4X16_COMBINE_MAX_MB");
-            if (w && *w) window_us = atol(w);                   // a fixed window instead of the adaptive one
-            if (m && *m && atol(m) > 0) max_batch = atol(m);
-            if (k && *k && atol(k) > 0 && atol(k) <= 4) workers = atol(k);
-            if (mb && *mb && atol(mb) > 0) max_bytes = (size_t)atol(mb) << 20;
+            const R4Opts *o = r4x16_opts_defaults();
+            if (o->v[OPT_COMBINE_WINDOW_US] >= 0) window_us = o->v[OPT_COMBINE_WINDOW_US];     // a fixed window instead of the adaptive one
+            if (o->v[OPT_COMBINE_MAX] > 0) max_batch = o->v[OPT_COMBINE_MAX];
+            if (o->v[OPT_COMBINE_WORKERS] > 0 && o->v[OPT_COMBINE_WORKERS] <= 4) workers = o->v[OPT_COMBINE_WORKERS];
+            if (o->v[OPT_COMBINE_MAX_MB] > 0) max_bytes = (size_t)o->v[OPT_COMBINE_MAX_MB] << 20;
             // (detached, and the combiner itself is never destroyed: tearing GPU contexts down from static destructors
             //  at process exit races the runtime's own shutdown.  After fork() the child has no workers and no usable
             //  runtime either - HIP does not survive a fork - so nothing is done about that case.)
@@ -588,8 +710,7 @@ struct Combiner {
 // one combiner per device (a caller's current device decides, as it did for its per-thread context)
 static Combiner *combiner_for_current_device()
 {
-    static const bool enabled = !(getenv("R4X16_COMBINE") && atoi(getenv("R4X16_COMBINE")) == 0);
-    if (!enabled) return nullptr;
+    if (!r4x16_opts_defaults()->v[OPT_COMBINE]) return nullptr;
     int ndev = 0, dev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     static std::mutex mu;
@@ -705,15 +826,14 @@ extern "C" int rans4x8_hip_compress_dev(rans4x16_hip_ctx *c, int n,
     hipStream_t s = (hipStream_t)stream;
     const u64 scratch_stride = align_up(std::max((size_t)r4x8_compress_bound(max_in_size) + 64, (size_t)ENC_F_BYTES), 256);
     EncWs w;
-    const size_t per_blk = enc_ws_layout(nullptr, 1, scratch_stride, 0, 0, &w) + 4096;
-    size_t chunk = plan_chunk(c, (size_t)n, per_blk);
+    size_t chunk = plan_chunk(c, (size_t)n, [&](size_t nb) { return enc_ws_layout(nullptr, nb, scratch_stride, 0, &w) + 4096; });
     if (ws_order_begin(c, s) != 0) return -1;
     for (;;) {
-        if (ensure_ws(c, enc_ws_layout(nullptr, chunk, scratch_stride, 0, 0, &w)) == 0) break;
+        if (ensure_ws(c, enc_ws_layout(nullptr, chunk, scratch_stride, 0, &w)) == 0) break;
         if (chunk == 1) return -1;
         chunk = (chunk + 1) / 2;
     }
-    enc_ws_layout(c->ws, chunk, scratch_stride, 0, 0, &w);
+    enc_ws_layout(c->ws, chunk, scratch_stride, 0, &w);
     w.logtab = c->logtab;
     w.rcptab = c->rcptab;
     BatchArgs a;
@@ -741,8 +861,7 @@ extern "C" int rans4x8_hip_uncompress_dev(rans4x16_hip_ctx *c, int n,
     if (n == 0) return 0;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
-    const size_t per_blk = r4x8_dec_ws_bytes(1) + 4096;
-    size_t chunk = plan_chunk(c, (size_t)n, per_blk);
+    size_t chunk = plan_chunk(c, (size_t)n, [&](size_t nb) { return r4x8_dec_ws_bytes(nb) + 4096; });
     if (ws_order_begin(c, s) != 0) return -1;
     for (;;) {
         if (ensure_ws(c, r4x8_dec_ws_bytes(chunk)) == 0) break;

@@ -314,6 +314,23 @@ struct EncDesc {
 
 #define CLS_MAX  64u
 #define CLS_NONE 0xffffffffu
+// streams grouped by LDS size class and ordered by chain length on the device (r4x16_sched.h)
+#define SCHED_NB   256u                         // length buckets per class (8 per octave: 240 used)
+#define SCHED_BINS (CLS_MAX * SCHED_NB)
+// per-class arrays of SchedWs.cnt, CLS_MAX entries each
+#define SCHED_COUNT 0u                          // streams of the class
+#define SCHED_START (1u * CLS_MAX)              // first position in the list
+#define SCHED_CLAIM (2u * CLS_MAX)              // next share to hand out
+#define SCHED_SEATS (3u * CLS_MAX)              // workgroups of the class's launch that may work
+#define SCHED_CNT_WORDS (4u * CLS_MAX)
+
+struct SchedWs {
+    u32 *key;        // [nitems]  class << 8 | 255 - bucket, or CLS_NONE
+    u32 *list;       // [nitems]  item indices, by class, longest first
+    u32 *cnt;        // [SCHED_CNT_WORDS]
+    u32 *bins;       // [2 * SCHED_BINS]  per (class, bucket): count -> start, fill cursor
+    u64 *work;       // [CLS_MAX]  sum of chain lengths per class
+};
 // An order-1 block whose table is itself an order-0 stream (rANS_static4x16pr.c:944-955): k_dec_front<0> hands that
 // stream to the chain kernel as an item of its own and leaves what k_dec_front<1> needs to carry on from the decoded
 // table bytes.
@@ -325,18 +342,43 @@ struct DecWs {
     DecResume *resume; // [nblk]
     u8 *images;        // [nblk][DEC_IMG_SLOT]
     u8 *tbuf;          // [nblk][TBUF_BYTES]
-    u8 *tmp;           // [nblk][tmp_stride]   stage buffer for PACK / RLE
-    u8 *meta;          // [nblk][meta_stride]  decoded RLE meta
-    u64 tmp_stride, meta_stride;
-    // streams grouped by LDS size class on the device (k_dec_classify .. k_cls_scatter), so that every chain
+    // X_PACK / X_RLE staging: a region per block that carries one of the flags, sized from the block's own output
+    // capacity and laid out on the device (dec_var_bytes, k_dec_voff): block b owns var[voff[b] .. voff[b + 1])
+    u8 *var;           // stage buffer of the inverse transforms, then the decoded run-length meta
+    u64 *voff;         // [nblk + 1]
+    u64 var_bytes;     // bytes behind `var` (a block whose region would end beyond them reports UNSUPPORTED)
+    u32 max_out_cap;   // the caller's bound on a transformed block's size
+    u32 pad2;
+    // streams grouped by LDS size class on the device (k_dec_classify, r4x16_sched.hip), so that every chain
     // workgroup gets a full set of streams of its class whatever the mix of blocks in the batch
-    u32 *cls;          // [2*nblk]  class of each item (CLS_NONE: nothing to run)   (the nested tables' pass uses the first nblk)
-    u32 *cls_list;     // [2*nblk]  item indices, grouped by class
-    u32 *cls_count;    // [3][CLS_MAX]  per class: number of items, first position in cls_list, fill cursor
+    SchedWs sched;     // key / list: [2*nblk]  (the nested tables' pass uses the first nblk)
     u32 direct_budget; // LDS bytes a stream of this batch may take for direct rows (0: never); set per chunk by the host
     u32 pad;
 };
 
+
+// Per-block staging of the transforms (host bound and device layout use the same arithmetic).
+static inline __host__ __device__ u64 var_align(u64 v) { return (v + 255u) & ~(u64)255u; }
+struct EncVar { u64 packed, lits, meta, scratch2, total; };      // offsets inside the block's region, and its size
+static inline __host__ __device__ EncVar enc_var_layout(u32 n, int order)
+{
+    EncVar v = {0, 0, 0, 0, 0};
+    if ((order & X_CAT) || !(order & (X_PACK | X_RLE))) return v;
+    u64 at = 0;
+    if (order & X_PACK) { v.packed = at; at += var_align((u64)n + 64u); }
+    if (order & X_RLE) {
+        v.lits = at; at += var_align((u64)n + 64u);
+        v.meta = at; at += var_align((u64)n + 64u + 768u);
+        v.scratch2 = at; at += var_align((u64)r4x16_bound_hd(n + 768u, 0) + 64u);
+    }
+    v.total = at;
+    return v;
+}
+// host: an upper bound of the sum of enc_var_layout(..).total over `nblk` blocks of `total_in` bytes together
+static inline u64 enc_var_bound(u64 nblk, u64 total_in) { return nblk * 4096u + total_in * 4u + total_in / 16u + (1u << 20); }
+static inline __host__ __device__ u64 dec_var_tmp(u32 cap) { return var_align((u64)cap + 64u); }
+static inline __host__ __device__ u64 dec_var_bytes(u32 cap) { return dec_var_tmp(cap) + var_align((u64)cap + 512u); }
+static inline u64 dec_var_bound(u64 nblk, u64 total_out) { return nblk * 1536u + 2u * total_out + (1u << 20); }
 
 // What the histogram kernel hands to the table kernel (per block).
 struct EncStat {
@@ -359,16 +401,17 @@ struct EncWs {
     const double *logtab;   // [2][257]  log(1024+k), log(4096+k) from the host libm (:651-652)
     const u32 *rcptab;      // [4097]    reciprocal by frequency (rANS_word.h:252), shared by all streams
     u64 scratch_stride;
-    // X_PACK / X_RLE staging (strides are 0 when the batch cannot use them)
-    u8 *packed;         // [nblk][xf_stride]   bit-packed bytes
-    u8 *lits;           // [nblk][xf_stride]   RLE literals (filled from the end)
-    u8 *meta;           // [nblk][xf_stride + 768]  RLE meta: nsyms, syms, run varints (filled from the end)
+    // X_PACK / X_RLE staging: a region per block that asks for a transform, sized from the block's own length and laid
+    // out on the device (enc_var_bytes, k_enc_voff): block b owns var[voff[b] .. voff[b + 1]) - bit-packed bytes, RLE
+    // literals (filled from the end), RLE meta (nsyms, syms, run varints; filled from the end), the backward-written
+    // meta stream.  var == nullptr when the batch cannot use transforms.
+    u8 *var;
+    u64 *voff;          // [nblk + 1]
+    u64 var_bytes;      // bytes behind `var` (a block whose region would end beyond them reports UNSUPPORTED)
     u8 *metatab;        // [nblk][1024]        order-0 table of the meta stream
-    u8 *scratch2;       // [nblk][scratch2_stride]  backward-written meta stream
     EncStat *stat;      // [nblk]
     u8 *dump;           // [ENC_DUMP_BYTES]  target of the chain coder's idle output slots (never read)
-    u64 xf_stride, scratch2_stride;
-    u32 *cls, *cls_list, *cls_count;   // streams grouped by LDS size class (as in DecWs)
+    SchedWs sched;      // streams grouped by LDS size class (as in DecWs); key / list: [3*nblk]
     u32 direct_budget;  // LDS bytes a stream of this batch may take for symbol records (0: never); set per chunk by the host
     u32 meta_records;   // the RLE-meta streams take records too (set where the class launches go out in stream order: a wave then
                         // walks a block's literals and its run lengths together; side by side they are better off in two kernels)

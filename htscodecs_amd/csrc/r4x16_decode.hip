@@ -15,6 +15,7 @@
 #include <mutex>
 #include <type_traits>
 #include "r4x16_dev.h"
+#include "r4x16_sched.h"
 
 static inline size_t align_up_sz(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -1284,8 +1285,13 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(PHASE ? 8 
     }
 
     // ---- container header: flags, sizes, PACK map, RLE meta (:1435-1572) ---------------------------
-    u8 *tmp = ws.tmp + (u64)b * ws.tmp_stride;
-    u8 *metabuf = ws.meta + (u64)b * ws.meta_stride;
+    // the block's staging region for the inverse transforms (r4x16_common.h: dec_var_bytes; laid out by k_dec_voff
+    // for the blocks whose first byte carries X_PACK or X_RLE): stage buffer, then the decoded run-length meta
+    const u32 vcap = cap < ws.max_out_cap ? cap : ws.max_out_cap;
+    const bool vhas = ws.var && ws.voff[b + 1] > ws.voff[b] && ws.voff[b + 1] <= ws.var_bytes;
+    u8 *tmp = vhas ? ws.var + ws.voff[b] : nullptr;
+    u8 *metabuf = vhas ? tmp + dec_var_tmp(vcap) : nullptr;
+    const u32 tmp_room = vhas ? vcap : 0u, meta_room = vhas ? vcap + 256u : 0u;
     if (lane == 0) {
         DecItem *I2 = &ws.items[2 * gridDim.x + b];
         I0->active = 0; I1->active = 0; I2->active = 0;
@@ -1306,7 +1312,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(PHASE ? 8 
                 if (!(flags & X_NOSZ)) pos += var_get(src, pos, in_size, &osz);
                 else osz = cap;
                 if (cap < osz) st = ST_CAPACITY;                       // :1464
-                else if ((flags & (X_PACK | X_RLE)) && osz > ws.tmp_stride) st = ST_UNSUPPORTED;
+                else if ((flags & (X_PACK | X_RLE)) && osz > tmp_room) st = ST_UNSUPPORTED;
             }
         }
         D->flags = flags;
@@ -1363,7 +1369,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(PHASE ? 8 
                 } else {                                               // order-0 compressed meta
                     sz += var_get(src, pos + sz, in_size, &c_meta);
                     mlen /= 2;
-                    if (mlen > ws.meta_stride) st = ST_UNSUPPORTED;    // larger than any valid meta for this batch
+                    if (mlen > meta_room) st = ST_UNSUPPORTED;         // larger than any valid meta for this batch
                     else {
                         H.meta_nested = 1; H.meta_pos = pos + sz; H.meta_slen = left - sz; H.meta_len = mlen;
                         D->rle_meta = (u64)metabuf;
@@ -1506,20 +1512,21 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(PHASE ? 8 
 // images too big for LDS (lo = largest class).
 // ---------------------------------------------------------------------------------------------
 template <bool LDS_IMG, int LV>
-__global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDesc *desc, const u32 *list, const u32 *count,
-                                                    int qpw, u32 lds_per_item)
+__global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDesc *desc, const u32 *list, u32 *count,
+                                                    int qpw, u32 lds_per_item, int dyn)
 {
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
     const u32 lane = threadIdx.x;
     const u32 quad = lane >> 2;
-    // Persistent: the grid holds as many workgroups as are resident at once and each walks its share
-    // of the batch.  (Re-dispatching a second round of workgroups into slots as they free up left CUs
-    // under-filled: 15,360 streams took 153 ms instead of 2 x 63.)
-    // the streams of this launch's class: count[0] of them, their item indices at list[count[CLS_MAX] ..]
-    const int nmine = (int)count[0];
-    list += count[CLS_MAX];
-    const int nwg = (nmine + qpw - 1) / qpw;
-    for (int wg = (int)blockIdx.x; wg < nwg; wg += (int)gridDim.x) {
+    // Persistent: the grid holds as many workgroups as are resident at once and each walks shares of the batch
+    // (re-dispatching a second round of workgroups into slots as they free up left CUs under-filled: 15,360 streams
+    // took 153 ms instead of 2 x 63).  The streams of this launch's class: count[SCHED_COUNT] of them, their item
+    // indices at list[count[SCHED_START] ..], longest first; a share is `qpw` consecutive entries, claimed from the
+    // class's counter; only the first count[SCHED_SEATS] workgroups of the grid work (r4x16_sched.h).
+    const int nmine = (int)count[SCHED_COUNT];
+    list += count[SCHED_START];
+    SchedWalk walk(count, nmine, qpw, dyn != 0);
+    for (int wg = walk.next_wave(); wg >= 0; wg = walk.next_wave()) {
     const int slot = wg * qpw + (int)quad;
     const bool mine = quad < (u32)qpw && slot < nmine;
     const DecItem *I = &items[mine ? list[slot] : list[wg * qpw]];
@@ -1527,6 +1534,7 @@ __global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDes
     const u32 nsym = active ? I->nsym : 1u;
     const u32 img_bytes = active ? I->img_bytes : 0u;
     if (!wave_any(active)) continue;
+    sched_setprio(sched_prio_of(active, active ? I->out_sz : 0u));
 
     // fields are read one by one (a register copy of the struct indexed by lane would spill)
     gcu8 *words = (gcu8 *)I->words;
@@ -2267,12 +2275,43 @@ __global__ __launch_bounds__(NT) void k_dec_back(BatchArgs a, DecWs ws, int base
     }
 }
 
-// ---- host-callable launchers (r4x16_api.hip) ---------------------------------------------------
-static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitems, bool one_row_only, hipStream_t s, const R4Fork *fk = nullptr);
-extern "C" void r4x16_launch_dec_front(const BatchArgs *a, const DecWs *ws, int base, int nblk, hipStream_t s)
+// Where each block's staging region for the inverse transforms starts: blocks whose flag byte carries X_PACK or X_RLE
+// get dec_var_bytes(min(capacity, the caller's bound)), the others nothing; exclusive prefix sum by one workgroup.
+__device__ __forceinline__ u64 dec_var_of(const BatchArgs &a, int i, u32 max_out_cap)
 {
+    if (!a.in_size[i]) return 0ull;
+    const u8 flags = a.in[a.in_off[i]];
+    if ((flags & X_STRIPE) || !(flags & (X_PACK | X_RLE))) return 0ull;
+    const u32 cap = a.out_cap[i];
+    return dec_var_bytes(cap < max_out_cap ? cap : max_out_cap);
+}
+__global__ __launch_bounds__(1024) void k_dec_voff(BatchArgs a, int base, int nblk, u64 *voff, u32 max_out_cap)
+{
+    __shared__ u64 part[1024];
+    const u32 t = threadIdx.x;
+    const int per = (nblk + 1023) / 1024, lo = (int)t * per, hi = lo + per < nblk ? lo + per : nblk;
+    u64 sum = 0;
+    for (int b = lo; b < hi; b++) sum += dec_var_of(a, base + b, max_out_cap);
+    part[t] = sum;
+    __syncthreads();
+    for (u32 d = 1; d < 1024u; d <<= 1) {
+        const u64 add = t >= d ? part[t - d] : 0ull;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    u64 at = part[t] - sum;
+    for (int b = lo; b < hi; b++) { voff[b] = at; at += dec_var_of(a, base + b, max_out_cap); }
+    if (t == 1023) voff[nblk] = part[1023];
+}
+
+// ---- host-callable launchers (r4x16_api.hip) ---------------------------------------------------
+static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitems, bool one_row_only, hipStream_t s, const R4Fork *fk, const R4Opts *o, const SchedHint *hint);
+extern "C" void r4x16_launch_dec_front(const BatchArgs *a, const DecWs *ws, int base, int nblk, hipStream_t s, const R4Opts *o)
+{
+    if (ws->var) hipLaunchKernelGGL(k_dec_voff, dim3(1), dim3(1024), 0, s, *a, base, nblk, ws->voff, ws->max_out_cap);
     hipLaunchKernelGGL(k_dec_front<0>, dim3(nblk), dim3(WAVE), 0, s, *a, *ws, base);
-    launch_dec_chain_of(ws, ws->items + 2 * (size_t)nblk, nblk, true, s);        // nested order-1 tables
+    launch_dec_chain_of(ws, ws->items + 2 * (size_t)nblk, nblk, true, s, nullptr, o, nullptr);        // nested order-1 tables
     hipLaunchKernelGGL(k_dec_front<1>, dim3(nblk), dim3(WAVE), 0, s, *a, *ws, base);
 }
 // LDS size classes: {bytes per stream (image + word ring), streams per wave, tree depth}.
@@ -2309,6 +2348,11 @@ static const struct { u32 bytes; int qpw; int lv; } DEC_CLASSES[] = {
     // block's literals where launches run side by side (one 1 MiB q8 block: 25.0 -> 18.7 ms), not behind them in the
     // same wave (only where launches do run side by side, DecClassTab.split_o0)
     {2576, 8, 7}, {4112, 8, 7},
+    // order-0 streams with compressed rows of up to 50 symbols (level 8 = level 2's kernel; such an image and its ring
+    // take at most 516 bytes).  The kernel runs a wave's order-1 streams, then its order-0 streams: in a class that
+    // holds both kinds - q4 / q8 order-1 tables are this small too - a wave of long streams of both kinds took twice
+    // the chain latency (round 4's heterogeneous batch: the class of its 1 MiB streams 104 ms instead of 50).
+    {656, 16, 8},
 };
 // workgroups of `lds_bytes` each that one CU holds at once (1,280-byte LDS granules, 32 wave slots)
 static int resident_per_cu(size_t lds_bytes, int waves_per_wg)
@@ -2358,29 +2402,30 @@ extern "C" int r4x16_resident_grid(size_t lds_bytes, int waves_per_wg, int wante
 // ---- streams -> classes, on the device ---------------------------------------------------------
 // class ids: index into DEC_CLASSES, then one catch-all per tree depth (images too large for LDS)
 #define DEC_NCLS ((u32)(sizeof(DEC_CLASSES) / sizeof(DEC_CLASSES[0])))
-struct DecClassTab { u32 n; u32 split_o0; u32 bytes[CLS_MAX]; u32 lv[CLS_MAX]; };
-// (per-class counts go through LDS first: a whole batch is usually one class, and 30,000 atomics on one global word
-//  took 0.18 ms)
-__global__ __launch_bounds__(256) void k_dec_classify(const DecItem *items, int nitems, DecClassTab tab, u32 *cls, u32 *count)
+struct DecClassTab { u32 n; u32 split_o0; u32 sort; u32 bytes[CLS_MAX]; u32 lv[CLS_MAX]; };
+// class, length bucket and the class's work per item (r4x16_sched.h); per-class counts go through LDS first: a whole
+// batch is usually one class, and 30,000 atomics on one global word took 0.18 ms
+__global__ __launch_bounds__(256) void k_dec_classify(const DecItem *items, int nitems, DecClassTab tab, SchedWs sw)
 {
     __shared__ u32 local[CLS_MAX];
-    if (threadIdx.x < CLS_MAX) local[threadIdx.x] = 0;
+    __shared__ u64 lwork[CLS_MAX];
+    if (threadIdx.x < CLS_MAX) { local[threadIdx.x] = 0; lwork[threadIdx.x] = 0ull; }
     __syncthreads();
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    u32 c = CLS_NONE, len = 0;
     if (i < nitems) {
         const DecItem *I = &items[i];
-        u32 c = CLS_NONE;
         if (I->active) {
-            const u32 need = I->img_bytes + RING_BYTES, lv0 = item_levels(I->nsym, I->packed), lv = (lv0 == 6u && I->order == 0 && tab.split_o0) ? 7u : lv0;
+            const u32 need = I->img_bytes + RING_BYTES, lv0 = item_levels(I->nsym, I->packed), lv = (lv0 == 6u && I->order == 0 && tab.split_o0) ? 7u : (lv0 == 2u && I->order == 0) ? 8u : lv0;
             c = tab.n + ((lv < 2u || lv > 4u) ? 0u : lv - 2u);  // catch-all of this depth (packed levels 1 and 5 always fit a class)
             for (u32 k = 0; k < tab.n; k++)
                 if (tab.lv[k] == lv && need <= tab.bytes[k]) { c = k; break; }   // classes of a depth ascend
-            atomicAdd(&local[c], 1u);
+            len = I->out_sz;
         }
-        cls[i] = c;
     }
+    sched_classify(sw, i, i < nitems, c, len, tab.sort != 0, local, lwork);
     __syncthreads();
-    if (threadIdx.x < CLS_MAX && local[threadIdx.x]) atomicAdd(&count[threadIdx.x], local[threadIdx.x]);
+    if (threadIdx.x < CLS_MAX && local[threadIdx.x]) atomicAdd((unsigned long long *)&sw.work[threadIdx.x], (unsigned long long)lwork[threadIdx.x]);
 }
 __global__ void k_cls_zero(u32 *count) { if (threadIdx.x < CLS_MAX) count[threadIdx.x] = 0; }
 __global__ void k_cls_scan(u32 *count)
@@ -2416,20 +2461,62 @@ extern "C" void r4x16_launch_cls_group(const u32 *cls, int nitems, u32 *count, u
     hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(64), 0, s, count);
     hipLaunchKernelGGL(k_cls_scatter, dim3((nitems + 255) / 256), dim3(256), 0, s, cls, nitems, count, list);
 }
-extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t s, const R4Fork *fk) { launch_dec_chain_of(ws, ws->items, nitems, false, s, fk); }
-// one_row_only: the items are order-0 streams (one-row images): only the classes such an image can fall into are launched
-static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitems, bool one_row_only, hipStream_t s0, const R4Fork *fk)
+extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t s, const R4Fork *fk, const R4Opts *o, const SchedHint *hint) { launch_dec_chain_of(ws, ws->items, nitems, false, s, fk, o, hint); }
+static int dec_class_qpw(u32 ci, const R4Opts *o)
 {
-    hipStream_t s = s0;
-    {
-        DecClassTab tab;
-        tab.n = DEC_NCLS;
-        tab.split_o0 = fk != nullptr;           // (launches in stream order: a wave takes both kinds, 4,096 x 1 MiB q8 with X_RLE 26.7 against 28.2 ms)
-        for (u32 k = 0; k < DEC_NCLS; k++) { tab.bytes[k] = DEC_CLASSES[k].bytes; tab.lv[k] = (u32)DEC_CLASSES[k].lv; }
-        r4x16_launch_cls_zero(ws->cls_count, s);
-        hipLaunchKernelGGL(k_dec_classify, dim3((nitems + 255) / 256), dim3(256), 0, s, items, nitems, tab, ws->cls, ws->cls_count);
-        r4x16_launch_cls_group(ws->cls, nitems, ws->cls_count, ws->cls_list, s);
+    const auto &c = DEC_CLASSES[ci];
+    const int force_qpw = (int)o->v[OPT_DEC_QPW], force_small = (int)o->v[OPT_DEC_QPW_SMALL], force_pk = (int)o->v[OPT_DEC_QPW_PK],
+              force_dir = (int)o->v[OPT_DEC_QPW_DIR];                                                    // tuning aids
+    int qpw = (c.lv == 1 && force_pk && c.bytes == 3496) ? force_pk :
+              c.lv != 2 ? c.qpw : (force_qpw && c.bytes == 5360) ? force_qpw : (force_small && c.bytes < 5360) ? force_small : c.qpw;
+    if ((c.lv == 6 || c.lv == 7) && force_dir > 0 && qpw > force_dir) qpw = force_dir;
+    return qpw;
+}
+// one_row_only: the items are order-0 streams (one-row images): only the classes such an image can fall into are launched
+static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitems, bool one_row_only, hipStream_t s0, const R4Fork *fk, const R4Opts *o, const SchedHint *hint)
+{
+    // Classes side by side (r4x16_sched.h, PLAN): the class launches are dealt out over the caller's stream and the side
+    // streams (fk), and the device-written plan gives each class its stream's share of the chip.  Without side streams
+    // (a lane of the host pipeline, option sched_concurrent = 0) the launches go out in stream order, every class with
+    // the whole chip - as up to round 3.
+    const int nq = fk ? fk->n + 1 : 1;
+    typedef void (*chain_fn)(const DecItem *, DecDesc *, const u32 *, u32 *, int, u32, int);
+    struct Launch { chain_fn kern; int grid, qpw; size_t ldsb; u32 ci, bytes; };
+    Launch todo[CLS_MAX];
+    int ntodo = 0;
+    SchedPlan plan;
+    DecClassTab tab;
+    tab.n = DEC_NCLS;
+    tab.split_o0 = fk != nullptr;           // (launches in stream order: a wave takes both kinds, 4,096 x 1 MiB q8 with X_RLE 26.7 against 28.2 ms)
+    tab.sort = o->v[OPT_SCHED_SORT] != 0;
+    plan.ncls = DEC_NCLS; plan.concurrent = nq > 1; plan.claim = o->v[OPT_SCHED_CLAIM] != 0; plan.pad = 0;
+    for (u32 ci = 0; ci < CLS_MAX; ci++) { plan.qpw[ci] = 16; plan.wgs_full[ci] = 0; plan.queue[ci] = 0xff; }
+    for (u32 ci = 0; ci < DEC_NCLS; ci++) {
+        const auto &c = DEC_CLASSES[ci];
+        tab.bytes[ci] = c.bytes; tab.lv[ci] = (u32)c.lv;
+        const int qpw = dec_class_qpw(ci, o);
+        const size_t ldsb = (size_t)qpw * c.bytes;
+        plan.qpw[ci] = (u16)qpw;
+        plan.wgs_full[ci] = (u16)(cu_count() * resident_per_cu(ldsb, 1));
+        // (an order-0 image: at most IMG_O0_BYTES; depth 4 only as the lone row of an alphabet beyond 150 symbols)
+        const bool skip = (one_row_only && (c.lv == 1 || c.lv == 2 || (c.lv >= 5 && c.lv != 8) || c.bytes > (c.lv == 4 ? 22528u : IMG_O0_BYTES + RING_BYTES + 128u))) ||
+                          ((c.lv == 6 || c.lv == 7) && !ws->direct_budget);      // (no stream of this batch was given direct blocks)
+        if (skip) continue;
+        chain_fn kern =
+            c.lv == 1 ? k_dec_chain<true, 1> : c.lv == 5 ? k_dec_chain<true, 5> : (c.lv == 2 || c.lv == 8) ? k_dec_chain<true, 2> : c.lv == 3 ? k_dec_chain<true, 3> :
+            (c.lv == 6 || c.lv == 7) ? k_dec_chain<true, 6> : k_dec_chain<true, 4>;
+        todo[ntodo++] = Launch{kern, r4x16_resident_grid(ldsb, 1, (nitems + qpw - 1) / qpw), qpw, ldsb, ci, c.bytes};
     }
+    u8 qof[CLS_MAX];
+    {
+        int cls_of[CLS_MAX];
+        for (int k = 0; k < ntodo; k++) cls_of[k] = (int)todo[k].ci;
+        sched_assign_queues(plan, cls_of, ntodo, nq, hint, qof);
+        for (int k = 0; k < ntodo; k++) plan.queue[todo[k].ci] = qof[k];
+    }
+    r4x16_sched_zero(&ws->sched, s0);
+    hipLaunchKernelGGL(k_dec_classify, dim3((nitems + 255) / 256), dim3(256), 0, s0, items, nitems, tab, ws->sched);
+    r4x16_sched_group(&ws->sched, nitems, &plan, s0);
     if (r4x16_first_on_device(1u)) {
         lds_limit((const void *)k_dec_chain<true, 1>, 163840);
         lds_limit((const void *)k_dec_chain<true, 5>, 163840);
@@ -2438,57 +2525,33 @@ static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitem
         lds_limit((const void *)k_dec_chain<true, 4>, 163840);
         lds_limit((const void *)k_dec_chain<true, 6>, 163840);
     }
-    static const int force_qpw = getenv("R4X16_DEC_QPW") ? atoi(getenv("R4X16_DEC_QPW")) : 0;   // tuning aids
-    static const int force_small = getenv("R4X16_DEC_QPW_SMALL") ? atoi(getenv("R4X16_DEC_QPW_SMALL")) : 0;
-    if (fk) fk->begin(s0);                     // a small batch: its classes run side by side (R4Fork, r4x16_dev.h)
-    // Forked launches run side by side - and so do the EMPTY ones: the host does not know which classes hold streams.
-    // An empty grid of workgroups that each ask for a whole CU's LDS (the 80 / 160 KB classes) competes for CUs with the
-    // class that does the work (measured: 1,024 q40 streams 29 -> 37-49 ms when such grids were started first, and
-    // erratic times when they ran beside it), so classes of more than FORK_LDS_MAX bytes per workgroup are never
-    // forked: they go out on the caller's stream after the join, in stream order.
-    constexpr size_t FORK_LDS_MAX = 40960;
-    u32 launched = 0;
-    for (int pass = 0; pass < (fk ? 2 : 1); pass++) {
-    if (fk && pass == 1) { s = s0; fk->end(s0); }
-    for (u32 ci = 0; ci < DEC_NCLS; ci++) {
-        const auto &c = DEC_CLASSES[ci];
-        static const int force_pk = getenv("R4X16_DEC_QPW_PK") ? atoi(getenv("R4X16_DEC_QPW_PK")) : 0;
-        int qpw = (c.lv == 1 && force_pk && c.bytes == 3496) ? force_pk :
-                        c.lv != 2 ? c.qpw : (force_qpw && c.bytes == 5360) ? force_qpw : (force_small && c.bytes < 5360) ? force_small : c.qpw;
-        static const int force_dir = getenv("R4X16_DEC_QPW_DIR") ? atoi(getenv("R4X16_DEC_QPW_DIR")) : 0;
-        if (c.lv >= 6 && force_dir > 0 && qpw > force_dir) qpw = force_dir;
-        const size_t ldsb = (size_t)qpw * c.bytes;
-        if (fk && (ldsb > FORK_LDS_MAX) != (pass == 1)) continue;
-        const int grid = r4x16_resident_grid(ldsb, 1, (nitems + qpw - 1) / qpw);
-        void (*kern)(const DecItem *, DecDesc *, const u32 *, const u32 *, int, u32) =
-            c.lv == 1 ? k_dec_chain<true, 1> : c.lv == 5 ? k_dec_chain<true, 5> : c.lv == 2 ? k_dec_chain<true, 2> : c.lv == 3 ? k_dec_chain<true, 3> :
-            (c.lv == 6 || c.lv == 7) ? k_dec_chain<true, 6> : k_dec_chain<true, 4>;
-        // (an order-0 image: at most IMG_O0_BYTES; depth 4 only as the lone row of an alphabet beyond 150 symbols)
-        const bool skip = (one_row_only && (c.lv == 1 || c.lv >= 5 || c.bytes > (c.lv == 4 ? 22528u : IMG_O0_BYTES + RING_BYTES + 128u))) ||
-                          (c.lv >= 6 && !ws->direct_budget);      // (no stream of this batch was given direct blocks)
-        if (!skip) {
-            if (fk && pass == 0) s = fk->pick(s0, launched++);
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVE), ldsb, s, items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci), qpw, c.bytes);
-        }
-    }
-    }
-    const u32 ci = DEC_NCLS;
-    s = s0;
+    const int dyn = o->v[OPT_SCHED_CLAIM] != 0;
+    auto go = [&](const Launch &L, hipStream_t s) {
+        DecDesc *desc = ws->desc;
+        const u32 *list = ws->sched.list;
+        u32 *cnt = ws->sched.cnt + L.ci;
+        int qpw = L.qpw, dyn_ = dyn;
+        u32 bytes = L.bytes;
+        void *args[] = {(void *)&items, (void *)&desc, (void *)&list, (void *)&cnt, (void *)&qpw, (void *)&bytes, (void *)&dyn_};
+        r4x16_sched_launch((const void *)L.kern, dim3(L.grid), dim3(WAVE), args, L.ldsb, s);
+    };
+    if (fk) fk->begin(s0);
+    for (int k = 0; k < ntodo; k++) go(todo[k], fk ? fk->pick(s0, (unsigned)qof[k]) : s0);
+    if (fk) { fk->end(s0); r4x16_sched_hint_save(&ws->sched, hint, s0); }
     if (one_row_only) return;                 // (such an image always fits a class)
-    // images that fit no LDS class: tables stay in global memory (L2)
+    // images that fit no LDS class: tables stay in global memory (L2); after the join, in stream order
     const int grid = (nitems + 15) / 16;
-    hipLaunchKernelGGL((k_dec_chain<false, 2>), dim3(grid), dim3(WAVE), 0, s, items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci + 0), 16, 0u);
-    hipLaunchKernelGGL((k_dec_chain<false, 3>), dim3(grid), dim3(WAVE), 0, s, items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci + 1), 16, 0u);
-    hipLaunchKernelGGL((k_dec_chain<false, 4>), dim3(grid), dim3(WAVE), 0, s, items, ws->desc, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci + 2), 16, 0u);
+    go(Launch{k_dec_chain<false, 2>, grid, 16, 0, DEC_NCLS + 0, 0u}, s0);
+    go(Launch{k_dec_chain<false, 3>, grid, 16, 0, DEC_NCLS + 1, 0u}, s0);
+    go(Launch{k_dec_chain<false, 4>, grid, 16, 0, DEC_NCLS + 2, 0u}, s0);
 }
 // LDS bytes a stream may spend on direct blocks (level 6) when `nblk` streams are to be resident at once: the largest
 // direct class that still holds the batch in ONE round of the chip (0: none does - the batch is large enough to be
 // bound by resident streams, which is what the compressed rows are for).
 //   R4X16_DEC_DIRECT=0  never;  =N (N >= 1)  accept up to N rounds of direct streams (default 1)
-extern "C" u32 r4x16_dec_direct_budget(int nblk)
+extern "C" u32 r4x16_dec_direct_budget(int nblk, const R4Opts *o)
 {
-    const char *ev = getenv("R4X16_DEC_DIRECT");           // (read per call: the tests switch it between calls)
-    const int rounds = ev && *ev ? atoi(ev) : 1;
+    const int rounds = (int)o->v[OPT_DEC_DIRECT];
     if (rounds <= 0 || nblk <= 0) return 0u;
     const long cus = cu_count();
     const long per_cu = (nblk + cus * rounds - 1) / (cus * rounds);
@@ -2513,13 +2576,13 @@ extern "C" int r4x16_dec_residency(u32 nsym, int order, u32 bits, int *streams_p
     *streams_per_wave = 16; *waves_per_cu = 8;              // tables in global memory: bounded by wave slots
     return 0;
 }
-extern "C" void r4x16_launch_dec_back(const BatchArgs *a, const DecWs *ws, int base, int nblk, hipStream_t s)
+extern "C" void r4x16_launch_dec_back(const BatchArgs *a, const DecWs *ws, int base, int nblk, hipStream_t s, const R4Opts *o)
 {
     // One wave per block at every batch size since its trips became 256 literals of LDS-fed work (64 x 1 MiB q8 blocks with
     // X_RLE: step 38.0 ms either way; 1,024: 53.5 against 55.6; 2,048: 56.2 against 64.6); the workgroup-per-block
     // kernel, round 3's first answer to the old trip's fixed ~19 ms per MiB, stays selectable: R4X16_BACK_WG_PER_CU=N
     // takes it up to N blocks per CU.
-    const int wg_per_cu = getenv("R4X16_BACK_WG_PER_CU") ? atoi(getenv("R4X16_BACK_WG_PER_CU")) : 0;
+    const int wg_per_cu = (int)o->v[OPT_BACK_WG_PER_CU];
     if (nblk <= wg_per_cu * cu_count()) hipLaunchKernelGGL(k_dec_back<BACK_THREADS>, dim3(nblk), dim3(BACK_THREADS), 0, s, *a, *ws, base);
     else hipLaunchKernelGGL(k_dec_back<WAVE>, dim3(nblk), dim3(WAVE), 0, s, *a, *ws, base);
 }

@@ -43,13 +43,15 @@ __device__ __forceinline__ void wsync()
 // `buffer_inv sc1`, microseconds under load - and nothing here is read by another workgroup before the kernel ends.)
 __device__ __forceinline__ void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
-// Side streams of a context for the chain kernels of a SMALL batch.  The chain kernels are launched once per LDS size
-// class, in stream order - so a batch that mixes alphabets (q4 / q8 / q40 blocks: several classes) pays one chain latency
-// per class, one after the other, although each launch leaves most of the chip idle.  A batch of at most two blocks per
-// CU forks its class launches over these streams and joins them again (events); larger ones never do: forked launches
-// run side by side, the empty ones included, and a class that needs all of the LDS at once loses workgroups - a second
-// round - to whatever holds LDS when it starts (r4x16_api.hip: fork_blocks).
-#define R4_FORK_STREAMS 3
+// Side streams of a context for the chain kernels.  The chain kernels are launched once per LDS size class; in stream
+// order a batch that mixes alphabets (q4 / q8 / q40 blocks: several classes) pays one chain latency per class, one after
+// the other, although each launch leaves most of the chip idle.  So the class launches of a batch are dealt out over the
+// caller's stream and these side streams, and joined again (events); a device-written plan gives every class its share
+// of the chip (r4x16_sched.h).  Streams of ONE priority share two hardware queues, and the launches in a queue run one
+// after the other (tools/micro/launch_overlap.hip: 4 streams of one priority = 2 at a time; 6 streams cycling through
+// the three priorities = 6 at a time; hipExtAnyOrderLaunch on one stream = 1 at a time on gfx950) - hence five side
+// streams: two of the highest priority, two of the lowest, one of the caller's presumed own.
+#define R4_FORK_STREAMS 5
 struct R4Fork {
     hipStream_t aux[R4_FORK_STREAMS];
     hipEvent_t ev[R4_FORK_STREAMS + 1];
@@ -68,6 +70,22 @@ struct R4Fork {
         for (int i = 0; i < n; i++) { (void)hipEventRecord(ev[i + 1], aux[i]); (void)hipStreamWaitEvent(s, ev[i + 1], 0); }
     }
 };
+
+// Options of a context (include/rans4x16_hip.h: rans4x16_hip_set_option / rans4x16_hip_get_option).  The R4X16_*
+// environment variables only provide the DEFAULTS, and are read once per process (r4x16_opts_defaults, r4x16_api.hip):
+// nothing on a call path reads the environment.  The launchers take the calling context's options as an argument.
+enum R4Opt {
+    OPT_DEC_DIRECT, OPT_ENC_DIRECT, OPT_BACK_WG_PER_CU,
+    OPT_SCHED_SORT, OPT_SCHED_CLAIM, OPT_SCHED_CONCURRENT, OPT_MAX_WS_MB,
+    OPT_HOST_STRIPE_DEV, OPT_HOST_PIPE_MB, OPT_HOST_THREADS, OPT_HOST_LANES, OPT_HOST_SLAB_MIN_MB,
+    OPT_HOST_DEC_SLABS, OPT_HOST_ENC_SLABS, OPT_HOST_PACK, OPT_HOST_TRACE,
+    OPT_DEC_QPW, OPT_DEC_QPW_SMALL, OPT_DEC_QPW_PK, OPT_DEC_QPW_DIR,
+    OPT_ENC_QPW, OPT_ENC_WAVES, OPT_ENC_QPW_REC, OPT_ENC_QPW_CAP, OPT_FRONT_LDS,
+    OPT_COMBINE, OPT_COMBINE_WINDOW_US, OPT_COMBINE_MAX, OPT_COMBINE_WORKERS, OPT_COMBINE_MAX_MB, OPT_NUMA,
+    OPT_COUNT
+};
+struct R4Opts { long v[OPT_COUNT]; };
+extern "C" const R4Opts *r4x16_opts_defaults(void);
 
 // Arguments of a device-resident batch (include/rans4x16_hip.h, *_dev entry points).
 struct BatchArgs {

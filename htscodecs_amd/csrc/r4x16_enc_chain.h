@@ -4,6 +4,7 @@
 #pragma once
 #include <stdlib.h>
 #include "r4x16_dev.h"
+#include "r4x16_sched.h"
 #include "r4x16_enc_step.h"
 
 // General form: image in global memory, byte loads.  Used for the small nested streams inside
@@ -445,8 +446,8 @@ __device__ __forceinline__ u32 chain_encode_o0_pipe(const u8 *img_lds, u8 *ring,
 // PK: the class holds packed order-1 streams only (10-bit tables): a 1,025-entry reciprocal table suffices.
 #define ENC_LRCP_PK_BYTES 4112u      // 1,025 dwords, padded to 16
 template <bool LDS_IMG, bool PK>
-__global__ __launch_bounds__(256) void k_enc_chain(EncItem *items, const u32 *rcptab_, u8 *dump_, const u32 *list, const u32 *count,
-                                                   int qpw, int spw, u32 lds_per_item)
+__global__ __launch_bounds__(256) void k_enc_chain(EncItem *items, const u32 *rcptab_, u8 *dump_, const u32 *list, u32 *count,
+                                                   int qpw, int spw, u32 lds_per_item, int dyn)
 {
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
     const u32 tid = threadIdx.x;
@@ -454,12 +455,14 @@ __global__ __launch_bounds__(256) void k_enc_chain(EncItem *items, const u32 *rc
     // qpw streams per workgroup, spw per wave (the first spw quads of each wave)
     const u32 wq = lane >> 2;
     const u32 quad = (tid >> 6) * (u32)spw + wq;
-    // persistent: as many workgroups as are resident at once, each walking its share (see k_dec_chain)
-    // the streams of this launch's class, grouped on the device (k_enc_classify, r4x16_launch_cls_group)
-    const int nmine = (int)count[0];
-    list += count[CLS_MAX];
-    const int nwg = (nmine + qpw - 1) / qpw;
-    for (int wg = (int)blockIdx.x; wg < nwg; wg += (int)gridDim.x) {
+    // persistent: as many workgroups as are resident at once, each walking shares of its class's list (see k_dec_chain
+    // and r4x16_sched.h: longest streams first, shares claimed from the class's counter, count[SCHED_SEATS] workgroups work)
+    const int nmine = (int)count[SCHED_COUNT];
+    list += count[SCHED_START];
+    SchedWalk walk(count, nmine, qpw, dyn != 0);
+    for (;;) {
+    const int wg = LDS_IMG ? walk.next_wg((volatile u32 *)lds + 1) : walk.next_wave();
+    if (wg < 0) break;
     const int slot = wg * qpw + (int)quad;
     const bool mine = wq < (u32)spw && quad < (u32)qpw && slot < nmine;
     EncItem *I = &items[mine ? list[slot] : list[wg * qpw]];
@@ -477,6 +480,7 @@ __global__ __launch_bounds__(256) void k_enc_chain(EncItem *items, const u32 *rc
         __syncthreads();
         if (!any) continue;
     } else if (!wave_any(active)) continue;
+    sched_setprio(sched_prio_of(active, active ? I->n : 0u));
 
     const u32 order = active ? I->order : 2u;
     gcu32 *rcptab = to_global(rcptab_);

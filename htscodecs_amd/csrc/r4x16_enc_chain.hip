@@ -6,8 +6,7 @@
 
 // r4x16_enc_chain_pk.hip: k_enc_chain<true, true>
 extern "C" void r4x16_enc_chain_pk_lds_limit(int bytes);
-extern "C" void r4x16_enc_chain_pk_launch(int grid, int threads, size_t lds, hipStream_t s, EncItem *items, const u32 *rcptab, u8 *dump,
-                                          const u32 *list, const u32 *count, int qpw, int spw, u32 lds_per_item);
+extern "C" const void *r4x16_enc_chain_pk_kernel(void);
 
 // ---- host-callable launcher ----------------------------------------------------------------------
 extern "C" bool r4x16_first_on_device(u32 bit);                                          // r4x16_decode.hip
@@ -26,132 +25,163 @@ static const u32 ENC_CLASSES[] = {656, 1296, 2576, 4752, 6416, 12816, 16272, 244
 static const u32 ENC_PK_CLASSES[] = {1168, 2064, 2832, 3536, 3728, 4752, 6416};
 // symbol records (kind 2, r4x16_enc_chain_rec.hip; only batches that leave LDS to spare make such images): one wave
 // per workgroup, {LDS bytes per stream, streams per wave}; four workgroups per CU, then fewer
-static const struct { u32 bytes; int qpw; } ENC_REC_CLASSES[] = {
+struct EncRecClass { u32 bytes; int qpw; };
+static const EncRecClass ENC_REC_CLASSES[] = {
     {2576, 15}, {4112, 9}, {8080, 5}, {13584, 3}, {20368, 2}, {32000, 1}, {40960, 1}, {53760, 1}, {81920, 1}, {163840, 1},
 };
 #define ENC_REC_NCLS ((u32)(sizeof(ENC_REC_CLASSES) / sizeof(ENC_REC_CLASSES[0])))
 extern "C" void r4x16_enc_chain_rec_lds_limit(int bytes);
-extern "C" void r4x16_enc_chain_rec_launch(int grid, size_t lds, hipStream_t s, EncItem *items, const u32 *safe, u8 *dump,
-                                           const u32 *list, const u32 *count, int qpw, u32 lds_per_item);
+extern "C" const void *r4x16_enc_chain_rec_kernel(void);
 #define ENC_NCLS    ((u32)(sizeof(ENC_CLASSES) / sizeof(ENC_CLASSES[0])))
 #define ENC_PK_NCLS ((u32)(sizeof(ENC_PK_CLASSES) / sizeof(ENC_PK_CLASSES[0])))
-static int enc_class_qpw(u32 bytes, bool pk = false)
+static int enc_class_qpw(u32 bytes, bool pk, const R4Opts *o)
 {
     const u32 room = 163840u - (pk ? ENC_LRCP_PK_BYTES : ENC_LRCP_BYTES);
     const u32 fit = room / bytes;
-    static const int cap = getenv("R4X16_ENC_QPW_CAP") ? atoi(getenv("R4X16_ENC_QPW_CAP")) : 64;   // tuning aid
+    const int cap = (int)o->v[OPT_ENC_QPW_CAP];                  // tuning aid (default 64)
     return (int)(fit > (u32)cap ? (u32)cap : fit);
 }
 extern "C" int r4x16_resident_grid(size_t lds_bytes, int waves_per_wg, int wanted);      // r4x16_decode.hip
 extern "C" int r4x16_cu_count(void);
-struct EncClassTab { u32 n; u32 bytes[CLS_MAX]; u32 pk[CLS_MAX]; };     // classes: u16 images, then packed ones
-__global__ __launch_bounds__(256) void k_enc_classify(const EncItem *items, int nitems, EncClassTab tab, u32 *cls, u32 *count)
+struct EncClassTab { u32 n; u32 sort; u32 bytes[CLS_MAX]; u32 pk[CLS_MAX]; };     // classes: u16 images, then packed ones, then records
+__global__ __launch_bounds__(256) void k_enc_classify(const EncItem *items, int nitems, EncClassTab tab, SchedWs sw)
 {
     __shared__ u32 local[CLS_MAX];
-    if (threadIdx.x < CLS_MAX) local[threadIdx.x] = 0;
+    __shared__ u64 lwork[CLS_MAX];
+    if (threadIdx.x < CLS_MAX) { local[threadIdx.x] = 0; lwork[threadIdx.x] = 0ull; }
     __syncthreads();
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i < nitems) {
-        u32 c = CLS_NONE;
-        if (items[i].active) {
-            const u32 need = items[i].img_bytes + ENC_RING_BYTES, pk = items[i].packed;
-            c = tab.n;                                         // images too large for LDS (never a packed one)
-            for (u32 k = 0; k < tab.n; k++) if (tab.pk[k] == pk && need <= tab.bytes[k]) { c = k; break; }
-            atomicAdd(&local[c], 1u);
-        }
-        cls[i] = c;
+    u32 c = CLS_NONE, len = 0;
+    if (i < nitems && items[i].active) {
+        // kinds: 0 u16 rows, 1 packed rows, 2 symbol records; the order-0 streams of kinds 0 and 2 have classes of their
+        // own (kinds 3 and 4): the kernels run a wave's order-1 streams, then its order-0 streams, and a class that holds
+        // both kinds - small order-1 alphabets make images as small as a one-row image - would pay both latencies
+        const u32 need = items[i].img_bytes + ENC_RING_BYTES, raw = items[i].packed,
+                  pk = items[i].order != 0 ? raw : raw == 0u ? 3u : raw == 2u ? 4u : raw;
+        c = tab.n;                                         // images too large for LDS (never a packed one)
+        for (u32 k = 0; k < tab.n; k++) if (tab.pk[k] == pk && need <= tab.bytes[k]) { c = k; break; }
+        len = items[i].n;
     }
+    sched_classify(sw, i, i < nitems, c, len, tab.sort != 0, local, lwork);
     __syncthreads();
-    if (threadIdx.x < CLS_MAX && local[threadIdx.x]) atomicAdd(&count[threadIdx.x], local[threadIdx.x]);
+    if (threadIdx.x < CLS_MAX && local[threadIdx.x]) atomicAdd((unsigned long long *)&sw.work[threadIdx.x], (unsigned long long)lwork[threadIdx.x]);
 }
-extern "C" void r4x16_launch_cls_group(const u32 *cls, int nitems, u32 *count, u32 *list, hipStream_t s);   // r4x16_decode.hip
-extern "C" void r4x16_launch_cls_zero(u32 *count, hipStream_t s);
-extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t s0, const R4Fork *fk)
+// the shape of a class's launch: streams per workgroup, waves, streams per wave, LDS bytes
+struct EncShape { int qpw, waves, spw; size_t ldsb; u32 bytes; };
+#define ENC_O0_ROWS_BYTES 1296u      // order-0 streams with u16 rows: a 770-byte image and the ring
+#define ENC_O0_REC_BYTES  8080u      // order-0 streams with symbol records: a 4,352-byte image and the ring
+#define ENC_O0_REC_QPW    5
+static EncShape enc_rows_shape(u32 cls, int nitems, const R4Opts *o, u32 bytes_o0 = 0)
 {
-    hipStream_t s = s0;
+    const bool pk = !bytes_o0 && cls >= ENC_NCLS;
+    const u32 bytes = bytes_o0 ? bytes_o0 : pk ? ENC_PK_CLASSES[cls - ENC_NCLS] : ENC_CLASSES[cls];
+    const u32 tuned = pk ? 3536u : 4752u;                // the class of the 46-symbol quality tables
+    const int force_qpw = (int)o->v[OPT_ENC_QPW], force_waves = (int)o->v[OPT_ENC_WAVES];   // tuning aids
+    int qpw = (force_qpw && bytes == tuned) ? force_qpw : enc_class_qpw(bytes, pk, o);
+    // One workgroup per CU is the best shape (measured: 30 streams per CU as 1 x 32 beat 2 x 16 by a
+    // third and half-filled 64s by a fifth), so a batch that cannot fill the class's workgroups on
+    // every CU gets smaller ones (items [0, n/3) are the payload streams).
     {
-        EncClassTab tab;
-        tab.n = 0;
-        for (const u32 bytes : ENC_CLASSES) { tab.pk[tab.n] = 0; tab.bytes[tab.n++] = bytes; }
-        for (const u32 bytes : ENC_PK_CLASSES) { tab.pk[tab.n] = 1; tab.bytes[tab.n++] = bytes; }
-        for (const auto &c : ENC_REC_CLASSES) { tab.pk[tab.n] = 2; tab.bytes[tab.n++] = c.bytes; }
-        r4x16_launch_cls_zero(ws->cls_count, s);
-        hipLaunchKernelGGL(k_enc_classify, dim3((nitems + 255) / 256), dim3(256), 0, s, (const EncItem *)ws->items, nitems, tab, ws->cls, ws->cls_count);
-        r4x16_launch_cls_group(ws->cls, nitems, ws->cls_count, ws->cls_list, s);
+        const int cus = r4x16_cu_count();
+        int want = (((nitems + 2) / 3 + cus - 1) / cus + 3) & ~3;
+        if (want < 8) want = 8;
+        if (qpw > want) qpw = want;
     }
+    int waves = (qpw + 7) / 8;                         // about eight streams per wave measured best (fewer
+    if (waves > 4) waves = 4;                          // lanes per LDS access, one wave per SIMD)
+    if (force_waves && bytes == tuned) waves = force_waves;
+    EncShape sh;
+    sh.qpw = qpw; sh.waves = waves; sh.spw = (qpw + waves - 1) / waves; sh.bytes = bytes;
+    sh.ldsb = (size_t)(pk ? ENC_LRCP_PK_BYTES : ENC_LRCP_BYTES) + (size_t)qpw * bytes;
+    return sh;
+}
+static EncShape enc_rec_shape(u32 r, const R4Opts *o, bool o0 = false)
+{
+    const EncRecClass c0 = {ENC_O0_REC_BYTES, ENC_O0_REC_QPW};
+    const EncRecClass &c = o0 ? c0 : ENC_REC_CLASSES[r];
+    const int force_rec = (int)o->v[OPT_ENC_QPW_REC];     // tuning aid
+    EncShape sh;
+    sh.qpw = (force_rec > 0 && c.qpw > force_rec) ? force_rec : c.qpw;
+    sh.waves = 1; sh.spw = sh.qpw; sh.bytes = c.bytes;
+    sh.ldsb = (size_t)sh.qpw * c.bytes;
+    return sh;
+}
+static int enc_wgs_per_cu(const EncShape &sh)
+{
+    const long granules = ((long)sh.ldsb + 1279) / 1280;      // LDS is allocated in 1,280-byte granules
+    long wgs = granules ? 128 / granules : 32;
+    if (wgs * sh.waves > 32) wgs = 32 / sh.waves;
+    return wgs < 1 ? 1 : (int)wgs;
+}
+extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t s0, const R4Fork *fk, const R4Opts *o, const SchedHint *hint)
+{
+    // classes side by side over the caller's stream and the side streams, each with its stream's share of the chip
+    // (launch_dec_chain_of, r4x16_sched.h); class index ci = position in the classify table: u16 classes, packed
+    // classes, record classes
+    const int nq = fk ? fk->n + 1 : 1;
+    struct Launch { const void *kern; int grid; EncShape sh; u32 ci; };
+    Launch todo[CLS_MAX];
+    int ntodo = 0;
+    EncClassTab tab;
+    tab.n = 0;
+    tab.sort = o->v[OPT_SCHED_SORT] != 0;
+    SchedPlan plan;
+    plan.concurrent = nq > 1; plan.claim = o->v[OPT_SCHED_CLAIM] != 0; plan.pad = 0;
+    for (u32 ci = 0; ci < CLS_MAX; ci++) { plan.qpw[ci] = 16; plan.wgs_full[ci] = 0; plan.queue[ci] = 0xff; }
+    const int cus = r4x16_cu_count();
+    auto add = [&](u32 pk, u32 bytes, const EncShape &sh, const void *kern) {
+        const u32 ci = tab.n++;
+        tab.pk[ci] = pk; tab.bytes[ci] = bytes;
+        plan.qpw[ci] = (u16)sh.qpw; plan.wgs_full[ci] = (u16)(cus * enc_wgs_per_cu(sh));
+        if (!kern) return;
+        todo[ntodo++] = Launch{kern, r4x16_resident_grid(sh.ldsb, sh.waves, (nitems + sh.qpw - 1) / sh.qpw), sh, ci};
+    };
+    for (u32 k = 0; k < ENC_NCLS; k++) add(0, ENC_CLASSES[k], enc_rows_shape(k, nitems, o), (const void *)k_enc_chain<true, false>);
+    for (u32 k = 0; k < ENC_PK_NCLS; k++) add(1, ENC_PK_CLASSES[k], enc_rows_shape(ENC_NCLS + k, nitems, o), r4x16_enc_chain_pk_kernel());
+    // (record classes: only batches that leave LDS to spare make such images)
+    for (u32 k = 0; k < ENC_REC_NCLS; k++) add(2, ENC_REC_CLASSES[k].bytes, enc_rec_shape(k, o), ws->direct_budget ? r4x16_enc_chain_rec_kernel() : nullptr);
+    add(3, ENC_O0_ROWS_BYTES, enc_rows_shape(0, nitems, o, ENC_O0_ROWS_BYTES), (const void *)k_enc_chain<true, false>);
+    add(4, ENC_O0_REC_BYTES, enc_rec_shape(0, o, true), ws->direct_budget ? r4x16_enc_chain_rec_kernel() : nullptr);
+    plan.ncls = tab.n;
+    u8 qof[CLS_MAX];
+    {
+        int cls_of[CLS_MAX];
+        for (int k = 0; k < ntodo; k++) cls_of[k] = (int)todo[k].ci;
+        sched_assign_queues(plan, cls_of, ntodo, nq, hint, qof);
+        for (int k = 0; k < ntodo; k++) plan.queue[todo[k].ci] = qof[k];
+    }
+    r4x16_sched_zero(&ws->sched, s0);
+    hipLaunchKernelGGL(k_enc_classify, dim3((nitems + 255) / 256), dim3(256), 0, s0, (const EncItem *)ws->items, nitems, tab, ws->sched);
+    r4x16_sched_group(&ws->sched, nitems, &plan, s0);
     if (r4x16_first_on_device(4u)) {
         (void)hipFuncSetAttribute((const void *)k_enc_chain<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
         r4x16_enc_chain_pk_lds_limit(163840);
         r4x16_enc_chain_rec_lds_limit(163840);
     }
-    if (fk) fk->begin(s0);                     // a small batch: its classes run side by side (R4Fork, r4x16_dev.h)
-    u32 launched = 0;
-    static const int force_qpw = getenv("R4X16_ENC_QPW") ? atoi(getenv("R4X16_ENC_QPW")) : 0;   // tuning aids
-    static const int force_waves = getenv("R4X16_ENC_WAVES") ? atoi(getenv("R4X16_ENC_WAVES")) : 0;
-    // class index ci = position in the classify table: u16 classes, packed classes, record classes
-    // (forked: classes of more than FORK_LDS_MAX bytes per workgroup wait for the join and go out in stream order -
-    //  an EMPTY grid of workgroups that each ask for most of a CU's LDS competes for CUs with the class that does the
-    //  work, see launch_dec_chain_of; pass 0 = the forked classes, pass 1 = the rest after the join)
-    constexpr size_t FORK_LDS_MAX = 40960;
-    int pass = 0;
-    auto launch_rows = [&](u32 cls) {
-        const bool pk = cls >= ENC_NCLS;
-        const u32 bytes = pk ? ENC_PK_CLASSES[cls - ENC_NCLS] : ENC_CLASSES[cls];
-        const u32 tuned = pk ? 3536u : 4752u;                // the class of the 46-symbol quality tables
-        int qpw = (force_qpw && bytes == tuned) ? force_qpw : enc_class_qpw(bytes, pk);
-        // One workgroup per CU is the best shape (measured: 30 streams per CU as 1 x 32 beat 2 x 16 by a
-        // third and half-filled 64s by a fifth), so a batch that cannot fill the class's workgroups on
-        // every CU gets smaller ones (items [0, n/3) are the payload streams).
-        {
-            const int cus = r4x16_cu_count();
-            int want = (((nitems + 2) / 3 + cus - 1) / cus + 3) & ~3;
-            if (want < 8) want = 8;
-            if (qpw > want) qpw = want;
-        }
-        int waves = (qpw + 7) / 8;                         // about eight streams per wave measured best (fewer
-        if (waves > 4) waves = 4;                          // lanes per LDS access, one wave per SIMD)
-        if (force_waves && bytes == tuned) waves = force_waves;
-        const int spw = (qpw + waves - 1) / waves;
-        const size_t ldsb = (size_t)(pk ? ENC_LRCP_PK_BYTES : ENC_LRCP_BYTES) + (size_t)qpw * bytes;
-        if (fk && (ldsb > FORK_LDS_MAX) != (pass == 1)) return;
-        const int grid = r4x16_resident_grid(ldsb, waves, (nitems + qpw - 1) / qpw);
-        if (fk && pass == 0) s = fk->pick(s0, launched++);
-        if (pk)
-            r4x16_enc_chain_pk_launch(grid, (int)(WAVE * waves), ldsb, s, ws->items, ws->rcptab, ws->dump, (const u32 *)ws->cls_list,
-                                      (const u32 *)(ws->cls_count + cls), qpw, spw, bytes);
-        else
-            hipLaunchKernelGGL((k_enc_chain<true, false>), dim3(grid), dim3(WAVE * waves), ldsb, s,
-                               ws->items, ws->rcptab, ws->dump, (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + cls), qpw, spw, bytes);
+    const int dyn = o->v[OPT_SCHED_CLAIM] != 0;
+    auto go = [&](const Launch &L, hipStream_t s) {
+        EncItem *items = ws->items;
+        const u32 *rcptab = ws->rcptab;
+        u8 *dump = ws->dump;
+        const u32 *list = ws->sched.list;
+        u32 *cnt = ws->sched.cnt + L.ci;
+        int qpw = L.sh.qpw, spw = L.sh.spw, dyn_ = dyn;
+        u32 bytes = L.sh.bytes;
+        void *args[] = {(void *)&items, (void *)&rcptab, (void *)&dump, (void *)&list, (void *)&cnt, (void *)&qpw, (void *)&spw, (void *)&bytes, (void *)&dyn_};
+        r4x16_sched_launch(L.kern, dim3(L.grid), dim3(WAVE * L.sh.waves), args, L.sh.ldsb, s);
     };
-    auto launch_rec = [&](u32 r) {
-        const auto &c = ENC_REC_CLASSES[r];
-        if (!ws->direct_budget) return;                       // (no stream of this batch was given records)
-        static const int force_rec = getenv("R4X16_ENC_QPW_REC") ? atoi(getenv("R4X16_ENC_QPW_REC")) : 0;   // tuning aid
-        const int qpw = (force_rec > 0 && c.qpw > force_rec) ? force_rec : c.qpw;
-        const size_t ldsb = (size_t)qpw * c.bytes;
-        if (fk && (ldsb > FORK_LDS_MAX) != (pass == 1)) return;
-        const int grid = r4x16_resident_grid(ldsb, 1, (nitems + qpw - 1) / qpw);
-        if (fk && pass == 0) s = fk->pick(s0, launched++);
-        r4x16_enc_chain_rec_launch(grid, ldsb, s, ws->items, ws->rcptab, ws->dump, (const u32 *)ws->cls_list,
-                                   (const u32 *)(ws->cls_count + ENC_NCLS + ENC_PK_NCLS + r), qpw, c.bytes);
-    };
-    for (pass = 0; pass < (fk ? 2 : 1); pass++) {
-        if (fk && pass == 1) { s = s0; fk->end(s0); }
-        for (u32 cls = 0; cls < ENC_NCLS + ENC_PK_NCLS; cls++) launch_rows(cls);
-        for (u32 r = 0; r < ENC_REC_NCLS; r++) launch_rec(r);
-    }
-    const u32 ci = ENC_NCLS + ENC_PK_NCLS + ENC_REC_NCLS;
-    s = s0;
-    const int grid = (nitems + 15) / 16;
-    hipLaunchKernelGGL((k_enc_chain<false, false>), dim3(grid), dim3(WAVE), 0, s, ws->items, ws->rcptab, ws->dump,
-                       (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + ci), 16, 16, 0u);
+    if (fk) fk->begin(s0);
+    for (int k = 0; k < ntodo; k++) go(todo[k], fk ? fk->pick(s0, (unsigned)qof[k]) : s0);
+    if (fk) { fk->end(s0); r4x16_sched_hint_save(&ws->sched, hint, s0); }
+    EncShape sh;
+    sh.qpw = 16; sh.waves = 1; sh.spw = 16; sh.bytes = 0u; sh.ldsb = 0;
+    go(Launch{(const void *)k_enc_chain<false, false>, (nitems + 15) / 16, sh, tab.n}, s0);     // images too large for LDS
 }
 // LDS bytes a stream may spend on symbol records when `nblk` streams are to be resident at once: the largest record
 // class that still holds the batch in one round of the chip (0: none).  R4X16_ENC_DIRECT=0 never; =N up to N rounds.
-extern "C" u32 r4x16_enc_direct_budget(int nblk)
+extern "C" u32 r4x16_enc_direct_budget(int nblk, const R4Opts *o)
 {
-    const char *ev = getenv("R4X16_ENC_DIRECT");           // (read per call: the tests switch it between calls)
-    const int rounds = ev && *ev ? atoi(ev) : 1;
+    const int rounds = (int)o->v[OPT_ENC_DIRECT];
     if (rounds <= 0 || nblk <= 0) return 0u;
     const long cus = r4x16_cu_count();
     const long per_cu = (nblk + cus * rounds - 1) / (cus * rounds);
@@ -174,7 +204,7 @@ extern "C" int r4x16_enc_residency(u32 nsym, int order, int *streams_per_wave, i
         if ((cls >= ENC_NCLS) != pk) continue;
         const u32 bytes = pk ? ENC_PK_CLASSES[cls - ENC_NCLS] : ENC_CLASSES[cls];
         if (need > bytes) continue;
-        const int qpw = enc_class_qpw(bytes, pk);
+        const int qpw = enc_class_qpw(bytes, pk, r4x16_opts_defaults());
         int waves = (qpw + 7) / 8;
         if (waves > 4) waves = 4;
         *streams_per_wave = (qpw + waves - 1) / waves;

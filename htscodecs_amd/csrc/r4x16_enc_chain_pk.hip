@@ -11,8 +11,4 @@ extern "C" void r4x16_enc_chain_pk_lds_limit(int bytes)
 {
     (void)hipFuncSetAttribute((const void *)k_enc_chain<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
-extern "C" void r4x16_enc_chain_pk_launch(int grid, int threads, size_t lds, hipStream_t s, EncItem *items, const u32 *rcptab, u8 *dump,
-                                          const u32 *list, const u32 *count, int qpw, int spw, u32 lds_per_item)
-{
-    hipLaunchKernelGGL((k_enc_chain<true, true>), dim3(grid), dim3(threads), lds, s, items, rcptab, dump, list, count, qpw, spw, lds_per_item);
-}
+extern "C" const void *r4x16_enc_chain_pk_kernel(void) { return (const void *)k_enc_chain<true, true>; }

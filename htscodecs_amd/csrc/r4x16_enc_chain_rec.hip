@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "r4x16_dev.h"
+#include "r4x16_sched.h"
 
 struct RecOut {
     u8 *ring;            // LDS: 128-byte ring of emitted words (word j of the stream at byte 126 - 2 (j & 63)) + dump slot
@@ -295,21 +296,22 @@ __device__ __forceinline__ u32 chain_encode_rec(const u8 *img_lds, u8 *ring, gcu
 // k_enc_chain_rec: one wave per workgroup, qpw streams per wave (one per quad), persistent, one launch per LDS size
 // class (see k_dec_chain).  A stream owns lds_per_item bytes: image (idx_of + records), then the word ring.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVE) void k_enc_chain_rec(EncItem *items, const u32 *safe_, u8 *dump_, const u32 *list, const u32 *count,
-                                                        int qpw, u32 lds_per_item)
+__global__ __launch_bounds__(WAVE) void k_enc_chain_rec(EncItem *items, const u32 *safe_, u8 *dump_, const u32 *list, u32 *count,
+                                                        int qpw, int spw_unused, u32 lds_per_item, int dyn)
 {
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
     const u32 lane = threadIdx.x;
     const u32 quad = lane >> 2;
-    const int nmine = (int)count[0];
-    list += count[CLS_MAX];
-    const int nwg = (nmine + qpw - 1) / qpw;
-    for (int wg = (int)blockIdx.x; wg < nwg; wg += (int)gridDim.x) {
+    const int nmine = (int)count[SCHED_COUNT];
+    list += count[SCHED_START];
+    SchedWalk walk(count, nmine, qpw, dyn != 0);          // (r4x16_sched.h)
+    for (int wg = walk.next_wave(); wg >= 0; wg = walk.next_wave()) {
         const int slot = wg * qpw + (int)quad;
         const bool mine = quad < (u32)qpw && slot < nmine;
         EncItem *I = &items[mine ? list[slot] : list[wg * qpw]];
         const bool active = mine && I->active;
         if (!wave_any(active)) continue;
+        sched_setprio(sched_prio_of(active, active ? I->n : 0u));
         const u32 img_bytes = active ? I->img_bytes : 0u;
         const u32 order = active ? I->order : 2u;
         gcu8 *data = (gcu8 *)I->data;
@@ -349,8 +351,4 @@ extern "C" void r4x16_enc_chain_rec_lds_limit(int bytes)
 {
     (void)hipFuncSetAttribute((const void *)k_enc_chain_rec, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
-extern "C" void r4x16_enc_chain_rec_launch(int grid, size_t lds, hipStream_t s, EncItem *items, const u32 *safe, u8 *dump,
-                                           const u32 *list, const u32 *count, int qpw, u32 lds_per_item)
-{
-    hipLaunchKernelGGL(k_enc_chain_rec, dim3(grid), dim3(WAVE), lds, s, items, safe, dump, list, count, qpw, lds_per_item);
-}
+extern "C" const void *r4x16_enc_chain_rec_kernel(void) { return (const void *)k_enc_chain_rec; }

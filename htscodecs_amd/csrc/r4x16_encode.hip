@@ -1037,7 +1037,9 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
     u8 *img = ws.images + (u64)b * ENC_IMG_BYTES;
     u8 *tab = ws.tab + (u64)b * TAB_BYTES;
     u8 *scratch = ws.scratch + (u64)b * ws.scratch_stride;
-    u8 *scratch_end = scratch + ws.scratch_stride;
+    // the block's staging region for the transforms (r4x16_common.h: enc_var_layout; laid out by k_enc_voff)
+    const EncVar V = enc_var_layout(in_size, order);
+    u8 *var = ws.var ? ws.var + ws.voff[b] : nullptr;
 
     // ---- container header (:1144-1237) ---------------------------------------------------------
     if (tid == 0) {
@@ -1053,9 +1055,6 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
         u32 go = 0;
         H.flags = 0; H.hl = 0;
         if (cap < compress_bound(in_size, order)) st = ST_CAPACITY;
-        // the backward-write area was sized from the caller's max_in_size: a larger block would run the
-        // table and chain coders past the start of its slot, into its neighbour's
-        else if ((u64)compress_bound(in_size, 0xc1) + 64u > ws.scratch_stride) st = ST_UNSUPPORTED;
         else {
             if (in_size <= 20) order &= ~X_STRIPE;                         // :1151
             if (order & X_STRIPE) st = ST_UNSUPPORTED;                     // host entry points split stripes
@@ -1063,8 +1062,8 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
                 D->hdr[0] = X_CAT;
                 D->hdr_len = 1 + var_put(D->hdr + 1, in_size);
                 D->cat = 1; D->data = (u64)in; D->dlen = in_size; D->flags = X_CAT;
-            } else if ((order & (X_PACK | X_RLE)) && (in_size > ws.xf_stride)) {
-                st = ST_UNSUPPORTED;                                       // batch was sized without transform staging
+            } else if (V.total && (!var || ws.voff[b] + V.total > ws.var_bytes)) {
+                st = ST_UNSUPPORTED;                                       // batch was sized without transform staging, or for less data than it holds
             } else {
                 u32 flags = (u32)order & 0xff;
                 u32 hl = 1;
@@ -1090,7 +1089,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
     if (flags & X_PACK) {
         if (n == 0) flags &= ~(u32)X_PACK;
         else {
-            u8 *pbuf = ws.packed + (u64)b * ws.xf_stride;
+            u8 *pbuf = var + V.packed;
             // hts_pack only asks WHICH bytes occur (pack.c:62-75): the presence pass, plain byte stores, instead of the
             // counting histogram, whose LDS atomics all but serialise on the two to sixteen symbols PACK is made for
             // Blocks of 256 KiB and more take the symbol set from their first 64 KiB and pack at once; the packing
@@ -1122,8 +1121,8 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
     if (flags & X_RLE) {
         if (n == 0) flags &= ~(u32)X_RLE;
         else {
-            u8 *lits_end = ws.lits + (u64)b * ws.xf_stride + ws.xf_stride;
-            u8 *meta_end = ws.meta + (u64)b * (ws.xf_stride + 768) + (ws.xf_stride + 768);
+            u8 *lits_end = var + V.meta;                                   // (the literals' region ends where the meta's begins)
+            u8 *meta_end = var + V.scratch2;
             PROF(3);
             wg_hist8_t<true>(data, n, S.F, S.T, (u32 *)dyn, tid);          // + per symbol, the bytes that repeat their predecessor
             PROF(4);
@@ -1154,7 +1153,7 @@ __global__ __launch_bounds__(FRONT_THREADS) void k_enc_front(BatchArgs a, EncWs 
                         I1->data = (u64)m; I1->n = mlen; I1->image = (u64)imgm; I1->bits = O0_BITS; I1->order = 0;
                         I1->ns = 256; I1->img_bytes = mrec ? enc_rec_img_bytes(256u, 1u) : ENC_IMG_IDX + 2u * 257u;
                         I1->packed = mrec ? 2u : 0u; I1->affine = mrec ? 1u : 0u;
-                        I1->scratch_end = (u64)(ws.scratch2 + (u64)b * ws.scratch2_stride + ws.scratch2_stride);
+                        I1->scratch_end = (u64)(var + V.total);
                         I1->active = S.status == ST_OK;
                     }
                 }
@@ -1294,8 +1293,19 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
     u8 *img = ws.images + (u64)b * ENC_IMG_BYTES;
     u8 *tab = ws.tab + (u64)b * TAB_BYTES;
     u8 *tabraw = tab + 1;                                 // the serialised order-1 table, behind its header byte
-    u8 *scratch = ws.scratch + (u64)b * ws.scratch_stride;
-    u8 *scratch_end = scratch + ws.scratch_stride;
+    u8 *scratch = ws.scratch + (u64)b * ws.scratch_stride;      // pair counters, then the nested table stream (NEST_AREA)
+    // The payload is written backwards from the end of the caller's own slot - what the reference's coders do with their
+    // output buffer (rANS_static4x16pr.c:396-402, :706-710: `ptr = out_end`, then a memmove behind the table) - so the
+    // workspace holds no bound-sized area per block any more.  k_enc_front has checked the slot against
+    // rans_compress_bound_4x16(in_size, order); the end used is 16-byte aligned inside it (the bound's own slack of
+    // twenty bytes covers the difference).
+    u8 *scratch_end;
+    {
+        const int i = base + (int)b;
+        const int order_i = a.d_order ? a.d_order[i] : a.order;
+        const u64 slot = (u64)(a.out + a.out_off[i]);
+        scratch_end = (u8 *)((slot + compress_bound(a.in_size[i], order_i)) & ~15ull);
+    }
     const u8 *data = (const u8 *)D->data;
     const u32 n = D->dlen;
 
@@ -1541,6 +1551,34 @@ __global__ __launch_bounds__(WAVE) void k_enc_tables(BatchArgs a, EncWs ws, int 
 // k_enc_finish
 // ---------------------------------------------------------------------------------------------
 #define FINISH_THREADS 256u
+// Move n bytes DOWN inside one buffer (dst <= src) by a workgroup of NT threads.  Where the regions do not overlap
+// it is group_copy; where they do, a tile is read by all threads before any of them writes it (a thread that ran ahead
+// by more than the distance between the regions would otherwise overwrite bytes another one has yet to read).
+template <u32 NT>
+__device__ __forceinline__ void slot_move(u8 *dst, const u8 *src, u32 n, u32 t)
+{
+    if (dst == src || n == 0) return;
+    if (src >= dst + n) { group_copy<NT>(dst, src, n, t); return; }
+    for (u32 base = 0; base < n; base += 32u * NT) {                      // 32 bytes per thread and tile
+        const u32 at = base + 32u * t;
+        u32x4 v0 = {0, 0, 0, 0}, v1 = {0, 0, 0, 0};
+        u32 w[8] = {0, 0, 0, 0, 0, 0, 0, 0};                              // the one partial piece, at the very end
+        const u32 left = at < n ? n - at : 0u;
+        if (left >= 32u) { v0 = *(const u32x4_unaligned *)(src + at); v1 = *(const u32x4_unaligned *)(src + at + 16); }
+        else {
+#pragma unroll
+            for (u32 j = 0; j < 32u; j++) if (j < left) w[j >> 2] |= (u32)src[at + j] << (8u * (j & 3u));
+        }
+        __syncthreads();
+        if (left >= 32u) { *(u32x4_unaligned *)(dst + at) = v0; *(u32x4_unaligned *)(dst + at + 16) = v1; }
+        else {
+#pragma unroll
+            for (u32 j = 0; j < 32u; j++) if (j < left) dst[at + j] = (u8)(w[j >> 2] >> (8u * (j & 3u)));
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(FINISH_THREADS) void k_enc_finish(BatchArgs a, EncWs ws, int base)
 {
     __shared__ u8 vbuf[16];
@@ -1621,7 +1659,12 @@ __global__ __launch_bounds__(FINISH_THREADS) void k_enc_finish(BatchArgs a, EncW
                 group_copy<FINISH_THREADS>(out + pos, (const u8 *)D->tab, D->tab_len, lane);
                 pos += D->tab_len;
             }
-            group_copy<FINISH_THREADS>(out + pos, (const u8 *)I0->scratch_end - pay, pay, lane);
+            // the payload sits at the end of this very slot (k_enc_tables): moved down behind the table.  Header, meta
+            // and table were written below `pos`, which the reference's own layout keeps below the payload's start
+            // (the same bytes in a buffer of the same bound); a stream that did not would have been cut: reported.
+            const u8 *psrc = (const u8 *)I0->scratch_end - pay;
+            if (out + pos > psrc) { if (lane == 0) { a.status[i] = ST_CAPACITY; a.out_size[i] = 0; } return; }
+            slot_move<FINISH_THREADS>(out + pos, psrc, pay, lane);
             pos += pay;
         }
     }
@@ -1632,15 +1675,38 @@ __global__ __launch_bounds__(FINISH_THREADS) void k_enc_finish(BatchArgs a, EncW
     }
 }
 
+// Where each block's staging region for the transforms starts (enc_var_layout): an exclusive prefix sum of the
+// regions' sizes over the chunk, by one workgroup - every thread a contiguous run of blocks.
+__global__ __launch_bounds__(1024) void k_enc_voff(BatchArgs a, int base, int nblk, u64 *voff)
+{
+    __shared__ u64 part[1024];
+    const u32 t = threadIdx.x;
+    const int per = (nblk + 1023) / 1024, lo = (int)t * per, hi = lo + per < nblk ? lo + per : nblk;
+    u64 sum = 0;
+    for (int b = lo; b < hi; b++) sum += enc_var_layout(a.in_size[base + b], a.d_order ? a.d_order[base + b] : a.order).total;
+    part[t] = sum;
+    __syncthreads();
+    for (u32 d = 1; d < 1024u; d <<= 1) {
+        const u64 add = t >= d ? part[t - d] : 0ull;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    u64 at = part[t] - sum;
+    for (int b = lo; b < hi; b++) { voff[b] = at; at += enc_var_layout(a.in_size[base + b], a.d_order ? a.d_order[base + b] : a.order).total; }
+    if (t == 1023) voff[nblk] = part[1023];
+}
+
 // ---- host-callable launchers -------------------------------------------------------------------
 extern "C" bool r4x16_first_on_device(u32 bit);                                          // r4x16_decode.hip
-extern "C" void r4x16_launch_enc_front(const BatchArgs *a, const EncWs *ws, int base, int nblk, hipStream_t s)
+extern "C" void r4x16_launch_enc_front(const BatchArgs *a, const EncWs *ws, int base, int nblk, hipStream_t s, const R4Opts *o)
 {
+    if (ws->var) hipLaunchKernelGGL(k_enc_voff, dim3(1), dim3(1024), 0, s, *a, base, nblk, ws->voff);
     // static + dynamic LDS exceeds the 64 KB default; gfx950 has 160 KB per CU
     if (r4x16_first_on_device(2u))
         (void)hipFuncSetAttribute((const void *)k_enc_front, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    static const u32 dynb0 = getenv("R4X16_FRONT_LDS") ? (u32)atoi(getenv("R4X16_FRONT_LDS")) : FRONT_DYN_LDS;  // tuning aid
-    static const u32 dynb = dynb0 < RLE_LDS_BYTES ? RLE_LDS_BYTES : dynb0 > 65536u - 8192u ? 65536u - 8192u : dynb0;   // (the run-length split's slots; wg_hist8's 16 x 257 counters are smaller)
+    const u32 dynb0 = o->v[OPT_FRONT_LDS] > 0 ? (u32)o->v[OPT_FRONT_LDS] : FRONT_DYN_LDS;  // tuning aid
+    const u32 dynb = dynb0 < RLE_LDS_BYTES ? RLE_LDS_BYTES : dynb0 > 65536u - 8192u ? 65536u - 8192u : dynb0;   // (the run-length split's slots; wg_hist8's 16 x 257 counters are smaller)
     hipLaunchKernelGGL(k_enc_front, dim3(nblk), dim3(FRONT_THREADS), dynb, s, *a, *ws, base, dynb);
 }
 extern "C" void r4x16_launch_enc_tables(const BatchArgs *a, const EncWs *ws, int base, int nblk, hipStream_t s)
@@ -2118,17 +2184,18 @@ extern "C" void r4x8_launch_encode(const BatchArgs *a, const EncWs *ws, int base
         (void)hipFuncSetAttribute((const void *)k8_enc_front, hipFuncAttributeMaxDynamicSharedMemorySize, FRONT_DYN_LDS);
     const u32 room = (u32)(ws->scratch_stride > 0xffffffffull ? 0xffffffffu : ws->scratch_stride);
     hipLaunchKernelGGL(k8_enc_front, dim3(nblk), dim3(FRONT_THREADS), FRONT_DYN_LDS, s, *a, *ws, base);
-    r4x16_launch_cls_zero(ws->cls_count, s);
-    hipLaunchKernelGGL(k8_enc_classify, dim3((nblk + 255) / 256), dim3(256), 0, s, (const EncItem *)ws->items, nblk, ws->cls, ws->cls_count);
-    r4x16_launch_cls_group(ws->cls, nblk, ws->cls_count, ws->cls_list, s);
+    // (the 4x16 encoder's grouping arrays, with round 2's plain grouping by class: key = class, cnt = count / start / cursor)
+    r4x16_launch_cls_zero(ws->sched.cnt, s);
+    hipLaunchKernelGGL(k8_enc_classify, dim3((nblk + 255) / 256), dim3(256), 0, s, (const EncItem *)ws->items, nblk, ws->sched.key, ws->sched.cnt);
+    r4x16_launch_cls_group(ws->sched.key, nblk, ws->sched.cnt, ws->sched.list, s);
     if (r4x16_first_on_device(32u))
         (void)hipFuncSetAttribute((const void *)k8_enc_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     const int grid = (nblk + 15) / 16;
     hipLaunchKernelGGL(k8_enc_chain<true>, dim3(grid), dim3(WAVE), X8E_LRCP_BYTES + 16 * X8E_SLOT0, s, ws->items, ws->rcptab,
-                       (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + 0), room, X8E_SLOT0);
+                       (const u32 *)ws->sched.list, (const u32 *)(ws->sched.cnt + 0), room, X8E_SLOT0);
     hipLaunchKernelGGL(k8_enc_chain<true>, dim3(grid), dim3(WAVE), X8E_LRCP_BYTES + 16 * X8E_SLOT1, s, ws->items, ws->rcptab,
-                       (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + 1), room, X8E_SLOT1);
+                       (const u32 *)ws->sched.list, (const u32 *)(ws->sched.cnt + 1), room, X8E_SLOT1);
     hipLaunchKernelGGL(k8_enc_chain<false>, dim3(grid), dim3(WAVE), 0, s, ws->items, ws->rcptab,
-                       (const u32 *)ws->cls_list, (const u32 *)(ws->cls_count + 2), room, 0u);
+                       (const u32 *)ws->sched.list, (const u32 *)(ws->sched.cnt + 2), room, 0u);
     hipLaunchKernelGGL(k8_enc_finish, dim3(nblk), dim3(FINISH_THREADS), 0, s, *a, *ws, base, room);
 }

@@ -75,7 +75,7 @@ int r4x16_run_host_batch(rans4x16_hip_ctx *c, int n, bool decode,
     }
     if (!striped.empty()) {
         std::vector<int> sst(striped.size(), 0);
-        static const bool dev_route = !(getenv("R4X16_HOST_STRIPE_DEV") && atoi(getenv("R4X16_HOST_STRIPE_DEV")) == 0);
+        const bool dev_route = c->opts.v[OPT_HOST_STRIPE_DEV] != 0;
         const int rc = dev_route ? stripe_many_dev(c, decode, striped, in, in_size, out, out_size, order, sst.data())
                      : decode ? stripe_uncompress_many(c, striped, in, in_size, out, out_size, sst.data())
                               : stripe_compress_many(c, striped, in, in_size, out, out_size, order, sst.data());
@@ -121,13 +121,17 @@ static int run_slab(rans4x16_hip_ctx *c, int n, bool decode,
     std::vector<i32> ord(n);
     size_t in_tot = 0, out_tot = 0;
     u32 max_in = 0, max_cap = 0;
+    u64 sum_in = 0, sum_cap = 0;
     for (int i = 0; i < n; i++) {
         in_off[i] = in_tot; in_tot += align_up((size_t)in_size[i] + 16, 256);
         cap[i] = out_size[i];
         out_off[i] = out_tot; out_tot += align_up((size_t)cap[i] + 16, 256);
         if (in_size[i] > max_in) max_in = in_size[i];
         // decode: only blocks with PACK / RLE need the stage buffers that max_out_cap sizes (r4x16_api.hip)
-        if (cap[i] > max_cap && (!decode || (in_size[i] && (in[i][0] & (X_PACK | X_RLE))))) max_cap = cap[i];
+        const bool xfb = !decode || (in_size[i] && (in[i][0] & (X_PACK | X_RLE)));
+        if (cap[i] > max_cap && xfb) max_cap = cap[i];
+        sum_in += in_size[i];
+        if (xfb) sum_cap += cap[i];
         ord[i] = order ? order[i] : 0;
     }
     const size_t arr = align_up((size_t)n * 8, 256);
@@ -149,11 +153,11 @@ static int run_slab(rans4x16_hip_ctx *c, int n, bool decode,
 
     int rc;
     if (decode)
-        rc = rans4x16_hip_uncompress_dev(c, n, d_in, d_in_off, d_in_size, d_out, d_out_off, d_cap, d_osz,
-                                         d_status, max_in, max_cap, s);
+        rc = rans4x16_hip_uncompress_dev_sized(c, n, d_in, d_in_off, d_in_size, d_out, d_out_off, d_cap, d_osz,
+                                               d_status, max_in, max_cap, sum_cap, s);
     else
-        rc = rans4x16_hip_compress_dev(c, n, d_in, d_in_off, d_in_size, d_out, d_out_off, d_cap, d_osz,
-                                       d_status, 0, d_order, max_in, s);
+        rc = rans4x16_hip_compress_dev_sized(c, n, d_in, d_in_off, d_in_size, d_out, d_out_off, d_cap, d_osz,
+                                             d_status, 0, d_order, max_in, sum_in, s);
     if (rc != 0) return -1;
 
     std::vector<u32> osz(n);
@@ -185,15 +189,10 @@ static int run_slab(rans4x16_hip_ctx *c, int n, bool decode,
 //   * A slab's results are copied out as soon as its kernels finish, beside later slabs' kernels.
 // A chain kernel needs its 25-55 ms per MiB of block size however few blocks it is given, so slabs are
 // large (up to 2 GiB of input + output capacity) and all lanes run at once.
-// Knobs: R4X16_HOST_PIPE_MB (batches of at least this size, or of 32 blocks and more, take this route; default 64;
-//        0 = never),
-//        R4X16_HOST_THREADS (default 8), R4X16_HOST_LANES (default 2), R4X16_HOST_SLAB_MIN_MB (default 32).
+// Options of the context (rans4x16_hip_set_option): host_pipe_mb (batches of at least this size, or of 32 blocks and
+//        more, take this route; default 64; 0 = never), host_threads (default 8), host_lanes (default 2),
+//        host_slab_min_mb (default 32).
 // ---------------------------------------------------------------------------------------------
-static long env_long(const char *name, long dflt)
-{
-    const char *e = getenv(name);
-    return e && *e ? atol(e) : dflt;
-}
 
 #define PIPE_CHUNK ((size_t)8 << 20)          // bytes per pinned bounce buffer
 
@@ -258,6 +257,7 @@ static int pipe_prepare(rans4x16_hip_ctx *c, int threads, int nlanes, size_t nev
             rans4x16_hip_ctx *l = rans4x16_hip_create(c->device);
             if (!l) { c->err = "host batch: cannot create a lane context"; return -1; }
             l->no_fork = true;          // (side streams of equal priority on two lanes would share a hardware queue)
+            l->opts = c->opts;
             // The runtime keeps one pool of hardware queues per stream priority and multiplexes the streams of
             // a priority onto it; two lane streams of equal priority were seen sharing a queue, which runs their
             // kernels one after the other.  Lanes therefore take different priorities: different queues.
@@ -306,6 +306,7 @@ struct PipeSlab {
     int gin = 1, gout = 1;                    // blocks per copy-in / copy-out unit
     int nin = 0, nout = 0;                    // units
     u32 max_in = 0, max_cap = 0;
+    u64 sum_in = 0, sum_cap = 0;              // the slab's input bytes / the output capacities of its X_PACK and X_RLE blocks
     std::atomic<int> in_next{0}, in_queued{0}, out_next{0};
     std::atomic<int> launched{0}, finished{0};
     // copy-out plan, made once by the first thread that sees the slab's kernels finished:
@@ -378,8 +379,8 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
     // exactly 1,024 blocks on ONE lane reach 25.3 GB/s (each takes the short-step rows, 31 ms, and its output leaves
     // while the next runs) - but only for alphabets whose direct rows fit four streams per CU, which the host cannot
     // know; with any other data three serial slabs cost three full chain latencies.  Not adopted.
-    size_t nslab = (rounds ? rounds : 1) * (size_t)nlanes * (size_t)(decode ? env_long("R4X16_HOST_DEC_SLABS", 1) : env_long("R4X16_HOST_ENC_SLABS", 1));
-    const long slab_min_mb = env_long("R4X16_HOST_SLAB_MIN_MB", 32);
+    size_t nslab = (rounds ? rounds : 1) * (size_t)nlanes * (size_t)(decode ? c->opts.v[OPT_HOST_DEC_SLABS] : c->opts.v[OPT_HOST_ENC_SLABS]);
+    const long slab_min_mb = c->opts.v[OPT_HOST_SLAB_MIN_MB];
     while (nslab > 1 && tot / nslab < ((size_t)(slab_min_mb > 0 ? slab_min_mb : 1) << 20)) nslab--;
     if (nslab > (size_t)n) nslab = (size_t)n;
     std::vector<PipeSlab> slabs(nslab);
@@ -405,7 +406,10 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
             if (in_size[i] > S.max_in) S.max_in = in_size[i];
             if (out_size[i] > widest) widest = out_size[i];
             // decode: only blocks with PACK / RLE need the stage buffers that max_out_cap sizes (r4x16_api.hip)
-            if (out_size[i] > S.max_cap && (!decode || (in_size[i] && (in[i][0] & (X_PACK | X_RLE))))) S.max_cap = out_size[i];
+            const bool xfb = !decode || (in_size[i] && (in[i][0] & (X_PACK | X_RLE)));
+            if (out_size[i] > S.max_cap && xfb) S.max_cap = out_size[i];
+            S.sum_in += in_size[i];
+            if (xfb) S.sum_cap += out_size[i];
         }
         const size_t gi = PIPE_CHUNK / (align_up((size_t)S.max_in + 16, 256));
         const size_t go = PIPE_CHUNK / ((size_t)widest + 64);
@@ -428,7 +432,7 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
 
     std::atomic<int> broken{0};
     std::mutex err_mu;
-    const bool trace = env_long("R4X16_HOST_TRACE", 0) != 0;
+    const bool trace = c->opts.v[OPT_HOST_TRACE] != 0;
     const auto t_begin = std::chrono::steady_clock::now();
     auto now_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     if (trace) fprintf(stderr, "[pipe] %s n=%d slabs=%zu threads=%d lanes=%d in=%.1f MB cap=%.1f MB\n", decode ? "dec" : "enc", n, nslab, threads, nlanes, in_tot / 1e6, out_tot / 1e6);
@@ -470,11 +474,11 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
         const int lo = S.lo * K, m = (S.hi - S.lo) * K;          // items
         int rc;
         if (decode)
-            rc = rans4x16_hip_uncompress_dev(l, m, d_in, d_in_off + lo, d_in_size + lo, d_out, d_out_off + lo, d_cap + lo,
-                                             d_osz + lo, d_status + lo, S.max_in, S.max_cap, l->stream);
+            rc = rans4x16_hip_uncompress_dev_sized(l, m, d_in, d_in_off + lo, d_in_size + lo, d_out, d_out_off + lo, d_cap + lo,
+                                                   d_osz + lo, d_status + lo, S.max_in, S.max_cap, S.sum_cap * (u64)K, l->stream);
         else
-            rc = rans4x16_hip_compress_dev(l, m, d_in, d_in_off + lo, d_in_size + lo, d_out, d_out_off + lo, d_cap + lo,
-                                           d_osz + lo, d_status + lo, 0, d_order + lo, S.max_in, l->stream);
+            rc = rans4x16_hip_compress_dev_sized(l, m, d_in, d_in_off + lo, d_in_size + lo, d_out, d_out_off + lo, d_cap + lo,
+                                                 d_osz + lo, d_status + lo, 0, d_order + lo, S.max_in, S.sum_in * (u64)K, l->stream);
         if (rc != 0) {
             std::lock_guard<std::mutex> g2(err_mu);
             if (!broken.exchange(1)) c->err = l->err;
@@ -590,7 +594,7 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
         const u64 in_region = in_off[S.hi - 1] + align_up((size_t)in_size[S.hi - 1] + 16, 256) - in_off[S.lo];
         const u64 out_extent = out_off[(size_t)(S.hi - 1) * K + (K - 1)] + cap[(size_t)(S.hi - 1) * K + (K - 1)] - out_off[(size_t)S.lo * K];
         const bool dense = K == 1 && sum * 4 >= out_extent * 3;       // decode: capacity = size, slots are adjacent
-        if (dense || T > in_region || env_long("R4X16_HOST_PACK", 1) == 0) {
+        if (dense || T > in_region || c->opts.v[OPT_HOST_PACK] == 0) {
             S.plan.store(3, std::memory_order_release);
             return true;
         }
@@ -732,8 +736,8 @@ static int run_plain_batch(rans4x16_hip_ctx *c, int n, bool decode,
                            const unsigned char *const *in, const unsigned int *in_size,
                            unsigned char *const *out, unsigned int *out_size, const int *order, int *status)
 {
-    const long pipe_mb = env_long("R4X16_HOST_PIPE_MB", 64);
-    long threads = env_long("R4X16_HOST_THREADS", 8), nlanes = env_long("R4X16_HOST_LANES", 2);
+    const long pipe_mb = c->opts.v[OPT_HOST_PIPE_MB];
+    long threads = c->opts.v[OPT_HOST_THREADS], nlanes = c->opts.v[OPT_HOST_LANES];
     threads = threads < 1 ? 1 : threads > 32 ? 32 : threads;
     nlanes = nlanes < 1 ? 1 : nlanes > 16 ? 16 : nlanes;
     size_t tot = 0;
@@ -1187,7 +1191,7 @@ extern "C" int rans4x16_hip_compress_best_batch(rans4x16_hip_ctx *c, int n,
     std::vector<int> best(n, -1), st(n, R4X16_E_UNSUPPORTED);
     std::vector<unsigned int> capv(out_size, out_size + n);
     if (!plain_m.empty()) {
-        long threads = env_long("R4X16_HOST_THREADS", 8), nlanes = env_long("R4X16_HOST_LANES", 2);
+        long threads = c->opts.v[OPT_HOST_THREADS], nlanes = c->opts.v[OPT_HOST_LANES];
         threads = threads < 1 ? 1 : threads > 32 ? 32 : threads;
         nlanes = nlanes < 1 ? 1 : nlanes > 16 ? 16 : nlanes;
         size_t tot = 0;

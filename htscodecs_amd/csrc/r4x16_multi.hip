@@ -101,7 +101,7 @@ struct NodeBinding {
     bool bound = false;
     explicit NodeBinding(int node)
     {
-        static const bool enabled = !(getenv("R4X16_NUMA") && atoi(getenv("R4X16_NUMA")) == 0);
+        const bool enabled = r4x16_opts_defaults()->v[OPT_NUMA] != 0;
         cpu_set_t want;
         if (!enabled || !node_cpus(node, &want)) return;
         if (pthread_getaffinity_np(pthread_self(), sizeof old, &old) != 0) return;

@@ -1,0 +1,132 @@
+// r4x16_sched.hip - the device-side grouping, ordering and launch plan of the chain kernels' streams (r4x16_sched.h).
+#include "r4x16_sched.h"
+#include <algorithm>
+
+__global__ __launch_bounds__(256) void k_sched_zero(SchedWs w)
+{
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i < 2u * SCHED_BINS) w.bins[i] = 0u;
+    if (i < SCHED_CNT_WORDS) w.cnt[i] = 0u;
+    if (i < CLS_MAX) w.work[i] = 0ull;
+}
+
+// One workgroup: exclusive scan of the (class, bucket) bins -> where each bin's streams start in the list; per-class
+// counts and starts; and the plan - how many workgroups of each class's launch may work.
+//   A class alone on the chip needs  t_c = work_c / (qpw_c x wgs_full_c)  (bytes per resident stream: the classes' step
+//   times are within a factor of two of each other, the counts of resident streams differ by a factor of fifty).  The
+//   launches of one stream run one after the other, the streams side by side: stream q gets the fraction
+//   T_q / sum(T) of the chip, T_q = the sum of its classes' t_c, and each of its classes that fraction of wgs_full_c
+//   while it runs - all streams then end together.  If every stream's largest class fits beside the others' as a
+//   whole, nothing is rationed.
+__global__ __launch_bounds__(1024) void k_sched_scan(SchedWs w, SchedPlan plan)
+{
+    __shared__ u32 part[1024];
+    __shared__ float tq[CLS_MAX], fillq[CLS_MAX];
+    const u32 t = threadIdx.x;
+    constexpr u32 PER = SCHED_BINS / 1024u;                  // bins per thread (16): a class is 16 threads
+    u32 v[PER], sum = 0;
+#pragma unroll
+    for (u32 j = 0; j < PER; j++) { v[j] = w.bins[t * PER + j]; sum += v[j]; }
+    part[t] = sum;
+    __syncthreads();
+    for (u32 d = 1; d < 1024u; d <<= 1) {                    // inclusive scan, 10 steps
+        const u32 add = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    u32 at = part[t] - sum;
+#pragma unroll
+    for (u32 j = 0; j < PER; j++) { w.bins[t * PER + j] = at; at += v[j]; }
+    constexpr u32 TPC = SCHED_NB / PER;                      // threads per class
+    if (t % TPC == 0) {
+        const u32 c = t / TPC;
+        const u32 first = part[t] - sum, last = part[t + TPC - 1];
+        w.cnt[SCHED_COUNT + c] = last - first;
+        w.cnt[SCHED_START + c] = first;
+    }
+    if (t < CLS_MAX) { tq[t] = 0.f; fillq[t] = 0.f; }
+    __syncthreads();
+    if (t == 0 && plan.concurrent) {
+        for (u32 c = 0; c < plan.ncls; c++) {
+            const u32 n = w.cnt[SCHED_COUNT + c], q = plan.queue[c];
+            if (!n || !plan.wgs_full[c] || q >= CLS_MAX) continue;
+            tq[q] += (float)w.work[c] / ((float)plan.qpw[c] * (float)plan.wgs_full[c]);
+            const float fill = (float)((n + plan.qpw[c] - 1u) / plan.qpw[c]) / (float)plan.wgs_full[c];
+            if (fill > fillq[q]) fillq[q] = fill;
+        }
+    }
+    __syncthreads();
+    if (t < CLS_MAX) {
+        const u32 n = w.cnt[SCHED_COUNT + t];
+        const u32 qpw = t < plan.ncls ? plan.qpw[t] : 16u, full = t < plan.ncls ? plan.wgs_full[t] : 0u;
+        const u32 q = t < plan.ncls ? plan.queue[t] : 0xffu;
+        u32 seats = full ? full : 0xffffffffu;               // (classes the host gave no figures for: every workgroup works)
+        if (plan.concurrent && n && full && q < CLS_MAX) {
+            float tot = 0.f, fills = 0.f;
+            for (u32 c = 0; c < CLS_MAX; c++) { tot += tq[c]; fills += fillq[c]; }
+            const u32 want = (n + qpw - 1u) / qpw;
+            u32 s = want;
+            if (fills > 1.f && tot > 0.f) {
+                s = (u32)ceilf(tq[q] / tot * (float)full);
+                if (s < 1u) s = 1u;
+                if (s > want) s = want;
+            }
+            if (s > full) s = full;
+            seats = s;
+        }
+        w.cnt[SCHED_SEATS + t] = n ? seats : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sched_scatter(SchedWs w, int nitems)
+{
+    const int i = (int)(blockIdx.x * 256u + threadIdx.x);
+    const u32 key = i < nitems ? w.key[i] : CLS_NONE;
+    const bool has = key != CLS_NONE;
+    const u32 rank = sched_wave_add(w.bins + SCHED_BINS, has ? key : 0u, has);
+    if (has) w.list[w.bins[key] + rank] = (u32)i;
+}
+
+extern "C" void r4x16_sched_zero(const SchedWs *w, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sched_zero, dim3((2u * SCHED_BINS + 255u) / 256u), dim3(256), 0, s, *w);
+}
+extern "C" void r4x16_sched_group(const SchedWs *w, int nitems, const SchedPlan *plan, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sched_scan, dim3(1), dim3(1024), 0, s, *w, *plan);
+    hipLaunchKernelGGL(k_sched_scatter, dim3((nitems + 255) / 256), dim3(256), 0, s, *w, nitems);
+}
+extern "C" void r4x16_sched_launch(const void *kernel, dim3 grid, dim3 block, void **args, size_t lds, hipStream_t s)
+{
+    (void)hipLaunchKernel(kernel, grid, block, args, lds, s);
+}
+
+void sched_assign_queues(const SchedPlan &plan, const int *todo_cls, int ntodo, int nq, const SchedHint *hint, u8 *queue_of_todo)
+{
+    double load[R4_FORK_STREAMS + 1] = {0};
+    double t[CLS_MAX];
+    int order[CLS_MAX];
+    bool any = false;
+    for (int k = 0; k < ntodo; k++) {
+        const int c = todo_cls[k];
+        const double w = hint && hint->work ? (double)hint->work[c] : 0.0;
+        t[k] = plan.wgs_full[c] ? w / ((double)plan.qpw[c] * plan.wgs_full[c]) : 0.0;
+        if (t[k] > 0.0) any = true;
+        order[k] = k;
+    }
+    if (nq <= 1 || !any) { for (int k = 0; k < ntodo; k++) queue_of_todo[k] = (u8)(nq > 1 ? k % nq : 0); return; }
+    std::stable_sort(order, order + ntodo, [&](int a, int b) { return t[a] > t[b]; });
+    int rr = 0;
+    for (int j = 0; j < ntodo; j++) {
+        const int k = order[j];
+        int q = 0;
+        if (t[k] > 0.0) { for (int i = 1; i < nq; i++) if (load[i] < load[q]) q = i; load[q] += t[k]; }
+        else q = rr++ % nq;                              // classes the last batch did not use: in turn
+        queue_of_todo[k] = (u8)q;
+    }
+}
+extern "C" void r4x16_sched_hint_save(const SchedWs *w, const SchedHint *hint, hipStream_t s)
+{
+    if (hint && hint->work) (void)hipMemcpyAsync(hint->work, w->work, CLS_MAX * sizeof(u64), hipMemcpyDeviceToHost, s);
+}

@@ -32,6 +32,15 @@ SIGNATURES = {
     "rans4x16_hip_uncompress_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_uint32, C.c_uint32, C.c_void_p]),
+    "rans4x16_hip_compress_dev_sized": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_int, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]),
+    "rans4x16_hip_uncompress_dev_sized": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p]),
+    "rans4x16_hip_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_long]),
+    "rans4x16_hip_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_long)]),
+    "rans4x16_hip_option_name": (C.c_char_p, [C.c_int]),
     "rans4x16_hip_workspace_bytes": (C.c_size_t, [C.c_void_p]),
     "rans4x16_hip_timing": (None, [C.c_void_p, C.c_int]),
     "rans4x16_hip_timing_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]),

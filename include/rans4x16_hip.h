@@ -133,12 +133,74 @@ int rans4x16_hip_uncompress_dev(rans4x16_hip_ctx *ctx, int n,
                                 int32_t *d_status, uint32_t max_in_size, uint32_t max_out_cap,
                                 void *stream);
 
+/* The same calls with one more host-side figure, the SUM of the blocks' sizes: the workspace a block needs for
+ * X_PACK / X_RLE depends on its own length, the device lays those regions out itself, and the host only has to bound
+ * their total - total_in_size (encode: sum of d_in_size) / total_out_cap (decode: sum of d_out_cap over the blocks
+ * that carry X_PACK or X_RLE; the sum over all blocks is a valid bound) instead of n x the largest block.  A batch of
+ * 90,000 blocks of 4 KiB .. 1 MiB then takes a quarter of the workspace and is walked in one chunk.  0 = unknown
+ * (the plain calls above).  A batch that holds more than it announced fails the blocks that do not fit (UNSUPPORTED). */
+int rans4x16_hip_compress_dev_sized(rans4x16_hip_ctx *ctx, int n,
+                                    const unsigned char *d_in, const uint64_t *d_in_off,
+                                    const uint32_t *d_in_size,
+                                    unsigned char *d_out, const uint64_t *d_out_off,
+                                    const uint32_t *d_out_cap, uint32_t *d_out_size,
+                                    int32_t *d_status, int order, const int32_t *d_order,
+                                    uint32_t max_in_size, uint64_t total_in_size, void *stream);
+int rans4x16_hip_uncompress_dev_sized(rans4x16_hip_ctx *ctx, int n,
+                                      const unsigned char *d_in, const uint64_t *d_in_off,
+                                      const uint32_t *d_in_size,
+                                      unsigned char *d_out, const uint64_t *d_out_off,
+                                      const uint32_t *d_out_cap, uint32_t *d_out_size,
+                                      int32_t *d_status, uint32_t max_in_size, uint32_t max_out_cap,
+                                      uint64_t total_out_cap, void *stream);
+
 /* Device-resident decode of X_STRIPE blocks: the flag and the plane count N live in the stream, so the host cannot
  * size the workspace per block; this sets what every block of later rans4x16_hip_uncompress_dev calls reserves:
  * `planes` internal sub-blocks (the default N is 4) and a plane buffer of `max_block_size` bytes.  A stripe block
  * with more planes, or larger than that, reports UNSUPPORTED; like the reference (:1379) a stripe block must be given
  * an output capacity equal to its stored size.  planes == 0 (the default) switches it off.  Returns 0, -1 on bad arguments. */
 int rans4x16_hip_set_dev_stripe_planes(rans4x16_hip_ctx *ctx, int planes, unsigned int max_block_size);
+
+/* ---- 2b. options ---------------------------------------------------------------------------
+ * Everything that can be tuned or switched is an option of the context, set by name; the value is a long.
+ * The R4X16_* environment variables named below only provide the DEFAULTS: they are read once per process, when the
+ * first context is created (or the first option is asked for); no call path reads the environment.
+ * ctx == NULL addresses the process-wide defaults: what contexts created from now on start with, and the
+ * process-wide options at the end of the list.  Returns 0, or -1 for an unknown name.
+ *
+ *   name               default  environment default     meaning
+ *   dec_direct            1     R4X16_DEC_DIRECT         decode: direct (short-step) rows for batches of up to N rounds of
+ *                                                        resident direct streams; 0 = never
+ *   enc_direct            1     R4X16_ENC_DIRECT         encode: the same for symbol records
+ *   back_wg_per_cu        0     R4X16_BACK_WG_PER_CU     decode: run-length expansion by a workgroup per block up to N
+ *                                                        blocks per compute unit (0: always one wave per block)
+ *   sched_sort            1     R4X16_SCHED_SORT         chain kernels: streams of a class ordered by length, longest first
+ *   sched_claim           1     R4X16_SCHED_CLAIM        chain kernels: shares claimed from a counter (0: fixed stride)
+ *   sched_concurrent      1     R4X16_SCHED_CONCURRENT   chain kernels: the classes of a batch side by side on six streams,
+ *                                                        each with its share of the chip (0: one after the other)
+ *   max_workspace_mb   98304    R4X16_MAX_WS_MB          ceiling of the device workspace; larger batches are walked in chunks
+ *   host_pipe_mb         64     R4X16_HOST_PIPE_MB       host batches of at least this many MiB (or 32 blocks) are pipelined
+ *   host_threads          8     R4X16_HOST_THREADS       copier threads of the host pipeline
+ *   host_lanes            2     R4X16_HOST_LANES         slabs of a host batch in flight at once
+ *   host_slab_min_mb     32     R4X16_HOST_SLAB_MIN_MB   smallest slab
+ *   host_dec_slabs / host_enc_slabs  1                   slabs per lane and round
+ *   host_pack             1     R4X16_HOST_PACK          encode results gathered on the device before they cross PCIe
+ *   host_stripe_dev       1     R4X16_HOST_STRIPE_DEV    X_STRIPE blocks of host batches through the device stripe kernels
+ *   host_trace            0     R4X16_HOST_TRACE         timeline of a pipelined host batch on stderr
+ *   dec_qpw, dec_qpw_small, dec_qpw_pk, dec_qpw_dir, enc_qpw, enc_waves, enc_qpw_rec, enc_qpw_cap, front_lds
+ *                                                        tuning aids: streams per wave / workgroup of single classes
+ *   process-wide (ctx == NULL, before the first single-block or multi-device call):
+ *   combine               1     R4X16_COMBINE            the five drop-in symbols go through the combiner
+ *   combine_window_us    -1     R4X16_COMBINE_WINDOW_US  fixed gathering window (-1: adaptive)
+ *   combine_max         256     R4X16_COMBINE_MAX        blocks per combined batch
+ *   combine_workers       1     R4X16_COMBINE_WORKERS    worker threads per direction
+ *   combine_max_mb     2048     R4X16_COMBINE_MAX_MB     buffer bytes per combined batch
+ *   numa                  1     R4X16_NUMA               multi-device calls bind each device's worker to its NUMA node
+ */
+int rans4x16_hip_set_option(rans4x16_hip_ctx *ctx, const char *name, long value);
+int rans4x16_hip_get_option(const rans4x16_hip_ctx *ctx, const char *name, long *value);
+/* Name of option number `index` (0, 1, ..), NULL past the last: lets a caller list what this build knows. */
+const char *rans4x16_hip_option_name(int index);
 
 /* Bytes of device workspace the context currently holds (grows on demand, never shrinks). */
 size_t rans4x16_hip_workspace_bytes(const rans4x16_hip_ctx *ctx);

@@ -94,7 +94,6 @@ def test_reference_drivers_link_unchanged_against_the_library(tmp_path):
     libdir = os.path.join(ROOT, "htscodecs_amd")
     inc = tmp_path / "inc"
     (inc / "htscodecs").mkdir(parents=True)
-    (inc / "config.h").write_text("")
     (inc / "htscodecs" / "rANS_static4x16pr.c").write_text("/* the library under test provides these symbols */\n")
     (tmp_path / "fuzz_main.c").write_text(
         "#include <stdint.h>\n#include <stddef.h>\nint LLVMFuzzerTestOneInput(uint8_t *, size_t);\n"
@@ -131,6 +130,37 @@ def test_reference_drivers_link_unchanged_against_the_library(tmp_path):
         r = subprocess.run([exe["driver"], "-d", str(src), str(tmp_path / "out")], capture_output=True, text=True, timeout=120)
         assert r.returncode == 1, (r.returncode, r.stderr)           # fails the way the driver fails on NULL, no crash
         assert "no CPU path" in r.stderr
+
+
+def test_options_by_name_without_a_gpu():
+    """include/rans4x16_hip.h part 2b: options are set by name on a context, or - ctx == NULL - as the process-wide
+    defaults; the environment only seeds those defaults, once.  Pure host bookkeeping: checked without a GPU."""
+    import ctypes as C
+    L = htscodecs_amd.load()
+    names = []
+    while L.rans4x16_hip_option_name(len(names)):
+        names.append(L.rans4x16_hip_option_name(len(names)).decode())
+    assert len(names) == len(set(names)) >= 25
+    header = open(os.path.join(ROOT, "include", "rans4x16_hip.h")).read()
+    for n in names:
+        assert re.search(r"\b%s\b" % n, header), f"option {n} is not listed in include/rans4x16_hip.h"
+    v = C.c_long(-7)
+    for n in names:
+        assert L.rans4x16_hip_get_option(None, n.encode(), C.byref(v)) == 0
+    assert L.rans4x16_hip_get_option(None, b"dec_direct", C.byref(v)) == 0
+    before = v.value
+    assert L.rans4x16_hip_set_option(None, b"dec_direct", 5) == 0
+    assert L.rans4x16_hip_get_option(None, b"dec_direct", C.byref(v)) == 0 and v.value == 5
+    assert L.rans4x16_hip_set_option(None, b"dec_direct", before) == 0
+    assert L.rans4x16_hip_set_option(None, b"no_such_option", 1) == -1
+    assert L.rans4x16_hip_get_option(None, b"no_such_option", C.byref(v)) == -1
+    assert L.rans4x16_hip_set_option(None, None, 1) == -1
+    # the library reads the environment in exactly one place
+    n_getenv = 0
+    for fn in os.listdir(os.path.join(ROOT, "htscodecs_amd", "csrc")):
+        if fn.endswith((".hip", ".h")):
+            n_getenv += len(re.findall(r"\bgetenv\s*\(", open(os.path.join(ROOT, "htscodecs_amd", "csrc", fn)).read()))
+    assert n_getenv == 1, n_getenv
 
 
 def test_cpulist_parser_for_the_numa_feed():

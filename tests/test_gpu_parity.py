@@ -28,12 +28,12 @@ def H(request):
         pytest.skip("no GPU")
     import htscodecs_amd
     htscodecs_amd.load()
-    knobs = ("R4X16_DEC_DIRECT", "R4X16_ENC_DIRECT")
-    for k in knobs:
-        os.environ[k] = "1" if request.param == "short-step" else "0"
+    from conftest import _Options
+    o = _Options()
+    for k in ("dec_direct", "enc_direct"):
+        o.set(k, 1 if request.param == "short-step" else 0)
     yield htscodecs_amd
-    for k in knobs:
-        os.environ.pop(k, None)
+    o.restore()
 
 
 def _fixture(fn):
@@ -380,23 +380,23 @@ def test_alphabet_sizes_at_the_tree_depth_boundaries(H, oracle):
     assert not bad, bad
 
 
-def test_host_batch_pipeline_matches_single_pass(H, oracle, monkeypatch):
+def test_host_batch_pipeline_matches_single_pass(H, oracle, opts):
     """Large host batches go through the staged pipeline (pinned bounce buffers, copier threads, slabs on
     several lanes: r4x16_host.hip run_pipelined).  Force that route on a small batch with everything awkward
     in it: empty and tiny blocks, a block larger than a bounce buffer, per-block orders, blocks that must
     fail on decode - and require reference bytes and the same statuses as the single-pass route."""
-    monkeypatch.setenv("R4X16_HOST_PIPE_MB", "1")
-    monkeypatch.setenv("R4X16_HOST_SLAB_MIN_MB", "1")
-    monkeypatch.setenv("R4X16_HOST_THREADS", "5")
-    monkeypatch.setenv("R4X16_HOST_LANES", "3")
+    opts.set("host_pipe_mb", 1)
+    opts.set("host_slab_min_mb", 1)
+    opts.set("host_threads", 5)
+    opts.set("host_lanes", 3)
     rs = np.random.RandomState(4242)
     datas = _random_inputs(rs, 120, max_n=300000)
     datas += [b"", b"x", datagen.tile("q40+dir", 9 * (1 << 20) + 13, 3).tobytes(), b"", datagen.tile("q4", 1 << 20, 1).tobytes()]
     datas += _random_inputs(rs, 60, max_n=100000)
     orders = [int(rs.choice(sorted(DEVICE_ORDERS))) for _ in datas]
     want = [oracle.compress(d, o) for d, o in zip(datas, orders)]
-    for pack in ("1", "0"):                 # results gathered on the device / copied from their slots one by one
-        monkeypatch.setenv("R4X16_HOST_PACK", pack)
+    for pack in (1, 0):                     # results gathered on the device / copied from their slots one by one
+        opts.set("host_pack", pack)
         enc, st = H.compress_batch(datas, orders)
         bad = [(i, len(d), o) for i, (d, o, e, w) in enumerate(zip(datas, orders, enc, want)) if e != w]
         assert not bad, (pack, bad[:10])
@@ -410,7 +410,7 @@ def test_host_batch_pipeline_matches_single_pass(H, oracle, monkeypatch):
         b = bytearray(comps[i]); b[1] ^= 0x55; b = b[:len(b) // 2]; comps[i] = bytes(b)
     caps = [len(d) for d in datas]
     dec, st = H.uncompress_batch(comps, caps)
-    monkeypatch.setenv("R4X16_HOST_PIPE_MB", "0")
+    opts.set("host_pipe_mb", 0)
     dec1, st1 = H.uncompress_batch(comps, caps)
     assert list(st) == list(st1)
     assert dec == dec1

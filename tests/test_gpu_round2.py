@@ -25,12 +25,12 @@ def H(request):
         pytest.skip("no GPU")
     import htscodecs_amd
     htscodecs_amd.load()
-    knobs = ("R4X16_DEC_DIRECT", "R4X16_ENC_DIRECT")
-    for k in knobs:
-        os.environ[k] = "1" if request.param == "short-step" else "0"
+    from conftest import _Options
+    o = _Options()
+    for k in ("dec_direct", "enc_direct"):
+        o.set(k, 1 if request.param == "short-step" else 0)
     yield htscodecs_amd
-    for k in knobs:
-        os.environ.pop(k, None)
+    o.restore()
 
 
 ALL_ORDERS = [0, 1, 64, 65, 128, 129, 192, 193, 8, 9, 0x48, 0xc9, (2 << 8) | 9, 16 | 1, 32]
@@ -121,15 +121,18 @@ def test_arbitrary_bytes_through_the_malloc_entry(H, oracle):
 
 
 def test_oversized_block_in_a_device_batch_fails_alone(H, oracle):
-    """rans4x16_hip_compress_dev sizes its backward-write areas from max_in_size; a block larger than that must be
-    refused (UNSUPPORTED) without touching its neighbours' scratch (it used to write backwards past
-    the start of its slot)."""
+    """rans4x16_hip_compress_dev sizes its workspace from max_in_size (or total_in_size) - a caller may lie.  Since round 4
+    the payload is written into the caller's own bound-sized slot and nothing per block depends on max_in_size any more
+    for the plain orders: a block larger than announced simply encodes.  With X_PACK / X_RLE the staging regions are laid
+    out on the device from the real sizes inside an area sized from the announced ones: a block whose region would end
+    beyond it must be refused (UNSUPPORTED) and every other block must carry the reference's bytes (an
+    oversized block used to write backwards past the start of its scratch, into its neighbour's)."""
     import torch
     dc = H.DeviceCodec(0)
     dev = dc.dev
-    sizes = [20000, 20000, 90000, 20000, 20000, 20000]
-    blocks = [datagen.tile("q40+dir", s, i) for i, s in enumerate(sizes)]
-    for order in (1, 0):
+    sizes = [20000, 20000, 3000000, 20000, 20000, 20000]
+    blocks = [datagen.tile("q8", s, i) for i, s in enumerate(sizes)]
+    for order in (1, 0, 65, 193):
         in_off = np.cumsum([0] + [(s + 255) // 256 * 256 for s in sizes])[:-1].astype(np.int64)
         arena = np.zeros(int(in_off[-1]) + sizes[-1] + 256, dtype=np.uint8)
         for b, off in zip(blocks, in_off):
@@ -141,15 +144,22 @@ def test_oversized_block_in_a_device_batch_fails_alone(H, oracle):
         d_out = torch.zeros(int(out_off[-1]) + int(caps[-1]) + 256, dtype=torch.uint8, device=dev)
         d_osz = torch.zeros(len(sizes), dtype=torch.int32, device=dev)
         d_st = torch.full((len(sizes),), -1, dtype=torch.int32, device=dev)
-        # the caller lies: max_in_size = 20000 although block 2 has 90000 bytes
+        # the caller lies: max_in_size = 20000 although block 2 has three million bytes
         dc.compress(d_in, t(in_off), t(np.array(sizes, dtype=np.int32)), d_out, t(out_off), t(caps), d_osz, d_st,
                     order, 20000)
         torch.cuda.synchronize()
         st, osz, comp = d_st.cpu().numpy(), d_osz.cpu().numpy(), d_out.cpu().numpy()
-        assert st[2] == 6 and osz[2] == 0, st.tolist()
-        for i in (0, 1, 3, 4, 5):
-            assert st[i] == 0
-            assert comp[out_off[i]:out_off[i] + osz[i]].tobytes() == oracle.compress(blocks[i].tobytes(), order), (i, order)
+        if order in (0, 1):
+            assert st.tolist() == [0] * 6, (order, st.tolist())
+        else:
+            assert st[2] == 6 and osz[2] == 0, (order, st.tolist())          # 6 x 20,000 bytes announced: three million do not fit
+            assert st[0] == 0 and st[1] == 0, (order, st.tolist())
+        for i in range(6):
+            assert st[i] in (0, 6), (order, st.tolist())
+            if st[i] == 0:
+                assert comp[out_off[i]:out_off[i] + osz[i]].tobytes() == oracle.compress(blocks[i].tobytes(), order), (i, order)
+            else:
+                assert osz[i] == 0
 
 
 def test_multi_device_batch_calls(H, oracle):

@@ -70,13 +70,13 @@ def test_two_rounds_of_full_size_blocks_byte_compared(H, oracle):
     assert int(csz[0]) == 507704                             # the reference's size for this tile
 
 
-def test_direct_rows_walk_several_rounds(H, oracle, monkeypatch):
+def test_direct_rows_walk_several_rounds(H, oracle, opts):
     """The short-step ("direct", r4x16_common.h level 6) rows are meant for batches of at most one round of their
-    resident streams; R4X16_DEC_DIRECT=8 lets 2,100 q40 streams (1,024 are resident at four per CU) take them anyway,
+    resident streams; option dec_direct = 8 lets 2,100 q40 streams (1,024 are resident at four per CU) take them anyway,
     so that the persistent walk over several rounds is covered for this row kind too: every block round-trips, the
     streams are the oracle's."""
-    monkeypatch.setenv("R4X16_DEC_DIRECT", "8")
-    monkeypatch.setenv("R4X16_ENC_DIRECT", "8")
+    opts.set("dec_direct", 8)
+    opts.set("enc_direct", 8)
     nblk, bs, order = 2100, 65536, 1
     bench, d_in, d_comp, csz, slot = _dev_roundtrip(H, "q40+dir", nblk, bs, order)
     rs = np.random.RandomState(8)
@@ -86,14 +86,14 @@ def test_direct_rows_walk_several_rounds(H, oracle, monkeypatch):
         assert got == oracle.compress(raw.tobytes(), order), b
 
 
-@pytest.mark.parametrize("knob", ["1", "0"])
-def test_small_batches_of_every_shape_both_row_kinds(H, oracle, monkeypatch, knob):
+@pytest.mark.parametrize("knob", [1, 0])
+def test_small_batches_of_every_shape_both_row_kinds(H, oracle, opts, knob):
     """Batches far below one round of resident streams, with the short-step rows (knob 1, the default) and without:
     1, 3 and 64 blocks of 1 MiB and ragged sizes, q4 / q8 / q40, orders 0, 1, 65, 193, device-resident; the compressed
     bytes are the oracle's for every block and every block round-trips."""
     import torch
-    monkeypatch.setenv("R4X16_DEC_DIRECT", knob)
-    monkeypatch.setenv("R4X16_ENC_DIRECT", knob)
+    opts.set("dec_direct", knob)
+    opts.set("enc_direct", knob)
     dc = H.DeviceCodec(0)
     dev = dc.dev
     for nblk, sizes in ((1, [1 << 20]), (3, [1 << 20, 777777, 5]), (64, [65536, 40001, 3, 131072])):
@@ -131,7 +131,7 @@ def test_small_batches_of_every_shape_both_row_kinds(H, oracle, monkeypatch, kno
                 assert (dec[off:off + len(b)] == b).all(), (name, order, nblk)
 
 
-def test_direct_rows_alphabet_shapes(H, oracle, monkeypatch):
+def test_direct_rows_alphabet_shapes(H, oracle, opts):
     """The short-step rows' special cases, each against the oracle both ways through the batch calls (few blocks: the
     default budget gives every stream its direct rows):
       * many symbols ONE slot wide (a dominant symbol and a hundred rare ones): slot pairs shared by two symbols, ranks
@@ -161,9 +161,9 @@ def test_direct_rows_alphabet_shapes(H, oracle, monkeypatch):
     add(datagen.weighted(1 << 18, [100000, 50000] + [1] * 100, 3), both=False)
     add(datagen.tile("q40+dir", 100001, 3))
     add(datagen.tile("q8", 99999, 4))
-    for knob in ("1", "0"):
-        monkeypatch.setenv("R4X16_DEC_DIRECT", knob)
-        monkeypatch.setenv("R4X16_ENC_DIRECT", knob)
+    for knob in (1, 0):
+        opts.set("dec_direct", knob)
+        opts.set("enc_direct", knob)
         enc, st = H.compress_batch(datas, orders)
         assert all(s == 0 for s in st), st
         want = [oracle.compress(d, o) for d, o in zip(datas, orders)]
@@ -240,16 +240,16 @@ def _runs(rs, n_runs, lens, syms):
     return np.concatenate(out)
 
 
-@pytest.mark.parametrize("route", ["0", "99999"], ids=["one-wave", "workgroup"])
-def test_run_length_shapes(H, oracle, monkeypatch, route):
-    """X_RLE both ways against the oracle, through both expansion kernels (R4X16_BACK_WG_PER_CU picks per call):
+@pytest.mark.parametrize("route", [0, 99999], ids=["one-wave", "workgroup"])
+def test_run_length_shapes(H, oracle, opts, route):
+    """X_RLE both ways against the oracle, through both expansion kernels (option back_wg_per_cu picks per call):
       * run lengths around the varint sizes (127 / 128, 16,383 / 16,384, 2^21) and long stretches of two- and
         three-byte varints (the one-wave route decodes the run stream 60 bytes at a time with four bytes of history);
       * literal counts around the trip sizes (63 .. 65, 255 .. 257, 1,023 .. 1,025) and a run at the very end;
       * runs around 2^22 bytes (where a trip leaves its 32-bit sums for the plain route) and one of more than 2^24 in
         a 20 MiB block;
       * X_PACK in front (order 192 / 193) and quality-like data."""
-    monkeypatch.setenv("R4X16_BACK_WG_PER_CU", route)
+    opts.set("back_wg_per_cu", route)
     rs = np.random.RandomState(4242)
     datas, orders = [], []
     def add(a, os_=(64, 65)):

@@ -92,7 +92,38 @@ def single_call(size=1 << 20, name="q40+dir", order=1, reps=10):
             "compress_ms": round((t1 - t0) / reps * 1e3, 3), "uncompress_ms": round((t2 - t1) / reps * 1e3, 3)}
 
 
+def hetero(out_path, gib):
+    """Batches whose blocks differ in length, alphabet and order (bench.hetero_leg), with the scheduling of the chain
+    kernels switched on step by step: round 3's behaviour (arrival order, fixed stride, classes one after the other),
+    + length-sorted class lists, + claimed shares, + classes side by side - one JSON line each, the same library."""
+    out = open(out_path, "w") if out_path else None
+    dev = torch.device("cuda", 0)
+    steps = (("round 3: arrival order, fixed stride, classes in stream order", 0, 0, 0),
+             ("+ class lists sorted by length", 1, 0, 0),
+             ("+ shares claimed from a counter", 1, 1, 0),
+             ("+ classes side by side (device-written plan)", 1, 1, 1))
+    only = os.environ.get("HETERO_STEPS")
+    for what, so, cl, co in steps:
+        if only and "%d%d%d" % (so, cl, co) not in only.split(","):
+            continue
+        dc = H.DeviceCodec(0)
+        dc.set_option("sched_sort", so); dc.set_option("sched_claim", cl); dc.set_option("sched_concurrent", co)
+        if os.environ.get("MAX_WS_MB"):
+            dc.set_option("max_workspace_mb", int(os.environ["MAX_WS_MB"]))
+        r = bench.hetero_leg(torch, H, dc, dev, total_bytes=int(gib * (1 << 30)))
+        r.update({"scheduling": what, "sched_sort": so, "sched_claim": cl, "sched_concurrent": co, "GiB": gib})
+        line = json.dumps(r)
+        print(line, flush=True)
+        if out:
+            out.write(line + "\n"); out.flush()
+        del dc
+        torch.cuda.empty_cache()
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--hetero":
+        hetero(sys.argv[2] if len(sys.argv) > 2 else None, float(os.environ.get("HETERO_GIB", 16)))
+        sys.exit(0)
     out = open(sys.argv[1], "w") if len(sys.argv) > 1 else None
     dc = H.DeviceCodec(0)
 
