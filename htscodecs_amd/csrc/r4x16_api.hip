@@ -17,7 +17,8 @@ static const struct { const char *name, *env; long dflt; } OPT_TAB[OPT_COUNT] = 
     /* OPT_SCHED_SORT        */ {"sched_sort", "R4X16_SCHED_SORT", 1},
     /* OPT_SCHED_CLAIM       */ {"sched_claim", "R4X16_SCHED_CLAIM", 1},
     /* OPT_SCHED_CONCURRENT  */ {"sched_concurrent", "R4X16_SCHED_CONCURRENT", 1},
-    /* OPT_MAX_WS_MB         */ {"max_workspace_mb", "R4X16_MAX_WS_MB", 96 << 10},
+    /* OPT_SCHED_TRACE       */ {"sched_trace", "R4X16_SCHED_TRACE", 0},
+    /* OPT_MAX_WS_MB         */ {"max_workspace_mb", "R4X16_MAX_WS_MB", 160 << 10},
     /* OPT_HOST_STRIPE_DEV   */ {"host_stripe_dev", "R4X16_HOST_STRIPE_DEV", 1},
     /* OPT_HOST_PIPE_MB      */ {"host_pipe_mb", "R4X16_HOST_PIPE_MB", 64},
     /* OPT_HOST_THREADS      */ {"host_threads", "R4X16_HOST_THREADS", 8},
@@ -76,7 +77,7 @@ extern "C" int rans4x16_hip_set_option(rans4x16_hip_ctx *c, const char *name, lo
         return 0;
     }
     c->opts.v[i] = value;
-    if (i == OPT_MAX_WS_MB) c->max_ws = value > 0 ? (size_t)value << 20 : (size_t)96 << 30;
+    if (i == OPT_MAX_WS_MB) c->max_ws = value > 0 ? (size_t)value << 20 : (size_t)160 << 30;
     return 0;
 }
 // a consistent copy of the process-wide defaults (contexts at creation; the drop-in symbols' contexts at every call)
@@ -85,7 +86,7 @@ static void opts_snapshot(rans4x16_hip_ctx *c)
     const R4Opts *d = r4x16_opts_defaults();
     std::lock_guard<std::mutex> g(g_opts_mu);
     c->opts = *d;
-    c->max_ws = d->v[OPT_MAX_WS_MB] > 0 ? (size_t)d->v[OPT_MAX_WS_MB] << 20 : (size_t)96 << 30;
+    c->max_ws = d->v[OPT_MAX_WS_MB] > 0 ? (size_t)d->v[OPT_MAX_WS_MB] << 20 : (size_t)160 << 30;
 }
 extern "C" int rans4x16_hip_get_option(const rans4x16_hip_ctx *c, const char *name, long *value)
 {
@@ -137,7 +138,7 @@ extern "C" rans4x16_hip_ctx *rans4x16_hip_create(int device)
         return nullptr;
     }
     for (int w = 0; w < 2; w++)
-        if (hipHostMalloc((void **)&c->hint[w].work, CLS_MAX * sizeof(u64), hipHostMallocDefault) == hipSuccess) memset(c->hint[w].work, 0, CLS_MAX * sizeof(u64));
+        if (hipHostMalloc((void **)&c->hint[w].work, SCHED_HINT_BYTES, hipHostMallocDefault) == hipSuccess) memset(c->hint[w].work, 0, SCHED_HINT_BYTES);
         else c->hint[w].work = nullptr;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         c->stream = nullptr;
@@ -299,7 +300,7 @@ static void sched_layout(Carver &cv, size_t nitems, SchedWs *w)
     w->list = cv.take<u32>(nitems);
     w->cnt = cv.take<u32>(SCHED_CNT_WORDS);
     w->bins = cv.take<u32>(2 * SCHED_BINS);
-    w->work = cv.take<u64>(CLS_MAX);
+    w->work = cv.take<u64>(2 * CLS_MAX);
 }
 
 static void time_begin(rans4x16_hip_ctx *c, int which, hipStream_t s, TimedLaunch &t)

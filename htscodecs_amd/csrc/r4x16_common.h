@@ -329,7 +329,7 @@ struct SchedWs {
     u32 *list;       // [nitems]  item indices, by class, longest first
     u32 *cnt;        // [SCHED_CNT_WORDS]
     u32 *bins;       // [2 * SCHED_BINS]  per (class, bucket): count -> start, fill cursor
-    u64 *work;       // [CLS_MAX]  sum of chain lengths per class
+    u64 *work;       // [2 * CLS_MAX]  per class: sum of chain lengths, then the longest chain
 };
 // An order-1 block whose table is itself an order-0 stream (rANS_static4x16pr.c:944-955): k_dec_front<0> hands that
 // stream to the chain kernel as an item of its own and leaves what k_dec_front<1> needs to carry on from the decoded

@@ -1534,7 +1534,7 @@ __global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDes
     const u32 nsym = active ? I->nsym : 1u;
     const u32 img_bytes = active ? I->img_bytes : 0u;
     if (!wave_any(active)) continue;
-    sched_setprio(sched_prio_of(active, active ? I->out_sz : 0u));
+    sched_setprio(sched_prio_of(active, active ? I->out_sz : 0u, (u32)qpw * lds_per_item >= 32768u));
 
     // fields are read one by one (a register copy of the struct indexed by lane would spill)
     gcu8 *words = (gcu8 *)I->words;
@@ -2276,7 +2276,7 @@ __global__ __launch_bounds__(NT) void k_dec_back(BatchArgs a, DecWs ws, int base
 }
 
 // Where each block's staging region for the inverse transforms starts: blocks whose flag byte carries X_PACK or X_RLE
-// get dec_var_bytes(min(capacity, the caller's bound)), the others nothing; exclusive prefix sum by one workgroup.
+// get dec_var_bytes(min(capacity, the caller's bound)), the others nothing; r4x16_voff_scan makes offsets of the sizes.
 __device__ __forceinline__ u64 dec_var_of(const BatchArgs &a, int i, u32 max_out_cap)
 {
     if (!a.in_size[i]) return 0ull;
@@ -2285,31 +2285,20 @@ __device__ __forceinline__ u64 dec_var_of(const BatchArgs &a, int i, u32 max_out
     const u32 cap = a.out_cap[i];
     return dec_var_bytes(cap < max_out_cap ? cap : max_out_cap);
 }
-__global__ __launch_bounds__(1024) void k_dec_voff(BatchArgs a, int base, int nblk, u64 *voff, u32 max_out_cap)
+__global__ __launch_bounds__(256) void k_dec_vsize(BatchArgs a, int base, int nblk, u64 *voff, u32 max_out_cap)
 {
-    __shared__ u64 part[1024];
-    const u32 t = threadIdx.x;
-    const int per = (nblk + 1023) / 1024, lo = (int)t * per, hi = lo + per < nblk ? lo + per : nblk;
-    u64 sum = 0;
-    for (int b = lo; b < hi; b++) sum += dec_var_of(a, base + b, max_out_cap);
-    part[t] = sum;
-    __syncthreads();
-    for (u32 d = 1; d < 1024u; d <<= 1) {
-        const u64 add = t >= d ? part[t - d] : 0ull;
-        __syncthreads();
-        part[t] += add;
-        __syncthreads();
-    }
-    u64 at = part[t] - sum;
-    for (int b = lo; b < hi; b++) { voff[b] = at; at += dec_var_of(a, base + b, max_out_cap); }
-    if (t == 1023) voff[nblk] = part[1023];
+    const int b = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (b < nblk) voff[b] = dec_var_of(a, base + b, max_out_cap);
 }
 
 // ---- host-callable launchers (r4x16_api.hip) ---------------------------------------------------
 static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitems, bool one_row_only, hipStream_t s, const R4Fork *fk, const R4Opts *o, const SchedHint *hint);
 extern "C" void r4x16_launch_dec_front(const BatchArgs *a, const DecWs *ws, int base, int nblk, hipStream_t s, const R4Opts *o)
 {
-    if (ws->var) hipLaunchKernelGGL(k_dec_voff, dim3(1), dim3(1024), 0, s, *a, base, nblk, ws->voff, ws->max_out_cap);
+    if (ws->var) {
+        hipLaunchKernelGGL(k_dec_vsize, dim3((nblk + 255) / 256), dim3(256), 0, s, *a, base, nblk, ws->voff, ws->max_out_cap);
+        r4x16_voff_scan(ws->voff, nblk, s);
+    }
     hipLaunchKernelGGL(k_dec_front<0>, dim3(nblk), dim3(WAVE), 0, s, *a, *ws, base);
     launch_dec_chain_of(ws, ws->items + 2 * (size_t)nblk, nblk, true, s, nullptr, o, nullptr);        // nested order-1 tables
     hipLaunchKernelGGL(k_dec_front<1>, dim3(nblk), dim3(WAVE), 0, s, *a, *ws, base);
@@ -2408,8 +2397,8 @@ struct DecClassTab { u32 n; u32 split_o0; u32 sort; u32 bytes[CLS_MAX]; u32 lv[C
 __global__ __launch_bounds__(256) void k_dec_classify(const DecItem *items, int nitems, DecClassTab tab, SchedWs sw)
 {
     __shared__ u32 local[CLS_MAX];
-    __shared__ u64 lwork[CLS_MAX];
-    if (threadIdx.x < CLS_MAX) { local[threadIdx.x] = 0; lwork[threadIdx.x] = 0ull; }
+    __shared__ u64 lwork[2 * CLS_MAX];
+    if (threadIdx.x < CLS_MAX) { local[threadIdx.x] = 0; lwork[threadIdx.x] = 0ull; lwork[CLS_MAX + threadIdx.x] = 0ull; }
     __syncthreads();
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     u32 c = CLS_NONE, len = 0;
@@ -2425,7 +2414,7 @@ __global__ __launch_bounds__(256) void k_dec_classify(const DecItem *items, int 
     }
     sched_classify(sw, i, i < nitems, c, len, tab.sort != 0, local, lwork);
     __syncthreads();
-    if (threadIdx.x < CLS_MAX && local[threadIdx.x]) atomicAdd((unsigned long long *)&sw.work[threadIdx.x], (unsigned long long)lwork[threadIdx.x]);
+    sched_classify_flush(sw, local, lwork);
 }
 __global__ void k_cls_zero(u32 *count) { if (threadIdx.x < CLS_MAX) count[threadIdx.x] = 0; }
 __global__ void k_cls_scan(u32 *count)
@@ -2489,8 +2478,8 @@ static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitem
     tab.n = DEC_NCLS;
     tab.split_o0 = fk != nullptr;           // (launches in stream order: a wave takes both kinds, 4,096 x 1 MiB q8 with X_RLE 26.7 against 28.2 ms)
     tab.sort = o->v[OPT_SCHED_SORT] != 0;
-    plan.ncls = DEC_NCLS; plan.concurrent = nq > 1; plan.claim = o->v[OPT_SCHED_CLAIM] != 0; plan.pad = 0;
-    for (u32 ci = 0; ci < CLS_MAX; ci++) { plan.qpw[ci] = 16; plan.wgs_full[ci] = 0; plan.queue[ci] = 0xff; }
+    plan.ncls = DEC_NCLS; plan.concurrent = nq > 1 ? (u32)o->v[OPT_SCHED_CONCURRENT] : 0u; plan.claim = o->v[OPT_SCHED_CLAIM] != 0; plan.pad = 0;
+    for (u32 ci = 0; ci < CLS_MAX; ci++) { plan.qpw[ci] = 16; plan.wgs_full[ci] = 0; plan.queue[ci] = 0xff; plan.rate[ci] = 0.f; }
     for (u32 ci = 0; ci < DEC_NCLS; ci++) {
         const auto &c = DEC_CLASSES[ci];
         tab.bytes[ci] = c.bytes; tab.lv[ci] = (u32)c.lv;
@@ -2498,6 +2487,7 @@ static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitem
         const size_t ldsb = (size_t)qpw * c.bytes;
         plan.qpw[ci] = (u16)qpw;
         plan.wgs_full[ci] = (u16)(cu_count() * resident_per_cu(ldsb, 1));
+        plan.rate[ci] = sched_rate(qpw, 1, resident_per_cu(ldsb, 1), cu_count());
         // (an order-0 image: at most IMG_O0_BYTES; depth 4 only as the lone row of an alphabet beyond 150 symbols)
         const bool skip = (one_row_only && (c.lv == 1 || c.lv == 2 || (c.lv >= 5 && c.lv != 8) || c.bytes > (c.lv == 4 ? 22528u : IMG_O0_BYTES + RING_BYTES + 128u))) ||
                           ((c.lv == 6 || c.lv == 7) && !ws->direct_budget);      // (no stream of this batch was given direct blocks)
@@ -2508,10 +2498,11 @@ static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitem
         todo[ntodo++] = Launch{kern, r4x16_resident_grid(ldsb, 1, (nitems + qpw - 1) / qpw), qpw, ldsb, ci, c.bytes};
     }
     u8 qof[CLS_MAX];
+    int lorder[CLS_MAX];
     {
         int cls_of[CLS_MAX];
         for (int k = 0; k < ntodo; k++) cls_of[k] = (int)todo[k].ci;
-        sched_assign_queues(plan, cls_of, ntodo, nq, hint, qof);
+        sched_assign_queues(plan, cls_of, ntodo, nq, hint, qof, lorder, (hint && hint->work && o->v[OPT_SCHED_TRACE]) ? "decode" : nullptr);
         for (int k = 0; k < ntodo; k++) plan.queue[todo[k].ci] = qof[k];
     }
     r4x16_sched_zero(&ws->sched, s0);
@@ -2536,7 +2527,7 @@ static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitem
         r4x16_sched_launch((const void *)L.kern, dim3(L.grid), dim3(WAVE), args, L.ldsb, s);
     };
     if (fk) fk->begin(s0);
-    for (int k = 0; k < ntodo; k++) go(todo[k], fk ? fk->pick(s0, (unsigned)qof[k]) : s0);
+    for (int j = 0; j < ntodo; j++) { const int k = lorder[j]; go(todo[k], fk ? fk->pick(s0, (unsigned)qof[k]) : s0); }
     if (fk) { fk->end(s0); r4x16_sched_hint_save(&ws->sched, hint, s0); }
     if (one_row_only) return;                 // (such an image always fits a class)
     // images that fit no LDS class: tables stay in global memory (L2); after the join, in stream order

@@ -47,8 +47,8 @@ struct EncClassTab { u32 n; u32 sort; u32 bytes[CLS_MAX]; u32 pk[CLS_MAX]; };   
 __global__ __launch_bounds__(256) void k_enc_classify(const EncItem *items, int nitems, EncClassTab tab, SchedWs sw)
 {
     __shared__ u32 local[CLS_MAX];
-    __shared__ u64 lwork[CLS_MAX];
-    if (threadIdx.x < CLS_MAX) { local[threadIdx.x] = 0; lwork[threadIdx.x] = 0ull; }
+    __shared__ u64 lwork[2 * CLS_MAX];
+    if (threadIdx.x < CLS_MAX) { local[threadIdx.x] = 0; lwork[threadIdx.x] = 0ull; lwork[CLS_MAX + threadIdx.x] = 0ull; }
     __syncthreads();
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     u32 c = CLS_NONE, len = 0;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void k_enc_classify(const EncItem *items, int 
     }
     sched_classify(sw, i, i < nitems, c, len, tab.sort != 0, local, lwork);
     __syncthreads();
-    if (threadIdx.x < CLS_MAX && local[threadIdx.x]) atomicAdd((unsigned long long *)&sw.work[threadIdx.x], (unsigned long long)lwork[threadIdx.x]);
+    sched_classify_flush(sw, local, lwork);
 }
 // the shape of a class's launch: streams per workgroup, waves, streams per wave, LDS bytes
 struct EncShape { int qpw, waves, spw; size_t ldsb; u32 bytes; };
@@ -126,13 +126,14 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
     tab.n = 0;
     tab.sort = o->v[OPT_SCHED_SORT] != 0;
     SchedPlan plan;
-    plan.concurrent = nq > 1; plan.claim = o->v[OPT_SCHED_CLAIM] != 0; plan.pad = 0;
-    for (u32 ci = 0; ci < CLS_MAX; ci++) { plan.qpw[ci] = 16; plan.wgs_full[ci] = 0; plan.queue[ci] = 0xff; }
+    plan.concurrent = nq > 1 ? (u32)o->v[OPT_SCHED_CONCURRENT] : 0u; plan.claim = o->v[OPT_SCHED_CLAIM] != 0; plan.pad = 0;
+    for (u32 ci = 0; ci < CLS_MAX; ci++) { plan.qpw[ci] = 16; plan.wgs_full[ci] = 0; plan.queue[ci] = 0xff; plan.rate[ci] = 0.f; }
     const int cus = r4x16_cu_count();
     auto add = [&](u32 pk, u32 bytes, const EncShape &sh, const void *kern) {
         const u32 ci = tab.n++;
         tab.pk[ci] = pk; tab.bytes[ci] = bytes;
         plan.qpw[ci] = (u16)sh.qpw; plan.wgs_full[ci] = (u16)(cus * enc_wgs_per_cu(sh));
+        plan.rate[ci] = sched_rate(sh.qpw, sh.waves, enc_wgs_per_cu(sh), cus);
         if (!kern) return;
         todo[ntodo++] = Launch{kern, r4x16_resident_grid(sh.ldsb, sh.waves, (nitems + sh.qpw - 1) / sh.qpw), sh, ci};
     };
@@ -144,10 +145,11 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
     add(4, ENC_O0_REC_BYTES, enc_rec_shape(0, o, true), ws->direct_budget ? r4x16_enc_chain_rec_kernel() : nullptr);
     plan.ncls = tab.n;
     u8 qof[CLS_MAX];
+    int lorder[CLS_MAX];
     {
         int cls_of[CLS_MAX];
         for (int k = 0; k < ntodo; k++) cls_of[k] = (int)todo[k].ci;
-        sched_assign_queues(plan, cls_of, ntodo, nq, hint, qof);
+        sched_assign_queues(plan, cls_of, ntodo, nq, hint, qof, lorder, (hint && hint->work && o->v[OPT_SCHED_TRACE]) ? "encode" : nullptr);
         for (int k = 0; k < ntodo; k++) plan.queue[todo[k].ci] = qof[k];
     }
     r4x16_sched_zero(&ws->sched, s0);
@@ -171,7 +173,7 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
         r4x16_sched_launch(L.kern, dim3(L.grid), dim3(WAVE * L.sh.waves), args, L.sh.ldsb, s);
     };
     if (fk) fk->begin(s0);
-    for (int k = 0; k < ntodo; k++) go(todo[k], fk ? fk->pick(s0, (unsigned)qof[k]) : s0);
+    for (int j = 0; j < ntodo; j++) { const int k = lorder[j]; go(todo[k], fk ? fk->pick(s0, (unsigned)qof[k]) : s0); }
     if (fk) { fk->end(s0); r4x16_sched_hint_save(&ws->sched, hint, s0); }
     EncShape sh;
     sh.qpw = 16; sh.waves = 1; sh.spw = 16; sh.bytes = 0u; sh.ldsb = 0;

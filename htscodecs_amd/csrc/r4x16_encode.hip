@@ -13,6 +13,7 @@
 //                  header + table + payload into the caller's slot, writes size and status.
 #include <stdlib.h>
 #include "r4x16_dev.h"
+#include "r4x16_sched.h"
 #include "r4x16_enc_step.h"
 
 #define FRONT_DYN_LDS  36864u                           // LDS counters: alphabets up to 96 symbols (three workgroups per CU;
@@ -1675,33 +1676,22 @@ __global__ __launch_bounds__(FINISH_THREADS) void k_enc_finish(BatchArgs a, EncW
     }
 }
 
-// Where each block's staging region for the transforms starts (enc_var_layout): an exclusive prefix sum of the
-// regions' sizes over the chunk, by one workgroup - every thread a contiguous run of blocks.
-__global__ __launch_bounds__(1024) void k_enc_voff(BatchArgs a, int base, int nblk, u64 *voff)
+// The size of each block's staging region for the transforms (enc_var_layout); r4x16_voff_scan turns the sizes into
+// where the regions start.
+__global__ __launch_bounds__(256) void k_enc_vsize(BatchArgs a, int base, int nblk, u64 *voff)
 {
-    __shared__ u64 part[1024];
-    const u32 t = threadIdx.x;
-    const int per = (nblk + 1023) / 1024, lo = (int)t * per, hi = lo + per < nblk ? lo + per : nblk;
-    u64 sum = 0;
-    for (int b = lo; b < hi; b++) sum += enc_var_layout(a.in_size[base + b], a.d_order ? a.d_order[base + b] : a.order).total;
-    part[t] = sum;
-    __syncthreads();
-    for (u32 d = 1; d < 1024u; d <<= 1) {
-        const u64 add = t >= d ? part[t - d] : 0ull;
-        __syncthreads();
-        part[t] += add;
-        __syncthreads();
-    }
-    u64 at = part[t] - sum;
-    for (int b = lo; b < hi; b++) { voff[b] = at; at += enc_var_layout(a.in_size[base + b], a.d_order ? a.d_order[base + b] : a.order).total; }
-    if (t == 1023) voff[nblk] = part[1023];
+    const int b = (int)(blockIdx.x * 256u + threadIdx.x);
+    if (b < nblk) voff[b] = enc_var_layout(a.in_size[base + b], a.d_order ? a.d_order[base + b] : a.order).total;
 }
 
 // ---- host-callable launchers -------------------------------------------------------------------
 extern "C" bool r4x16_first_on_device(u32 bit);                                          // r4x16_decode.hip
 extern "C" void r4x16_launch_enc_front(const BatchArgs *a, const EncWs *ws, int base, int nblk, hipStream_t s, const R4Opts *o)
 {
-    if (ws->var) hipLaunchKernelGGL(k_enc_voff, dim3(1), dim3(1024), 0, s, *a, base, nblk, ws->voff);
+    if (ws->var) {
+        hipLaunchKernelGGL(k_enc_vsize, dim3((nblk + 255) / 256), dim3(256), 0, s, *a, base, nblk, ws->voff);
+        r4x16_voff_scan(ws->voff, nblk, s);
+    }
     // static + dynamic LDS exceeds the 64 KB default; gfx950 has 160 KB per CU
     if (r4x16_first_on_device(2u))
         (void)hipFuncSetAttribute((const void *)k_enc_front, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);

@@ -64,7 +64,7 @@ struct rans4x16_hip_ctx {
     // timing hook
     int timing = 0;
     std::vector<TimedLaunch> timed[2];
-    size_t max_ws = (size_t)96 << 30;       // ceiling for one chunk of blocks (plan_chunk also looks at free memory)
+    size_t max_ws = (size_t)160 << 30;       // ceiling for one chunk of blocks (plan_chunk also looks at free memory)
     // X_STRIPE in the device-resident calls (r4x16_stripe.hip): the arena of the internal items, and how many planes a
     // device-resident decode batch reserves per block (0: stripe blocks report UNSUPPORTED there)
     u8 *xs = nullptr;

@@ -24,9 +24,9 @@ struct SchedPlan {
     u32 ncls, concurrent, claim, pad;
     u16 qpw[CLS_MAX];
     u16 wgs_full[CLS_MAX];
+    float rate[CLS_MAX];     // streams' worth of progress a full chip of this class makes at once (sched_rate)
     u8  queue[CLS_MAX];      // the stream the class's launch goes out on (launches of one stream run one after the other); 0xff: not launched
 };
-static inline size_t sched_ws_words(size_t nitems) { return 2 * nitems + SCHED_CNT_WORDS + 2 * SCHED_BINS + 2 * CLS_MAX + 64; }
 
 #ifdef __HIPCC__
 __device__ __forceinline__ u32 sched_bucket(u32 len)
@@ -54,13 +54,25 @@ __device__ __forceinline__ u32 sched_wave_add(u32 *bins, u32 key, bool has)
     return pos;
 }
 // called by the classify kernels (every thread of the launch, `has` = the item runs): key, bin count, class work
+// (lds_cnt[CLS_MAX] and lds_work[2 * CLS_MAX] are the workgroup's own sums, flushed by sched_classify_flush)
 __device__ __forceinline__ void sched_classify(const SchedWs &w, int i, bool in_range, u32 cls, u32 len, bool sort, u32 *lds_cnt, u64 *lds_work)
 {
     const bool has = in_range && cls != CLS_NONE;
     const u32 key = has ? (cls << 8) | (sort ? 255u - sched_bucket(len) : 0u) : CLS_NONE;
     if (in_range) w.key[i] = key;
     (void)sched_wave_add(w.bins, has ? key : 0u, has);
-    if (has) { atomicAdd(&lds_cnt[cls], 1u); atomicAdd((unsigned long long *)&lds_work[cls], (unsigned long long)len); }
+    if (has) {
+        atomicAdd(&lds_cnt[cls], 1u);
+        atomicAdd((unsigned long long *)&lds_work[cls], (unsigned long long)len);
+        atomicMax((unsigned long long *)&lds_work[CLS_MAX + cls], (unsigned long long)len);
+    }
+}
+__device__ __forceinline__ void sched_classify_flush(const SchedWs &w, const u32 *lds_cnt, const u64 *lds_work)
+{
+    if (threadIdx.x < CLS_MAX && lds_cnt[threadIdx.x]) {
+        atomicAdd((unsigned long long *)&w.work[threadIdx.x], (unsigned long long)lds_work[threadIdx.x]);
+        atomicMax((unsigned long long *)&w.work[CLS_MAX + threadIdx.x], (unsigned long long)lds_work[CLS_MAX + threadIdx.x]);
+    }
 }
 // Wave priority by chain length.  Long and short streams share a SIMD (other workgroups of the class, other classes):
 // the issue arbiter serves the wave of higher priority first, so the streams that decide when the batch ends run at
@@ -73,9 +85,14 @@ __device__ __forceinline__ void sched_setprio(u32 p)
     else if (p == 1u) __builtin_amdgcn_s_setprio(1);
     else __builtin_amdgcn_s_setprio(0);
 }
-__device__ __forceinline__ u32 sched_prio_of(bool active, u32 len)
+// `heavy`: the wave stands for a large piece of the CU's LDS (a class of large images: one wave per 50 KB where the
+// smallest class has one per 10 KB).  Side by side the classes share a CU by LDS bytes, but its issue slots go to waves:
+// without a lift the class of large images gets a fifth of the slots for half of the LDS (its launch took 85 ms where
+// its share of the chip promised 37).
+__device__ __forceinline__ u32 sched_prio_of(bool active, u32 len, bool heavy = false)
 {
-    return wave_any(active && len >= (1u << 19)) ? 3u : wave_any(active && len >= (1u << 17)) ? 2u : wave_any(active && len >= (1u << 15)) ? 1u : 0u;
+    const u32 p = wave_any(active && len >= (1u << 19)) ? 2u : wave_any(active && len >= (1u << 16)) ? 1u : 0u;
+    return p + (heavy ? 1u : 0u);
 }
 // the walk of a workgroup over the shares of its class
 struct SchedWalk {
@@ -119,16 +136,36 @@ struct SchedWalk {
 };
 #endif
 
-// What the last batch of a context looked like, as a hint for the next one: the per-class work sums, copied to pinned
-// host memory behind the chain kernels (no synchronisation - the next call reads whatever has arrived).  The host deals
-// the class launches out over the streams with it: heaviest classes first, each to the stream with the least work so
-// far, so that two heavy classes do not queue up behind each other while other streams idle.  Without a hint (first
-// call) the launches are dealt out in turn.
-struct SchedHint { u64 *work; };                // pinned, [CLS_MAX]; nullptr: no hint kept
-void sched_assign_queues(const SchedPlan &plan, const int *todo_cls, int ntodo, int nq, const SchedHint *hint, u8 *queue_of_todo);
+// How fast a class runs on a full chip, in "streams at a lone wave's pace".  Resident streams are not it: a CU issues for
+// four waves at a time, and the fourteen 16-stream waves a CU holds of the smallest class each get a quarter of a SIMD's
+// slots, not a whole one (order-0 q40: 409 GB/s with 224 streams per CU against 239 GB/s for the packed rows' 45) -
+// further waves on a SIMD only fill the slots the others leave while they wait for LDS, about a quarter each.
+static inline float sched_rate(int qpw, int waves_per_wg, int wgs_per_cu, int cus)
+{
+    const float waves = (float)waves_per_wg * (float)wgs_per_cu;                  // per CU
+    const float per_wave = (float)qpw / (float)waves_per_wg;
+    const float eff = waves <= 4.f ? waves : 4.f * (1.f + 0.25f * (waves / 4.f - 1.f));
+    return per_wave * eff * (float)cus;
+}
+// What the last batch of a context looked like, as a hint for the next one: per class the sum of the chain lengths and
+// the longest chain, copied to pinned host memory behind the chain kernels (no synchronisation - the next call reads
+// whatever has arrived).  The host deals the class launches out over the streams with it.  The plan's shares make all
+// streams end together whatever the deal - except that a class cannot end before its longest chain has run, at a lone
+// wave's pace (1 MiB: ~50 ms to decode): two such classes behind each other on one stream are two such latencies.  So
+// the classes go out longest first - by max(longest chain, work per resident stream) - each to the stream with the
+// least so far.  Without a hint (first call) the launches are dealt out in turn.
+struct SchedHint { u64 *work; };                // pinned, [2 * CLS_MAX]: sums, then longest - and behind them the SCHED_CNT_WORDS
+                                                // dwords of SchedWs.cnt (counts, seats: for the trace); nullptr: no hint kept
+#define SCHED_HINT_BYTES (2 * CLS_MAX * sizeof(u64) + SCHED_CNT_WORDS * sizeof(u32))
+// launch_order: the order in which the launches should go out - the classes the last batch used first (an EMPTY class's
+// launch still has to get its workgroups through the dispatcher, which on a chip full of seated persistent workgroups
+// takes until LDS frees up: 18 ms were seen - anything queued behind it on its stream waits that long)
+void sched_assign_queues(const SchedPlan &plan, const int *todo_cls, int ntodo, int nq, const SchedHint *hint, u8 *queue_of_todo,
+                         int *launch_order, const char *trace = nullptr);
 
 extern "C" {
 void r4x16_sched_hint_save(const SchedWs *w, const SchedHint *hint, hipStream_t s);
+void r4x16_voff_scan(u64 *v, int n, hipStream_t s);
 void r4x16_sched_zero(const SchedWs *w, hipStream_t s);
 void r4x16_sched_group(const SchedWs *w, int nitems, const SchedPlan *plan, hipStream_t s);
 void r4x16_sched_launch(const void *kernel, dim3 grid, dim3 block, void **args, size_t lds, hipStream_t s);

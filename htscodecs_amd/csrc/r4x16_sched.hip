@@ -1,13 +1,14 @@
 // r4x16_sched.hip - the device-side grouping, ordering and launch plan of the chain kernels' streams (r4x16_sched.h).
 #include "r4x16_sched.h"
 #include <algorithm>
+#include <stdio.h>
 
 __global__ __launch_bounds__(256) void k_sched_zero(SchedWs w)
 {
     const u32 i = blockIdx.x * 256u + threadIdx.x;
     if (i < 2u * SCHED_BINS) w.bins[i] = 0u;
     if (i < SCHED_CNT_WORDS) w.cnt[i] = 0u;
-    if (i < CLS_MAX) w.work[i] = 0ull;
+    if (i < 2u * CLS_MAX) w.work[i] = 0ull;
 }
 
 // One workgroup: exclusive scan of the (class, bucket) bins -> where each bin's streams start in the list; per-class
@@ -47,11 +48,11 @@ __global__ __launch_bounds__(1024) void k_sched_scan(SchedWs w, SchedPlan plan)
     }
     if (t < CLS_MAX) { tq[t] = 0.f; fillq[t] = 0.f; }
     __syncthreads();
-    if (t == 0 && plan.concurrent) {
+    if (t == 0 && plan.concurrent == 1) {
         for (u32 c = 0; c < plan.ncls; c++) {
             const u32 n = w.cnt[SCHED_COUNT + c], q = plan.queue[c];
             if (!n || !plan.wgs_full[c] || q >= CLS_MAX) continue;
-            tq[q] += (float)w.work[c] / ((float)plan.qpw[c] * (float)plan.wgs_full[c]);
+            tq[q] += (float)w.work[c] / plan.rate[c];
             const float fill = (float)((n + plan.qpw[c] - 1u) / plan.qpw[c]) / (float)plan.wgs_full[c];
             if (fill > fillq[q]) fillq[q] = fill;
         }
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(1024) void k_sched_scan(SchedWs w, SchedPlan plan)
         const u32 qpw = t < plan.ncls ? plan.qpw[t] : 16u, full = t < plan.ncls ? plan.wgs_full[t] : 0u;
         const u32 q = t < plan.ncls ? plan.queue[t] : 0xffu;
         u32 seats = full ? full : 0xffffffffu;               // (classes the host gave no figures for: every workgroup works)
-        if (plan.concurrent && n && full && q < CLS_MAX) {
+        if (plan.concurrent == 1 && n && full && q < CLS_MAX) {
             float tot = 0.f, fills = 0.f;
             for (u32 c = 0; c < CLS_MAX; c++) { tot += tq[c]; fills += fillq[c]; }
             const u32 want = (n + qpw - 1u) / qpw;
@@ -102,31 +103,89 @@ extern "C" void r4x16_sched_launch(const void *kernel, dim3 grid, dim3 block, vo
     (void)hipLaunchKernel(kernel, grid, block, args, lds, s);
 }
 
-void sched_assign_queues(const SchedPlan &plan, const int *todo_cls, int ntodo, int nq, const SchedHint *hint, u8 *queue_of_todo)
+void sched_assign_queues(const SchedPlan &plan, const int *todo_cls, int ntodo, int nq, const SchedHint *hint, u8 *queue_of_todo,
+                         int *launch_order, const char *trace)
 {
-    double load[R4_FORK_STREAMS + 1] = {0};
-    double t[CLS_MAX];
+    double load[R4_FORK_STREAMS + 1] = {0}, floor_q[R4_FORK_STREAMS + 1] = {0};
+    double t[CLS_MAX], fl[CLS_MAX];
     int order[CLS_MAX];
     bool any = false;
+    double sum_t = 0.0, seq = 0.0;
     for (int k = 0; k < ntodo; k++) {
         const int c = todo_cls[k];
         const double w = hint && hint->work ? (double)hint->work[c] : 0.0;
-        t[k] = plan.wgs_full[c] ? w / ((double)plan.qpw[c] * plan.wgs_full[c]) : 0.0;
-        if (t[k] > 0.0) any = true;
+        fl[k] = hint && hint->work ? (double)hint->work[CLS_MAX + c] : 0.0;               // the longest chain: the class cannot end before it
+        t[k] = plan.wgs_full[c] && plan.rate[c] > 0.f ? w / (double)plan.rate[c] : 0.0;   // the class alone on the chip, throughput-bound
+        sum_t += t[k];
+        seq += fl[k] > t[k] ? fl[k] : t[k];
+        if (t[k] > 0.0 || fl[k] > 0.0) any = true;
         order[k] = k;
     }
+    for (int k = 0; k < ntodo; k++) launch_order[k] = k;
     if (nq <= 1 || !any) { for (int k = 0; k < ntodo; k++) queue_of_todo[k] = (u8)(nq > 1 ? k % nq : 0); return; }
-    std::stable_sort(order, order + ntodo, [&](int a, int b) { return t[a] > t[b]; });
+    auto key = [&](int k) { return fl[k] > t[k] ? fl[k] : t[k]; };
+    std::stable_sort(order, order + ntodo, [&](int a, int b) { return key(a) > key(b); });
     int rr = 0;
     for (int j = 0; j < ntodo; j++) {
         const int k = order[j];
+        launch_order[j] = k;                             // (sorted: the used classes come first, the longest first)
         int q = 0;
-        if (t[k] > 0.0) { for (int i = 1; i < nq; i++) if (load[i] < load[q]) q = i; load[q] += t[k]; }
+        if (key(k) > 0.0) { for (int i = 1; i < nq; i++) if (load[i] < load[q]) q = i; load[q] += key(k); floor_q[q] += fl[k]; }
         else q = rr++ % nq;                              // classes the last batch did not use: in turn
         queue_of_todo[k] = (u8)q;
+    }
+    // Side by side or one after the other?  Side by side hides the classes' chain latencies behind each other but costs
+    // throughput (workgroups of several sizes share a CU's LDS badly, the shares are estimates: 262,144 x 64 KiB mixed
+    // blocks took 30 % longer that way); one after the other every class has the chip to itself but pays its own
+    // longest chain.  With the last batch's figures both can be priced: whichever is shorter.
+    double conc = 1.3 * sum_t;
+    for (int i = 0; i < nq; i++) if (floor_q[i] > conc) conc = floor_q[i];
+    if (seq <= conc) for (int k = 0; k < ntodo; k++) queue_of_todo[k] = 0;
+    if (trace) {                                         // option sched_trace: what the LAST batch looked like, and this deal
+        const u32 *cnt = (const u32 *)(hint->work + 2 * CLS_MAX);
+        fprintf(stderr, "rans4x16_hip sched %s: last batch seq %.0f conc %.0f (sum_t %.0f) -> %s\n", trace, seq, conc, sum_t, seq <= conc ? "in stream order" : "side by side");
+        for (int k = 0; k < ntodo; k++) {
+            const int c = todo_cls[k];
+            if (t[k] > 0.0 || fl[k] > 0.0)
+                fprintf(stderr, "  class %2d qpw %2u full %4u rate %7.0f: streams %6u seats %4u work %12llu longest %8.0f t %9.0f -> stream %u\n", c, plan.qpw[c],
+                        plan.wgs_full[c], plan.rate[c], cnt[SCHED_COUNT + c], cnt[SCHED_SEATS + c], (unsigned long long)hint->work[c], fl[k], t[k], queue_of_todo[k]);
+        }
     }
 }
 extern "C" void r4x16_sched_hint_save(const SchedWs *w, const SchedHint *hint, hipStream_t s)
 {
-    if (hint && hint->work) (void)hipMemcpyAsync(hint->work, w->work, CLS_MAX * sizeof(u64), hipMemcpyDeviceToHost, s);
+    if (hint && hint->work) {
+        (void)hipMemcpyAsync(hint->work, w->work, 2 * CLS_MAX * sizeof(u64), hipMemcpyDeviceToHost, s);
+        (void)hipMemcpyAsync(hint->work + 2 * CLS_MAX, w->cnt, SCHED_CNT_WORDS * sizeof(u32), hipMemcpyDeviceToHost, s);
+    }
 }
+
+// Exclusive prefix sum, in place, of the n u64 entries of v (the sizes of the blocks' staging regions, written by a
+// kernel of the encoder / decoder); the total goes to v[n].  One workgroup, tiles of 1,024 entries with a carry.
+__global__ __launch_bounds__(1024) void k_voff_scan(u64 *v, int n)
+{
+    __shared__ u64 part[1024];
+    __shared__ u64 carry;
+    const u32 t = threadIdx.x;
+    if (t == 0) carry = 0ull;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + (int)t;
+        const u64 mine = i < n ? v[i] : 0ull;
+        part[t] = mine;
+        __syncthreads();
+        for (u32 d = 1; d < 1024u; d <<= 1) {
+            const u64 add = t >= d ? part[t - d] : 0ull;
+            __syncthreads();
+            part[t] += add;
+            __syncthreads();
+        }
+        const u64 c = carry;
+        if (i < n) v[i] = c + part[t] - mine;
+        __syncthreads();
+        if (t == 1023) carry = c + part[1023];
+        __syncthreads();
+    }
+    if (t == 0) v[n] = carry;
+}
+extern "C" void r4x16_voff_scan(u64 *v, int n, hipStream_t s) { hipLaunchKernelGGL(k_voff_scan, dim3(1), dim3(1024), 0, s, v, n); }

@@ -178,7 +178,8 @@ int rans4x16_hip_set_dev_stripe_planes(rans4x16_hip_ctx *ctx, int planes, unsign
  *   sched_claim           1     R4X16_SCHED_CLAIM        chain kernels: shares claimed from a counter (0: fixed stride)
  *   sched_concurrent      1     R4X16_SCHED_CONCURRENT   chain kernels: the classes of a batch side by side on six streams,
  *                                                        each with its share of the chip (0: one after the other)
- *   max_workspace_mb   98304    R4X16_MAX_WS_MB          ceiling of the device workspace; larger batches are walked in chunks
+ *   sched_trace           0     R4X16_SCHED_TRACE        the last batch's classes, and how this one's launches are dealt out, on stderr
+ *   max_workspace_mb  163840    R4X16_MAX_WS_MB          ceiling of the device workspace; larger batches are walked in chunks
  *   host_pipe_mb         64     R4X16_HOST_PIPE_MB       host batches of at least this many MiB (or 32 blocks) are pipelined
  *   host_threads          8     R4X16_HOST_THREADS       copier threads of the host pipeline
  *   host_lanes            2     R4X16_HOST_LANES         slabs of a host batch in flight at once

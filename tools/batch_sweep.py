@@ -107,7 +107,7 @@ def hetero(out_path, gib):
         if only and "%d%d%d" % (so, cl, co) not in only.split(","):
             continue
         dc = H.DeviceCodec(0)
-        dc.set_option("sched_sort", so); dc.set_option("sched_claim", cl); dc.set_option("sched_concurrent", co)
+        dc.set_option("sched_sort", so); dc.set_option("sched_claim", cl); dc.set_option("sched_concurrent", int(os.environ.get("CONC_MODE", 1)) if co else 0)
         if os.environ.get("MAX_WS_MB"):
             dc.set_option("max_workspace_mb", int(os.environ["MAX_WS_MB"]))
         r = bench.hetero_leg(torch, H, dc, dev, total_bytes=int(gib * (1 << 30)))
