@@ -9,8 +9,8 @@ with the serial per-block loop replaced by batch calls).
   value      MB/s (1e6 B/s) of UNCOMPRESSED bytes through encode+decode: batch bytes / (t_enc+t_dec)
   roofline   for the slowest kernel of the step: algorithmic bytes (uncompressed + compressed,
              SURVEY.md §8d) / its HIP-event time, against the 8 TB/s HBM peak
-  cpu_baseline  the reference C library (oracle/_ref, built from the untouched sources) — or the
-             oracle port when that .so is absent — timed on this host's cores on a bounded sample
+  cpu_baseline  the oracle (oracle/rans4x16_oracle.c: the scalar C restatement of the reference's algorithm, pinned by
+             the reference's fixtures) timed on this host's cores on a bounded sample - kind "port"
 
 Launch: python bench.py [--gpus N --steps K --warmup W].  N > 1: one rank per GPU, either started by
 torch.distributed.run (RANK / WORLD_SIZE / LOCAL_RANK in the environment) or - when those are absent - by
@@ -68,13 +68,10 @@ def block_bytes(name, blk_size, b, first_block=0):
 
 
 def cpu_baseline(order, blk_size, name, seconds_target=12.0):
-    """Time the CPU reference on a bounded sample of the same workload (rank 0, N=1 only)."""
+    """Time the CPU oracle (the scalar C port) on a bounded sample of the same workload (rank 0, N=1 only)."""
     import cpu_libs
     import datagen
-    lib = cpu_libs.reference()
-    kind = "reference"
-    if lib is None:
-        lib, kind = cpu_libs.oracle(), "port"
+    lib, kind = cpu_libs.oracle(), "port"
     # one GPU's share of the host is 16 cores on the bench pool; never oversubscribe beyond that
     cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("R4X16_CPU_THREADS", 16)))
     blocks = [block_bytes(name, blk_size, b) for b in range(cores)]
@@ -269,10 +266,16 @@ def configs4_leg(torch, H, dc, dev, dist, red_dev, shard, rank, world, steps=3, 
         step()
     barrier()
     elapsed = shard.max_over_ranks(dist, time.perf_counter() - t0, red_dev)
-    assert int((st_e != 0).sum()) == 0 and int((st_d != 0).sum()) == 0 and torch.equal(d_back, d_in), "configs[4] leg: round trip"
+    # gate: one more, untimed, step into CLEARED outputs (a step that silently wrote nothing must not pass on what the
+    # warm-up left behind)
+    d_back.zero_(); d_comp.zero_(); comp_size.zero_(); back_size.zero_(); st_e.fill_(-1); st_d.fill_(-1)
+    step()
+    torch.cuda.synchronize()
+    assert int((st_e != 0).sum()) == 0 and int((st_d != 0).sum()) == 0 and torch.equal(back_size, in_size) \
+        and torch.equal(d_back, d_in), "configs[4] leg: round trip"
     if rank == 0:
         import cpu_libs
-        chk = cpu_libs.reference() or cpu_libs.oracle()
+        chk = cpu_libs.oracle()
         csz = comp_size.cpu().numpy()
         rs = np.random.RandomState(11)
         for b in sorted(set([0, 1, 2, nblk - 1] + [int(x) for x in rs.randint(0, nblk, size=28)])):
@@ -339,11 +342,22 @@ def hetero_block(sizes, text, text_off, b):
     return np.ascontiguousarray(datagen.tile(HETERO_TEXTS[int(text[b])], int(sizes[b]), 0, offset=int(text_off[b])))
 
 
-def hetero_run(torch, H, dc, dev, total_bytes, uniform=None, reps=2, check=64, seed=2024, first_block=0):
+def hetero_run(torch, H, dc, dev, total_bytes, uniform=None, reps=2, check=64, seed=2024, first_block=0, part=None):
     """One heterogeneous (or comparison) batch through rans4x16_hip_{compress,uncompress}_dev with per-block orders:
     best-of-`reps` HIP-event times of each direction, every block round-tripped, `check` blocks byte-compared with
-    the CPU checker."""
-    sizes, orders, text = hetero_plan(total_bytes, seed=seed, uniform=uniform, first_block=first_block)
+    the CPU checker.  part = (rank, world): the plan is the whole job's (world x total_bytes), cut into contiguous ranges
+    of near-equal bytes by the library's own weighted partition (rans4x16_hip_partition); this rank runs its range."""
+    share = None
+    if part is not None and part[1] > 1:
+        from htscodecs_amd import shard
+        rank, world = part
+        sizes, orders, text = hetero_plan(total_bytes * world, seed=seed, uniform=uniform)
+        lo, hi = shard.contiguous_partition(sizes, world)[rank]
+        share = {"blocks": [int(lo), int(hi)], "bytes": int(sizes[lo:hi].sum()), "job_bytes": int(sizes.sum()),
+                 "share_over_mean": round(float(sizes[lo:hi].sum()) * world / float(sizes.sum()), 4)}
+        sizes, orders, text = sizes[lo:hi].copy(), orders[lo:hi].copy(), text[lo:hi].copy()
+    else:
+        sizes, orders, text = hetero_plan(total_bytes, seed=seed, uniform=uniform, first_block=first_block)
     n = len(sizes)
     d_in, in_off, in_size, text_off = hetero_batch(torch, dev, sizes, text)
     L = H.load()
@@ -398,16 +412,17 @@ def hetero_run(torch, H, dc, dev, total_bytes, uniform=None, reps=2, check=64, s
             "enc_ms": round(be, 3), "dec_ms": round(bd, 3),
             "enc_GBps": round(tot / be / 1e6, 2), "dec_GBps": round(tot / bd / 1e6, 2),
             "both_GBps": round(tot / (be + bd) / 1e6, 2), "ratio": round(float(csz.sum()) / tot, 4),
-            "roundtrip_ok": ok, "bytes_equal_cpu_blocks": same, "workspace_GB": round(dc.workspace_bytes() / 2**30, 2)}
+            "roundtrip_ok": ok, "bytes_equal_cpu_blocks": same, "workspace_GB": round(dc.workspace_bytes() / 2**30, 2),
+            **({"partition": share} if share else {})}
 
 
-def hetero_leg(torch, H, dc, dev, total_bytes=16 << 30, first_block=0):
+def hetero_leg(torch, H, dc, dev, total_bytes=16 << 30, first_block=0, part=None):
     """a batch whose blocks differ in length, alphabet and order, beside an equal-bytes, equal-mix
     batch of uniform 64 KiB blocks."""
-    het = hetero_run(torch, H, dc, dev, total_bytes, first_block=first_block)
+    het = hetero_run(torch, H, dc, dev, total_bytes, first_block=first_block, part=part)
     assert het["roundtrip_ok"], "hetero leg: round trip"
     torch.cuda.empty_cache()
-    uni = hetero_run(torch, H, dc, dev, total_bytes, uniform=65536, first_block=first_block)
+    uni = hetero_run(torch, H, dc, dev, total_bytes, uniform=65536, first_block=first_block, part=part)
     assert uni["roundtrip_ok"], "hetero leg (uniform 64 KiB): round trip"
     torch.cuda.empty_cache()
     return {"hetero": het, "uniform_64KiB": uni,
@@ -477,6 +492,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-host", action="store_true", help="skip the PCIe-inclusive host-buffer figure")
     ap.add_argument("--no-configs4", action="store_true", help="skip the mixed 64 KiB leg (BASELINE configs[4]'s shape)")
+    ap.add_argument("--no-hetero", action="store_true", help="skip the heterogeneous leg (blocks of any size, alphabet and order)")
+    ap.add_argument("--hetero-gib", type=float, default=16.0, help="bytes per GPU of the heterogeneous leg")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -574,7 +591,7 @@ def main():
     if rank == 0:
         import cpu_libs
         import datagen
-        chk = cpu_libs.reference() or cpu_libs.oracle()
+        chk = cpu_libs.oracle()
         res = max(1, dec_spc * cus)
         edges = [b for r in range(0, nblk, res) for b in (r, min(nblk, r + res) - 1)]
         rs = np.random.RandomState(7)
@@ -587,12 +604,13 @@ def main():
 
     # ---- one workgroup alone: the per-step latency of a full set of streams without neighbours on the chip.  The SAME
     # kernel as the full grid's, so the short-step routes that such a small batch would take by itself are switched
-    # off for these two calls (the library reads the knobs per call)
+    # off for these two calls (options of the context)
     probe = None
     if rank == 0:
         probe = {}
-        saved = {k: os.environ.get(k) for k in ("R4X16_DEC_DIRECT", "R4X16_ENC_DIRECT")}
-        os.environ["R4X16_DEC_DIRECT"] = os.environ["R4X16_ENC_DIRECT"] = "0"
+        saved = {k: dc.get_option(k) for k in ("dec_direct", "enc_direct")}
+        for k_ in saved:
+            dc.set_option(k_, 0)
         try:
             for which, spc, lanes in ((1, dec_spc, dec_lanes), (0, enc_spc, enc_lanes)):
                 k = lanes // 4 if which == 1 else spc          # decode: one wave per workgroup; encode: one workgroup per CU
@@ -609,11 +627,10 @@ def main():
                 probe[which] = (k, ms)
         finally:
             for k_, v_ in saved.items():
-                if v_ is None:
-                    os.environ.pop(k_, None)
-                else:
-                    os.environ[k_] = v_
+                dc.set_option(k_, v_)
 
+    ws_headline = dc.workspace_bytes()
+    per_rank_ms = [round(x / args.steps * 1e3, 3) for x in shard.gather_over_ranks(dist, elapsed, red_dev)]
     elapsed = shard.max_over_ranks(dist, elapsed, red_dev)
     c4 = None
     if not args.no_configs4:
@@ -621,6 +638,25 @@ def main():
         d_back = d_comp = None
         torch.cuda.empty_cache()
         c4 = configs4_leg(torch, H, dc, dev, dist, red_dev, shard, rank, world)
+    het = None
+    if not args.no_hetero:
+        # (the headline's arenas are gone by now: the leg needs ~70 GB of its own beside the workspace)
+        d_back = d_comp = None
+        d_in = in_off = in_size = comp_off = comp_cap = None
+        torch.cuda.empty_cache()
+        mine = hetero_leg(torch, H, dc, dev, total_bytes=int(args.hetero_gib * (1 << 30)), part=(rank, world))
+        if dist is not None:
+            dist.barrier()
+        # every rank's figure, in rank order: how evenly the weighted partition cut the job
+        per = {k: shard.gather_over_ranks(dist, mine["hetero"][k], red_dev) for k in ("enc_ms", "dec_ms", "bytes")}
+        het = dict(mine)
+        if world > 1:
+            tot = sum(per["bytes"])
+            het["per_rank"] = {"enc_ms": [round(x, 3) for x in per["enc_ms"]], "dec_ms": [round(x, 3) for x in per["dec_ms"]],
+                               "bytes": [int(x) for x in per["bytes"]],
+                               "max_share_over_mean": round(max(per["bytes"]) * world / tot, 4)}
+            het["job"] = {"bytes": int(tot), "enc_GBps": round(tot / max(per["enc_ms"]) / 1e6, 2),
+                          "dec_GBps": round(tot / max(per["dec_ms"]) / 1e6, 2)}
 
     if rank == 0:
         total_unc = nblk * bs * world
@@ -695,12 +731,15 @@ def main():
                          "note": "avg_kernel_ms = HIP-event time of the chain kernel per step; the kernel is launched "
                                  "once per LDS size class and all but one class exit in microseconds, so compare with "
                                  "rocprof's TotalDurationNs / steps (profiles/r03_final_working_launches.csv)"},
-            "workspace_GB": round(dc.workspace_bytes() / 2**30, 2),
+            "workspace_GB": round(ws_headline / 2**30, 2),
             "gate": {"roundtrip_blocks": nblk, "bytes_equal_cpu_blocks": gate_blocks,
                      "how": "untimed extra step into cleared outputs after the timed ones"},
         }
+        out["per_rank_ms_per_step"] = {"each": per_rank_ms, "min": min(per_rank_ms), "max": max(per_rank_ms)}
         if c4:
             out["configs4"] = c4
+        if het:
+            out["hetero"] = het
         if world == 1 and not args.no_host:
             # The host-buffer calls are measured as a C program would see them: through their own context, with the
             # benchmark's device-resident context (its 35 GB workspace, its arenas) released first - an idle context

@@ -3,7 +3,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librans4x16_hip.so")
+# R4X16_LIB: another build of the SAME library (tools/build_variant.sh -> htscodecs_amd/variants/lib<name>.so) for A/B
+# measurements; it must exist and export the whole ABI, there is no fallback either way.
+LIB_PATH = os.environ.get("R4X16_LIB") or os.path.join(_HERE, "librans4x16_hip.so")
 
 STATUS_NAMES = {0: "OK", 1: "CAPACITY", 2: "TRUNCATED", 3: "TABLE", 4: "STATE", 5: "SIZE",
                 6: "UNSUPPORTED", 7: "CONTEXT", 8: "RLE", 9: "EMPTY"}

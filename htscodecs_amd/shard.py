@@ -66,3 +66,15 @@ def gather_sizes(dist, local_sizes):
     out = [None] * dist.get_world_size()
     dist.all_gather_object(out, list(local_sizes))
     return [s for part in out for s in part]
+
+
+def gather_over_ranks(dist, value, device=None):
+    """Every rank's Python float, in rank order (a one-element list without a process group)."""
+    if dist is None:
+        return [float(value)]
+    import torch
+    world = dist.get_world_size()
+    mine = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]

@@ -7,13 +7,14 @@
  * can check the HIP path bit-for-bit.  The product library (htscodecs_amd/csrc) never
  * includes, links or calls anything in this directory.
  *
- * Parity pin: tests/test_oracle.py checks this restatement against all 24 committed
- * reference fixtures (tests/golden/r4x16/), the varint known-answer tables and the
- * generated edge vectors in tests/golden/edge/ (made by oracle/make_golden.py from the
- * real reference compiled into oracle/_ref).
+ * Parity pin: tests/test_oracle.py checks this restatement against all 24 reference-held
+ * fixtures (tests/golden/r4x16/ = tests/dat/r4x16/ of the reference: decode AND byte-identical
+ * re-encode) and the varint known-answer tables of tests/varint_test.c.  The reference itself
+ * is not built here (its sources need an autotools-generated config.h, oracle/Makefile); the
+ * generated edge vectors of tests/golden/edge.json carry THIS restatement's outputs and are
+ * regression vectors for the HIP path, not a second pin.
  *
- * Symbols carry an orc_ prefix so the oracle, the compiled reference and the product
- * library can live in one process.  Signatures mirror htscodecs/rANS_static4x16.h:41-50.
+ * Symbols carry an orc_ prefix so the oracle and the product library can live in one process.  Signatures mirror htscodecs/rANS_static4x16.h:41-50.
  */
 #ifndef RANS4X16_ORACLE_H
 #define RANS4X16_ORACLE_H

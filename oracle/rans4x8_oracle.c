@@ -8,8 +8,8 @@
  *
  * Parity pin: tests/test_oracle4x8.py checks it against the reference's eight fixtures
  * (tests/golden/r4x8/, byte-identical copies of the files under /root/reference/tests/dat/r4x8/: decode AND byte-identical
- * re-encode) and, where oracle/_ref/libref4x16.so is present, differentially against the real reference
- * (rans_compress / rans_uncompress compiled from the untouched rANS_static.c by `make -C oracle ref`).
+ * re-encode).  The reference itself is not built in this repository (its sources need an autotools-generated config.h,
+ * oracle/Makefile): the fixtures are the pin.
  *
  * Stream (rANS_static.c:196-214, :590-607):
  *   byte 0      order (0 / 1)

@@ -17,15 +17,6 @@ def oracle():
     return cpu_libs.oracle()
 
 
-@pytest.fixture(scope="session")
-def reference():
-    import cpu_libs
-    ref = cpu_libs.reference()
-    if ref is None:
-        pytest.skip("reference library oracle/_ref/libref4x16.so not available")
-    return ref
-
-
 class _Options:
     """Library options for the duration of a test (include/rans4x16_hip.h part 2b): set as the process-wide default -
     what the five drop-in symbols and contexts created from now on use - AND on the calling thread's context (the

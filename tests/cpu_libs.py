@@ -92,7 +92,6 @@ def _build(target):
 
 
 _oracle = None
-_ref = None
 
 
 def oracle():
@@ -108,17 +107,3 @@ def oracle():
         for name in ("orc_compress_many", "orc_uncompress_many"):
             getattr(lib, name).restype = C.c_int
     return _oracle
-
-
-def reference():
-    """The real reference compiled into oracle/_ref (None when not available, e.g. GPU box
-    without a prebuilt copy)."""
-    global _ref
-    if _ref is None:
-        so = os.path.join(ORACLE_DIR, "_ref", "libref4x16.so")
-        if not os.path.exists(so) and os.path.isdir("/root/reference/htscodecs"):
-            _build("ref")
-        if not os.path.exists(so):
-            return None
-        _ref = _Codec(so)
-    return _ref

@@ -1,6 +1,6 @@
 """rANS 4x8 (CRAM 3.0's codec): the oracle's restatement (oracle/rans4x8_oracle.c) pinned by the
 reference's own eight fixtures (tests/golden/r4x8/ = tests/dat/r4x8/ of the reference, what tests/rans4x8.test
-decodes) and, where oracle/_ref is built, differentially against the real rANS_static.c."""
+decodes): decode, and byte-identical re-encode."""
 import ctypes as C
 import os
 
@@ -50,14 +50,6 @@ def orc8():
     return Codec8(cpu_libs.oracle().lib, "orc8_")
 
 
-@pytest.fixture(scope="module")
-def ref8():
-    ref = cpu_libs.reference()
-    if ref is None or not hasattr(ref.lib, "rans_compress"):
-        pytest.skip("oracle/_ref/libref4x16.so (with rANS_static.c) not available")
-    return Codec8(ref.lib, "")
-
-
 @pytest.mark.parametrize("fn", FIXTURES)
 def test_fixture_decodes_and_reencodes_byte_identically(orc8, fn):
     name, order = fn.rsplit(".", 1)
@@ -89,23 +81,16 @@ def _inputs(rs, count):
     return out
 
 
-def test_encoder_matches_the_reference(orc8, ref8):
+def test_round_trips_and_damaged_streams_do_not_crash(orc8):
+    """Random inputs of every kind round-trip through the restatement; damaged streams and garbage of every small length
+    are refused or decoded, never crashed on (the sanitizer build runs the same cases: test_oracle_sanitized.py)."""
     rs = np.random.RandomState(48)
     for d in _inputs(rs, 250) + [b"a", b"ab", b"abc", b"abcd", b"abcde", bytes(range(256)) * 3,
                                  datagen.tile("q40+dir", 1 << 20, 3).tobytes()]:
         for order in (0, 1):
-            want = ref8.compress(d, order)
-            got = orc8.compress(d, order)
-            assert got == want, (len(d), order)
-            assert orc8.uncompress(want) == d and ref8.uncompress(got) == d
-
-
-def test_decoder_agrees_with_the_reference_on_damaged_streams(orc8, ref8):
-    """Whatever the restatement accepts, the reference decodes to the same bytes; the restatement additionally
-    refuses the inputs on which the reference's behaviour is undefined (see the header of rans4x8_oracle.c), so it
-    may reject what the reference lets through - never the other way round on what it accepts."""
+            comp = orc8.compress(d, order)
+            assert comp is not None and orc8.uncompress(comp) == d, (len(d), order)
     rs = np.random.RandomState(84)
-    both = stricter = 0
     for d in _inputs(rs, 120):
         comp = bytearray(orc8.compress(d, int(rs.randint(0, 2))))
         for _ in range(6):
@@ -119,14 +104,7 @@ def test_decoder_agrees_with_the_reference_on_damaged_streams(orc8, ref8):
                 bad[1:5] = int(len(bad) - 9).to_bytes(4, "little")          # keep the size field consistent
             else:
                 bad[int(rs.randint(9, len(bad)))] ^= 1 << int(rs.randint(0, 8))
-            got = orc8.uncompress(bytes(bad))
-            if got is None:
-                stricter += ref8.uncompress(bytes(bad)) is not None
-                continue
-            assert ref8.uncompress(bytes(bad)) == got
-            both += 1
-    assert both > 100
-    # garbage of every small length must not crash either
+            orc8.uncompress(bytes(bad))
     for n in (0, 1, 8, 9, 10, 25, 26, 27, 40, 300):
         for _ in range(30):
             junk = bytes(rs.randint(0, 256, size=n).astype(np.uint8))
