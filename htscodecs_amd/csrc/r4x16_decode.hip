@@ -2526,9 +2526,11 @@ static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitem
         void *args[] = {(void *)&items, (void *)&desc, (void *)&list, (void *)&cnt, (void *)&qpw, (void *)&bytes, (void *)&dyn_};
         r4x16_sched_launch((const void *)L.kern, dim3(L.grid), dim3(WAVE), args, L.ldsb, s);
     };
-    if (fk) fk->begin(s0);
+    unsigned used = 0;
+    for (int k = 0; k < ntodo; k++) used |= 1u << (qof[k] % (unsigned)nq);
+    if (fk) fk->begin(s0, used);
     for (int j = 0; j < ntodo; j++) { const int k = lorder[j]; go(todo[k], fk ? fk->pick(s0, (unsigned)qof[k]) : s0); }
-    if (fk) { fk->end(s0); r4x16_sched_hint_save(&ws->sched, hint, s0); }
+    if (fk) { fk->end(s0, used); r4x16_sched_hint_save(&ws->sched, hint, s0); }
     if (one_row_only) return;                 // (such an image always fits a class)
     // images that fit no LDS class: tables stay in global memory (L2); after the join, in stream order
     const int grid = (nitems + 15) / 16;

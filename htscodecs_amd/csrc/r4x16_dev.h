@@ -56,18 +56,20 @@ struct R4Fork {
     hipStream_t aux[R4_FORK_STREAMS];
     hipEvent_t ev[R4_FORK_STREAMS + 1];
     int n;                         // side streams in use (0: none)
-    // fork: the side streams wait for what `s` holds so far
-    void begin(hipStream_t s) const
+    // fork: the side streams in `mask` (bit j = stream j of pick(); bit 0, the caller's own, is ignored) wait for what
+    // `s` holds so far.  Only the streams a batch uses are forked and joined: an idle side stream still has to be
+    // scheduled by the firmware to pass an event on, and a join over all five cost a millisecond per call.
+    void begin(hipStream_t s, unsigned mask) const
     {
-        if (!n) return;
+        if (!n || !(mask >> 1)) return;
         (void)hipEventRecord(ev[0], s);
-        for (int i = 0; i < n; i++) (void)hipStreamWaitEvent(aux[i], ev[0], 0);
+        for (int i = 0; i < n; i++) if (mask & (2u << i)) (void)hipStreamWaitEvent(aux[i], ev[0], 0);
     }
     hipStream_t pick(hipStream_t s, unsigned k) const { const unsigned j = k % (unsigned)(n + 1); return j == 0 ? s : aux[j - 1]; }
-    // join: `s` waits for every side stream
-    void end(hipStream_t s) const
+    // join: `s` waits for every side stream in `mask`
+    void end(hipStream_t s, unsigned mask) const
     {
-        for (int i = 0; i < n; i++) { (void)hipEventRecord(ev[i + 1], aux[i]); (void)hipStreamWaitEvent(s, ev[i + 1], 0); }
+        for (int i = 0; i < n; i++) if (mask & (2u << i)) { (void)hipEventRecord(ev[i + 1], aux[i]); (void)hipStreamWaitEvent(s, ev[i + 1], 0); }
     }
 };
 

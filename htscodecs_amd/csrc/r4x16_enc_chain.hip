@@ -172,9 +172,11 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
         void *args[] = {(void *)&items, (void *)&rcptab, (void *)&dump, (void *)&list, (void *)&cnt, (void *)&qpw, (void *)&spw, (void *)&bytes, (void *)&dyn_};
         r4x16_sched_launch(L.kern, dim3(L.grid), dim3(WAVE * L.sh.waves), args, L.sh.ldsb, s);
     };
-    if (fk) fk->begin(s0);
+    unsigned used = 0;
+    for (int k = 0; k < ntodo; k++) used |= 1u << (qof[k] % (unsigned)nq);
+    if (fk) fk->begin(s0, used);
     for (int j = 0; j < ntodo; j++) { const int k = lorder[j]; go(todo[k], fk ? fk->pick(s0, (unsigned)qof[k]) : s0); }
-    if (fk) { fk->end(s0); r4x16_sched_hint_save(&ws->sched, hint, s0); }
+    if (fk) { fk->end(s0, used); r4x16_sched_hint_save(&ws->sched, hint, s0); }
     EncShape sh;
     sh.qpw = 16; sh.waves = 1; sh.spw = 16; sh.bytes = 0u; sh.ldsb = 0;
     go(Launch{(const void *)k_enc_chain<false, false>, (nitems + 15) / 16, sh, tab.n}, s0);     // images too large for LDS
