@@ -14,6 +14,7 @@ static const struct { const char *name, *env; long dflt; } OPT_TAB[OPT_COUNT] = 
     /* OPT_DEC_DIRECT        */ {"dec_direct", "R4X16_DEC_DIRECT", 1},
     /* OPT_ENC_DIRECT        */ {"enc_direct", "R4X16_ENC_DIRECT", 1},
     /* OPT_BACK_WG_PER_CU    */ {"back_wg_per_cu", "R4X16_BACK_WG_PER_CU", 0},
+    /* OPT_DEC_SHORT_RING    */ {"dec_short_ring", "R4X16_DEC_SHORT_RING", 0},
     /* OPT_SCHED_SORT        */ {"sched_sort", "R4X16_SCHED_SORT", 1},
     /* OPT_SCHED_CLAIM       */ {"sched_claim", "R4X16_SCHED_CLAIM", 1},
     /* OPT_SCHED_CONCURRENT  */ {"sched_concurrent", "R4X16_SCHED_CONCURRENT", 1},
@@ -517,7 +518,7 @@ extern "C" int rans4x16_hip_uncompress_dev_sized(rans4x16_hip_ctx *c, int n,
     return ws_order_end(c, s);
 }
 
-extern "C" int r4x16_dec_residency(u32 nsym, int order, u32 bits, int *streams_per_wave, int *waves_per_cu);
+extern "C" int r4x16_dec_residency(u32 nsym, int order, u32 bits, int *streams_per_wave, int *waves_per_cu, int short_ring);
 extern "C" int r4x16_enc_residency(u32 nsym, int order, int *streams_per_wave, int *waves_per_cu);
 extern "C" int r4x16_cu_count(void);
 
@@ -528,7 +529,7 @@ extern "C" int rans4x16_hip_residency(rans4x16_hip_ctx *c, int decode, unsigned 
     if (hipSetDevice(c->device) != hipSuccess) return -1;
     int spw = 0, wpc = 0, total = 0;
     if (decode) {
-        if (r4x16_dec_residency(nsym, order & 1, shift, &spw, &wpc) != 0) return -1;
+        if (r4x16_dec_residency(nsym, order & 1, shift, &spw, &wpc, c->opts.v[OPT_DEC_SHORT_RING] != 0) != 0) return -1;
         total = spw * wpc;
     } else {
         total = r4x16_enc_residency(nsym, order & 1, &spw, &wpc);

@@ -151,8 +151,17 @@ __device__ __forceinline__ u32 lookup_step_pk(u32 row, u32x2 rootv, u32x2 rootw,
         g = (r3 ? 3u : 2u) - gneg;
         ga = row + 4u + 16u * g;
     }
+#ifdef VAR_ORDER
+    // Issue order = reverse order of first use: the compiler writes an s_waitcnt per LDS result as it is first used
+    // (lgkmcnt counts down in issue order), and a lone wave pays four cycles for each.  With the dword that is used LAST
+    // requested FIRST, the wait for the first compare covers it too.
+    const u32 D4 = *(LAS const volatile u32 *)(unsigned long)(ga + 16u);
+    const u32x2 D01 = *(LAS const volatile u32x2_a4 *)(unsigned long)ga, D23 = *(LAS const volatile u32x2_a4 *)(unsigned long)(ga + 8u);
+    const u32 D0 = D01.x, D1 = D01.y, D2 = D23.x, D3 = D23.y;
+#else
     const u32 D0 = img0.ld32(ga), D1 = img0.ld32(ga + 4), D2 = img0.ld32(ga + 8), D3 = img0.ld32(ga + 12),
               D4 = img0.ld32(ga + 16);
+#endif
     // dword of three.  A leaf dword holds L[3i + 1], L[3i + 2] in its guarded low fields and L[3i] in its TOP field, so
     // the pivots L[12g + 3], L[12g + 6], L[12g + 9] are tested without extraction: top field < m  <=>  dword < m << 22.
     const u32 m22 = m << 22;
@@ -166,7 +175,7 @@ __device__ __forceinline__ u32 lookup_step_pk(u32 row, u32x2 rootv, u32x2 rootw,
     const u32 rneg = __popc((D + GM) & GB);                   // 2 - r,  r = #{L[3q + 1], L[3q + 2] below m}
     const u32 r11 = 22u - 11u * rneg;
     // the candidates in stride-11 order: P = L[3q], L[3q + 1], L[3q + 2];  C = L[3q + 1], L[3q + 2], L[3q + 3]
-    const u32 P = (D << 11) | (D >> 22);
+    const u32 P = (D << 11) | (D >> 22);                      // (not a rotation: bit 21 is a guard bit, the top field must land on bit 0)
     const u32 Cc = (D & 0x003fffffu) | (Dn & 0xffc00000u);    // (one v_bfi_b32)
     const u32 prev = __builtin_amdgcn_ubfe(P, r11, 10);       // L[c]: end of the symbol before (1023 stands for -1)
     const u32 cur = __builtin_amdgcn_ubfe(Cc, r11, 10);       // L[c + 1]: end of this symbol
@@ -175,7 +184,16 @@ __device__ __forceinline__ u32 lookup_step_pk(u32 row, u32x2 rootv, u32x2 rootw,
     const u32 off = (m + np) & 1023u;                         // m - start
     const u32 xs = x >> 10;
     x = __umul24(fm1, xs) + xs + off;                         // freq <= 1024, x >> 10 < 2^22: exact mod 2^32
+#ifndef VAR_NO_FIRST2
+    // `first` arrives with the + 2 already in it (the image stores first + 2): two multiply-adds and a subtraction
+    // instead of two multiplies, a three-way add, a subtraction and an add
+    u32 t;
+    asm("v_mad_u32_u24 %0, %1, 12, %2" : "=v"(t) : "v"(g), "v"(first));
+    asm("v_mad_u32_u24 %0, %1, 3, %2" : "=v"(t) : "v"(q), "v"(t));
+    return t - rneg;
+#else
     return first + 12u * g + 3u * q + 2u - rneg;
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -263,7 +281,13 @@ __device__ __forceinline__ u32 chain_decode(IMG img, u32 nsym, gcu8 *words, u32 
 
 typedef u32 GAS __attribute__((aligned(1))) gu32_unaligned;   // global dword store at any byte address
 
-template <int ORDER, int LV>
+// TRIP: steps per loop trip.  8 with the 256-byte ring of four 64-byte quarters (three live, one being refilled: a trip
+// moves the cursor by up to 64 bytes and reads 12 ahead).  4 with a 128-byte ring of TWO quarters, both live, the next
+// one waiting in registers: a trip then moves the cursor by at most 32 bytes, so from anywhere in quarter h it stays
+// inside h and h + 1, and the quarter just left is overwritten at once.  136 bytes less per stream: 46-symbol packed
+// rows at 3,360 bytes, 3 x 16 streams per CU instead of 3 x 15 - for one more loop test per eight steps.
+#define RING_BYTES_SHORT 136u
+template <int ORDER, int LV, int TRIP = TRIP_STEPS>
 __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 *ring, gcu8 *words, u32 words_len,
                                                 gu8 *out, u32 out_sz, u32 x, u32 look, bool active, u32 lane)
 {
@@ -276,6 +300,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     const u32 rows = lds_addr(img_lds) + img_alpha_bytes(nsym), roww = PKD ? pk_row_bytes(nsym) : img_row_bytes(nsym);
     const u32 nwords = words_len >> 1;
     const u32 below = (1u << k) - 1u;                      // quad lanes below this one
+    constexpr u32 NQ = TRIP == 8 ? 4u : 2u, RB = 64u * NQ; // quarters and bytes of the ring
     u32 count;
     gu8 *op;                                               // next output byte of this chain
     if (ORDER == 0) {
@@ -304,13 +329,13 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     // Quarters h, h+1, h+2 of the stream are in the ring while the cursor is in quarter h (a trip moves it
     // by at most 64 bytes and reads 12 bytes ahead); quarter h+3 waits in `pend` for the next crossing.
     if (active) {
-        const u32x4 c0 = load_chunk(k), c1 = load_chunk(k + 4), c2 = load_chunk(k + 8);
+        const u32x4 c0 = load_chunk(k), c1 = load_chunk(k + 4);
         *(u32x4 *)(ring + 16 * k) = c0;
         *(u32x4 *)(ring + 64 + 16 * k) = c1;
-        *(u32x4 *)(ring + 128 + 16 * k) = c2;
-        if (k == 0) *(u32x2 *)(ring + 256) = c0.xy;
+        if (NQ == 4) *(u32x4 *)(ring + 128 + 16 * k) = load_chunk(k + 8);
+        if (k == 0) *(u32x2 *)(ring + RB) = c0.xy;
     }
-    u32x4 pend = load_chunk(12 + k);
+    u32x4 pend = load_chunk((NQ == 4 ? 12 : 8) + k);
     u32 half = 0;                                         // index of the 64-byte quarter holding the cursor
     __syncthreads();
 
@@ -331,30 +356,40 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     auto trip = [&](auto fastc) {
         constexpr bool FAST = decltype(fastc)::value;
 #pragma unroll
-        for (int u = 0; u < TRIP_STEPS; u++) {
+        for (int u = 0; u < TRIP; u++) {
             const u32 T = t + (u32)u;                     // index of this step
             const bool live = FAST ? true : T < count;
             // next four candidate words (8 bytes at any byte alignment) from the ring; issued
             // before the table lookups so that their latency hides under them
             const u32 cb = off0 + 2 * cursor;
-            const u32 ra = cb & 252u;
+            const u32 ra = cb & (RB - 4u);
             // Three ALIGNED dwords and a funnel shift: a dword read at a misaligned LDS address costs far
             // more than the extra read (measured: +12 % on the whole kernel per misaligned read and step).
             // (volatile: keeps the compiler from sinking these reads into a branch, which would put their
             //  latency back on the dependent path; explicit LDS pointer: a volatile generic access goes FLAT)
+#ifdef VAR_ORDER
+            const u32 d2 = *(lvcu32 *)(ring + ra + 8);                         // (requested first, used last: see lookup_step_pk)
+            const u32x2 d01 = *(LAS const volatile u32x2_a4 *)(ring + ra);     // one ds_read2_b32
+            const u32 d0 = d01.x, d1 = d01.y;
+#else
             const u32x2 d01 = *(LAS const volatile u32x2_a4 *)(ring + ra);     // one ds_read2_b32
             const u32 d0 = d01.x, d1 = d01.y, d2 = *(lvcu32 *)(ring + ra + 8);
+#endif
 
             u32 xn = x;
             RootSpec spec;
             spec.rows = rows; spec.roww = roww;
             const bool speculate = ORDER == 1 && LV == 2;
             u32 s, rown1 = 0;
+            u32 hn_first = 0;
             u32x2 rootn1 = {0u, 0u}, rootn2 = {0u, 0u};
             if (PKD) {
                 s = lookup_step_pk<WIDE>(row, root, root2, hdr >> PK_FIRST_SHIFT, xn);
                 // the next row's root: requested as soon as the symbol is known, used at the top of the next step
                 asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(rown1) : "v"(s), "v"(roww), "v"(rows));   // (the compiler's own choice is a 64-bit multiply-add)
+#ifdef VAR_ORDER
+                hn_first = *(LAS const volatile u16 *)(unsigned long)(lds_addr(img_lds) + 2u * s);   // (before the root: the root is used first)
+#endif
                 if (WIDE) {
                     rootn1 = *(LAS const volatile u32x2_a4 *)(unsigned long)rown1;
                     rootn2 = *(LAS const volatile u32x2_a4 *)(unsigned long)(rown1 + 8u);
@@ -363,7 +398,11 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             } else {
                 s = lookup_step<(PKD ? 2 : LV)>(img0, row, look, mask, xn, LV == 2 ? &root : nullptr, speculate ? &spec : nullptr);
             }
+#ifdef VAR_ORDER
+            const u32 hn = PKD ? hn_first : img.ld16(2 * s);
+#else
             const u32 hn = img.ld16(2 * s);               // byte value | ROW_EMPTY of the new context
+#endif
             u32 byte0 = 0;
             if (ORDER == 0) {
                 byte0 = hn & 0xffu;
@@ -381,7 +420,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
                 // the L2 write each line to HBM 3.5 times over; see profiles/)
                 if ((u & 3) == 0 && T >= 4 && (FAST || T <= count)) {
                     a0 = a1; a1 = a2; a2 = a3; a3 = acc;
-                    if (u == 0 && (t & 15u) == 0 && active) {       // t is a multiple of TRIP_STEPS: T % 16 == 0 only at u == 0
+                    if (u == 0 && (t & 15u) == 0 && active) {       // t is a multiple of the trip: T % 16 == 0 only at u == 0
                         const u32x4 v = {a0, a1, a2, a3};
                         *(GAS u32x4_unaligned *)op = v;
                         op += 16;
@@ -453,10 +492,10 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
                 }
             }
         }
-        t += TRIP_STEPS;
+        t += TRIP;
     };
     while (wave_any(t < count)) {
-        const bool slow = active && (t + TRIP_STEPS > count || cursor + 4 * TRIP_STEPS > nwords);
+        const bool slow = active && (t + TRIP > count || cursor + 4 * TRIP > nwords);
         if (!wave_any(slow)) trip(std::true_type{});
         else trip(std::false_type{});
 
@@ -464,11 +503,11 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
         const u32 nh = (off0 + 2 * cursor) >> 6;
         if (wave_any(active && nh != half)) {
             if (active && nh != half) {                   // idle lanes hold garbage cursors: they must not write LDS
-                // quarter `nh+2` was requested at the previous crossing: park it in the slots just vacated
-                const u32 slot = ((nh + 2) & 3u) * 64u + 16u * k;
+                // the quarter in `pend` was requested at the previous crossing: park it in the slot just vacated
+                const u32 slot = (NQ == 4 ? ((nh + 2) & 3u) : ((nh + 1) & 1u)) * 64u + 16u * k;
                 *(u32x4 *)(ring + slot) = pend;
-                if (slot == 0) *(u32x2 *)(ring + 256) = pend.xy;
-                pend = load_chunk(4 * (nh + 3) + k);
+                if (slot == 0) *(u32x2 *)(ring + RB) = pend.xy;
+                pend = load_chunk(4 * (nh + (NQ == 4 ? 3 : 2)) + k);
                 half = nh;
             }
             __syncthreads();
@@ -1210,7 +1249,11 @@ __device__ void o1_tables(const u8 *in, ByteSrc &src, const u8 *tbuf, bool compr
         if (direct)
             write_row_direct(rows0 + (u64)ci * stride, S, nsym, S.empty != 0, look, lane, dir_used);
         else if (packed) {
+#ifndef VAR_NO_FIRST2
+            if (lane == 0) ((u16 *)img)[ci] |= (u16)(((S.empty ? 0u : S.first) + 2u) << PK_FIRST_SHIFT);     // (first + 2: lookup_step_pk)
+#else
             if (lane == 0 && !S.empty) ((u16 *)img)[ci] |= (u16)(S.first << PK_FIRST_SHIFT);
+#endif
             write_row_pk(rows0 + (u64)ci * stride, S, nsym, S.empty != 0, lane);
         } else
             write_row(rows0 + (u64)ci * stride, S, nsym, S.empty != 0, lane);
@@ -1511,7 +1554,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(PHASE ? 8 
 // (image + word ring) and every other wave exits at once.  LDS_IMG=false is the catch-all for
 // images too big for LDS (lo = largest class).
 // ---------------------------------------------------------------------------------------------
-template <bool LDS_IMG, int LV>
+template <bool LDS_IMG, int LV, int TRIP = TRIP_STEPS>
 __global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDesc *desc, const u32 *list, u32 *count,
                                                     int qpw, u32 lds_per_item, int dyn)
 {
@@ -1557,7 +1600,7 @@ __global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDes
         }
         __syncthreads();
         const u8 *im = lds + (u64)quad * lds_per_item;
-        u8 *ring = lds + (u64)quad * lds_per_item + (lds_per_item - RING_BYTES);
+        u8 *ring = lds + (u64)quad * lds_per_item + (lds_per_item - (TRIP == 8 ? RING_BYTES : RING_BYTES_SHORT));
         // order-0 and order-1 streams may share a wave: run the two loops back to back
         if constexpr (LV == 6) {
             // (affine alphabets - byte = index + c - skip the alpha[] read per symbol; a wave takes that body only if
@@ -1571,7 +1614,7 @@ __global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDes
                 bad |= chain_decode_dir<0, false>(im, nsym, ring, words, words_len, out, out_sz, x0, look, 0u, active && order == 0, lane);
             }
         } else {
-        bad = chain_decode_lds<1, LV>(im, nsym, ring, words, words_len, out, out_sz, x0, look, active && order == 1, lane);
+        bad = chain_decode_lds<1, LV, TRIP>(im, nsym, ring, words, words_len, out, out_sz, x0, look, active && order == 1, lane);
         if (LV != 1 && LV != 5)                               // packed rows exist for order-1 streams only
             bad |= chain_decode_lds<0, ((LV == 1 || LV == 5) ? 2 : LV)>(im, nsym, ring, words, words_len, out, out_sz, x0, look, active && order == 0, lane);
         }
@@ -2342,6 +2385,10 @@ static const struct { u32 bytes; int qpw; int lv; } DEC_CLASSES[] = {
     // holds both kinds - q4 / q8 order-1 tables are this small too - a wave of long streams of both kinds took twice
     // the chain latency (round 4's heterogeneous batch: the class of its 1 MiB streams 104 ms instead of 50).
     {656, 16, 8},
+    // packed rows of 43..46 symbols with the short ring (level 9 = level 1's rows, four-step trips: chain_decode_lds):
+    // 3,224 bytes of image + 136 of ring = 3,360, 16 x 3,360 = 42 LDS granules exactly - three workgroups of SIXTEEN
+    // streams per CU where the long ring allows fifteen
+    {3360, 16, 9},
 };
 // workgroups of `lds_bytes` each that one CU holds at once (1,280-byte LDS granules, 32 wave slots)
 static int resident_per_cu(size_t lds_bytes, int waves_per_wg)
@@ -2391,7 +2438,7 @@ extern "C" int r4x16_resident_grid(size_t lds_bytes, int waves_per_wg, int wante
 // ---- streams -> classes, on the device ---------------------------------------------------------
 // class ids: index into DEC_CLASSES, then one catch-all per tree depth (images too large for LDS)
 #define DEC_NCLS ((u32)(sizeof(DEC_CLASSES) / sizeof(DEC_CLASSES[0])))
-struct DecClassTab { u32 n; u32 split_o0; u32 sort; u32 bytes[CLS_MAX]; u32 lv[CLS_MAX]; };
+struct DecClassTab { u32 n; u32 split_o0; u32 sort; u32 short_ring; u32 bytes[CLS_MAX]; u32 lv[CLS_MAX]; };
 // class, length bucket and the class's work per item (r4x16_sched.h); per-class counts go through LDS first: a whole
 // batch is usually one class, and 30,000 atomics on one global word took 0.18 ms
 __global__ __launch_bounds__(256) void k_dec_classify(const DecItem *items, int nitems, DecClassTab tab, SchedWs sw)
@@ -2405,10 +2452,11 @@ __global__ __launch_bounds__(256) void k_dec_classify(const DecItem *items, int 
     if (i < nitems) {
         const DecItem *I = &items[i];
         if (I->active) {
-            const u32 need = I->img_bytes + RING_BYTES, lv0 = item_levels(I->nsym, I->packed), lv = (lv0 == 6u && I->order == 0 && tab.split_o0) ? 7u : (lv0 == 2u && I->order == 0) ? 8u : lv0;
+            const u32 need = I->img_bytes + RING_BYTES, lv0 = item_levels(I->nsym, I->packed), lv = (lv0 == 6u && I->order == 0 && tab.split_o0) ? 7u : (lv0 == 2u && I->order == 0) ? 8u :
+                                                                 (lv0 == 1u && tab.short_ring && need > 3344u && I->img_bytes + RING_BYTES_SHORT <= 3360u) ? 9u : lv0;
             c = tab.n + ((lv < 2u || lv > 4u) ? 0u : lv - 2u);  // catch-all of this depth (packed levels 1 and 5 always fit a class)
             for (u32 k = 0; k < tab.n; k++)
-                if (tab.lv[k] == lv && need <= tab.bytes[k]) { c = k; break; }   // classes of a depth ascend
+                if (tab.lv[k] == lv && (lv == 9u ? I->img_bytes + RING_BYTES_SHORT : need) <= tab.bytes[k]) { c = k; break; }   // classes of a depth ascend
             len = I->out_sz;
         }
     }
@@ -2478,6 +2526,7 @@ static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitem
     tab.n = DEC_NCLS;
     tab.split_o0 = fk != nullptr;           // (launches in stream order: a wave takes both kinds, 4,096 x 1 MiB q8 with X_RLE 26.7 against 28.2 ms)
     tab.sort = o->v[OPT_SCHED_SORT] != 0;
+    tab.short_ring = o->v[OPT_DEC_SHORT_RING] != 0;
     plan.ncls = DEC_NCLS; plan.concurrent = nq > 1 ? (u32)o->v[OPT_SCHED_CONCURRENT] : 0u; plan.claim = o->v[OPT_SCHED_CLAIM] != 0; plan.pad = 0;
     for (u32 ci = 0; ci < CLS_MAX; ci++) { plan.qpw[ci] = 16; plan.wgs_full[ci] = 0; plan.queue[ci] = 0xff; plan.rate[ci] = 0.f; }
     for (u32 ci = 0; ci < DEC_NCLS; ci++) {
@@ -2489,11 +2538,12 @@ static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitem
         plan.wgs_full[ci] = (u16)(cu_count() * resident_per_cu(ldsb, 1));
         plan.rate[ci] = sched_rate(qpw, 1, resident_per_cu(ldsb, 1), cu_count());
         // (an order-0 image: at most IMG_O0_BYTES; depth 4 only as the lone row of an alphabet beyond 150 symbols)
-        const bool skip = (one_row_only && (c.lv == 1 || c.lv == 2 || (c.lv >= 5 && c.lv != 8) || c.bytes > (c.lv == 4 ? 22528u : IMG_O0_BYTES + RING_BYTES + 128u))) ||
+        const bool skip = (c.lv == 9 && !tab.short_ring) ||
+                          (one_row_only && (c.lv == 1 || c.lv == 2 || (c.lv >= 5 && c.lv != 8) || c.bytes > (c.lv == 4 ? 22528u : IMG_O0_BYTES + RING_BYTES + 128u))) ||
                           ((c.lv == 6 || c.lv == 7) && !ws->direct_budget);      // (no stream of this batch was given direct blocks)
         if (skip) continue;
         chain_fn kern =
-            c.lv == 1 ? k_dec_chain<true, 1> : c.lv == 5 ? k_dec_chain<true, 5> : (c.lv == 2 || c.lv == 8) ? k_dec_chain<true, 2> : c.lv == 3 ? k_dec_chain<true, 3> :
+            c.lv == 9 ? k_dec_chain<true, 1, 4> : c.lv == 1 ? k_dec_chain<true, 1> : c.lv == 5 ? k_dec_chain<true, 5> : (c.lv == 2 || c.lv == 8) ? k_dec_chain<true, 2> : c.lv == 3 ? k_dec_chain<true, 3> :
             (c.lv == 6 || c.lv == 7) ? k_dec_chain<true, 6> : k_dec_chain<true, 4>;
         todo[ntodo++] = Launch{kern, r4x16_resident_grid(ldsb, 1, (nitems + qpw - 1) / qpw), qpw, ldsb, ci, c.bytes};
     }
@@ -2510,6 +2560,7 @@ static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitem
     r4x16_sched_group(&ws->sched, nitems, &plan, s0);
     if (r4x16_first_on_device(1u)) {
         lds_limit((const void *)k_dec_chain<true, 1>, 163840);
+        lds_limit((const void *)k_dec_chain<true, 1, 4>, 163840);
         lds_limit((const void *)k_dec_chain<true, 5>, 163840);
         lds_limit((const void *)k_dec_chain<true, 2>, 163840);
         lds_limit((const void *)k_dec_chain<true, 3>, 163840);
@@ -2554,12 +2605,14 @@ extern "C" u32 r4x16_dec_direct_budget(int nblk, const R4Opts *o)
     return best;
 }
 // Streams of one kind that a CU holds at once in the chain decoder (host arithmetic on the class table above).
-extern "C" int r4x16_dec_residency(u32 nsym, int order, u32 bits, int *streams_per_wave, int *waves_per_cu)
+extern "C" int r4x16_dec_residency(u32 nsym, int order, u32 bits, int *streams_per_wave, int *waves_per_cu, int short_ring)
 {
     if (nsym == 0 || nsym > 256) return -1;
     const bool packed = order == 1 && bits == 10 && nsym >= PK_MIN_NSYM && nsym <= PKW_MAX_NSYM;
-    const u32 lv = item_levels(nsym, packed ? 1u : 0u);
-    const u32 need = (packed ? pk_img_bytes(nsym) : img_bytes(nsym, order ? nsym : 1u)) + RING_BYTES;
+    u32 lv = packed ? item_levels(nsym, 1u) : (order == 0 && img_levels(nsym) == 2u) ? 8u : item_levels(nsym, 0u);
+    const u32 img = packed ? pk_img_bytes(nsym) : img_bytes(nsym, order ? nsym : 1u);
+    u32 need = img + RING_BYTES;
+    if (lv == 1u && short_ring && need > 3344u && img + RING_BYTES_SHORT <= 3360u) { lv = 9u; need = img + RING_BYTES_SHORT; }
     for (const auto &c : DEC_CLASSES) {
         if ((u32)c.lv != lv || need > c.bytes) continue;
         *streams_per_wave = c.qpw;

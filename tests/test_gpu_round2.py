@@ -237,7 +237,7 @@ def test_bench_launches_its_own_ranks():
     env = dict(os.environ, R4X16_OVERSUBSCRIBE="1")
     env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--blocks", "600",
-                        "--steps", "2", "--warmup", "1", "--no-cpu", "--no-host"],
+                        "--steps", "2", "--warmup", "1", "--no-cpu", "--no-host", "--hetero-gib", "0.25"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -245,6 +245,11 @@ def test_bench_launches_its_own_ranks():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["blocks_per_gpu"] == 600
     assert out["value"] > 0 and out["roofline"]["achieved"] > 0
+    # every rank's step time, and the heterogeneous leg cut by the library's weighted partition
+    assert len(out["per_rank_ms_per_step"]["each"]) == 2
+    het = out["hetero"]
+    assert het["hetero"]["roundtrip_ok"] and het["uniform_64KiB"]["roundtrip_ok"]
+    assert len(het["per_rank"]["bytes"]) == 2 and het["per_rank"]["max_share_over_mean"] <= 1.05
 
 
 def test_single_block_calls_from_a_thread_pool_are_combined(H, oracle):

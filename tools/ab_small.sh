@@ -3,9 +3,9 @@
 # chain kernels and whole passes.  Variants: htscodecs_amd/variants/lib<name>.so (see tools/ab_variants.sh).
 #   gpurun -- 'bash tools/ab_small.sh'        SHAPES overrides the block counts
 cd ${GRAFT_REPO_ROOT:-.}
-cp htscodecs_amd/librans4x16_hip.so /tmp/base.so
+
 for v in base $(ls htscodecs_amd/variants 2>/dev/null | sed "s/^lib//; s/\.so$//"); do
-  if [ $v = base ]; then cp /tmp/base.so htscodecs_amd/librans4x16_hip.so; else cp htscodecs_amd/variants/lib$v.so htscodecs_amd/librans4x16_hip.so; fi
+  if [ $v = base ]; then export R4X16_LIB=$PWD/htscodecs_amd/librans4x16_hip.so; else export R4X16_LIB=$PWD/htscodecs_amd/variants/lib$v.so; fi   # (htscodecs_amd/lib.py: the shipped library is never replaced)
   echo "== $v"
   SHAPES=${SHAPES:-1,1024} python3 tools/batch_sweep.py 2>&1 | python3 -c "
 import json,sys
@@ -16,4 +16,4 @@ for l in sys.stdin:
     else: print('  single call %7d: compress %.3f ms  uncompress %.3f ms' % (d['block_size'], d['compress_ms'], d['uncompress_ms']))
 "
 done
-cp /tmp/base.so htscodecs_amd/librans4x16_hip.so
+
