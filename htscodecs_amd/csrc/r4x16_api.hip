@@ -14,6 +14,7 @@ static const struct { const char *name, *env; long dflt; } OPT_TAB[OPT_COUNT] = 
     /* OPT_DEC_DIRECT        */ {"dec_direct", "R4X16_DEC_DIRECT", 1},
     /* OPT_ENC_DIRECT        */ {"enc_direct", "R4X16_ENC_DIRECT", 1},
     /* OPT_BACK_WG_PER_CU    */ {"back_wg_per_cu", "R4X16_BACK_WG_PER_CU", 0},
+    /* OPT_DEC_MID           */ {"dec_mid", "R4X16_DEC_MID", 0},
     /* OPT_DEC_SHORT_RING    */ {"dec_short_ring", "R4X16_DEC_SHORT_RING", 0},
     /* OPT_SCHED_SORT        */ {"sched_sort", "R4X16_SCHED_SORT", 1},
     /* OPT_SCHED_CLAIM       */ {"sched_claim", "R4X16_SCHED_CLAIM", 1},
@@ -441,7 +442,7 @@ static size_t dec_ws_layout(u8 *base, size_t nblk, u64 var_bytes, u32 max_out_ca
     w->pad2 = 0;
     sched_layout(cv, 2 * nblk, &w->sched);
     w->direct_budget = 0;
-    w->pad = 0;
+    w->mid_budget = 0;
     return align_up(cv.off, 256);
 }
 
@@ -506,6 +507,7 @@ extern "C" int rans4x16_hip_uncompress_dev_sized(rans4x16_hip_ctx *c, int n,
     for (size_t base = 0; base < (size_t)n; base += chunk) {
         const int nb = (int)((size_t)n - base < chunk ? (size_t)n - base : chunk);
         w.direct_budget = r4x16_dec_direct_budget(nb, &c->opts);       // few streams: LDS to spare, the short-step rows (r4x16_common.h)
+        w.mid_budget = r4x16_dec_mid_budget(nb, &c->opts);             // one partly filled round: the mid rows
         r4x16_launch_dec_front(&a, &w, (int)base, nb, s, &c->opts);
         const R4Fork *fk = (nb > 1 || max_out_cap >= FORK_ONE_BLOCK_BYTES) ? fork_for(c) : nullptr;   // (one large block: 28.2 -> 19.8 ms per MiB of q8 with X_RLE)
         TimedLaunch t;

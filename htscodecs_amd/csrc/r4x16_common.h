@@ -180,6 +180,26 @@ static inline __host__ __device__ u32 dir_fb_bytes(u32 n) { return 4u * (n + 1u)
 static inline __host__ __device__ u32 dir_blk_bytes(u32 n, u32 look) { return dir_fb_bytes(n) + (1u << (look - 1u)); }
 static inline __host__ __device__ u32 dir_img_bytes(u32 n, u32 rows, u32 look) { return img_alpha_bytes(n) + rows * dir_blk_bytes(n, look); }
 
+// ---------------------------------------------------------------------------------------------
+// Mid rows ("level 10", round 4): the short-ish step for batches of ONE partly filled round - more streams than the
+// direct rows' 32 KB images allow (four per CU), fewer than would fill the chip with packed rows (45 per CU), e.g. the
+// sixteen 1 MiB blocks per CU of a 4,096-block batch, which paid the packed rows' 453-cycle step with two thirds of the
+// LDS empty.  Order-1 streams with 10-bit tables, per context:
+//     idx[64] (u8)  one entry per bucket of sixteen slots: e = (owner of slot 16 j) & ~1, | 0x80 if the symbols that can
+//                   own a slot of the bucket do not all lie in cum[e .. e + 6] (more than a handful of symbols that
+//                   share sixteen slots: rare, takes a scan)
+//     cum[n + 10] (u16)  the cumulative starts themselves, cum[n] = 1024, 0x7fff beyond
+// A lookup is two dependent LDS reads like the direct rows' - the bucket's entry, then ONE 16-byte window cum[e .. e + 7],
+// whose entries <= m are counted without compares (the u16 rows' SWAR count) - at a quarter of their footprint:
+// 172 bytes per context for 46 symbols, 8.3 KB per stream with alphabet and word ring, sixteen streams per CU.
+// ---------------------------------------------------------------------------------------------
+#define MID_MIN_NSYM 13u
+#define MID_MAX_NSYM 64u
+#define MID_OVF 0x80u
+static inline __host__ __device__ u32 mid_cum_len(u32 n) { return (n + 10u) & ~1u; }          // u16 entries, even: rows stay 4-byte aligned
+static inline __host__ __device__ u32 mid_row_bytes(u32 n) { return 64u + 2u * mid_cum_len(n); }
+static inline __host__ __device__ u32 mid_img_bytes(u32 n) { return img_alpha_bytes(n) + n * mid_row_bytes(n); }
+
 #define IMG_O0_BYTES  1344u                       // 256 symbols, one row
 #define IMG_MAX_BYTES (512u + 256u * 824u)        // 256 symbols, 256 rows
 
@@ -197,12 +217,12 @@ struct DecItem {
     u32 active;      // 0 = nothing to do (failed block, CAT, empty)
     u32 blk;         // owning block (errors are reported there)
     u32 nsym;        // compact alphabet size n (decides the tree depth and the row size)
-    u32 packed;      // 0: u16 rows of img_levels(nsym) levels, 1: packed 10-bit rows (level 1 / 5), 2: direct rows (level 6)
+    u32 packed;      // 0: u16 rows of img_levels(nsym) levels, 1: packed 10-bit rows (level 1 / 5), 2: direct rows (level 6), 3: mid rows (level 10)
     u32 affine;      // direct rows: c + 1 when byte = compact index + c for every symbol with a frequency, else 0
 };
 static inline __host__ __device__ u32 item_levels(u32 nsym, u32 packed)
 {
-    return packed == 2u ? 6u : packed ? (nsym > PK_MAX_NSYM ? 5u : 1u) : img_levels(nsym);
+    return packed == 3u ? 10u : packed == 2u ? 6u : packed ? (nsym > PK_MAX_NSYM ? 5u : 1u) : img_levels(nsym);
 }
 
 // Per-block record of the decode pipeline.
@@ -353,7 +373,7 @@ struct DecWs {
     // workgroup gets a full set of streams of its class whatever the mix of blocks in the batch
     SchedWs sched;     // key / list: [2*nblk]  (the nested tables' pass uses the first nblk)
     u32 direct_budget; // LDS bytes a stream of this batch may take for direct rows (0: never); set per chunk by the host
-    u32 pad;
+    u32 mid_budget;    // the same for mid rows (level 10)
 };
 
 

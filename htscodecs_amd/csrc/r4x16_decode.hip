@@ -296,7 +296,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     const u32 k = lane & 3;
     const u32 mask = (1u << look) - 1;
     constexpr bool PKD = LV == 1 || LV == 5, WIDE = LV == 5;       // packed rows (r4x16_common.h), with the 16-byte root
-    static_assert(LV != 6, "direct blocks have their own loop: chain_decode_dir");
+    static_assert(LV != 6 && LV != 10, "direct blocks and mid rows have their own loops: chain_decode_dir, chain_decode_mid");
     const u32 rows = lds_addr(img_lds) + img_alpha_bytes(nsym), roww = PKD ? pk_row_bytes(nsym) : img_row_bytes(nsym);
     const u32 nwords = words_len >> 1;
     const u32 below = (1u << k) - 1u;                      // quad lanes below this one
@@ -884,6 +884,30 @@ __device__ void write_row_pk(u8 *rowp, const FrontShared &S, u32 n, bool empty, 
     }
 }
 
+// Whole wave: one mid row (r4x16_common.h, "level 10") from S.cum: lane j writes the entry of bucket j (slots 16 j ..
+// 16 j + 15), all lanes the cumulative array.  owner(m) = #{t in 1 .. n - 1 : cum[t] <= m}: cum is non-decreasing, so
+// this is the last symbol that starts at or below m, and among symbols of equal start the last one - the one with a
+// frequency.  An empty row (context without a table): every slot owned by symbol 0 with the whole range; the stream is
+// failed through the ROW_EMPTY flag of the context, as with the other row kinds.
+__device__ void write_row_mid(u8 *rowp, const FrontShared &S, u32 n, bool empty, u32 lane)
+{
+    u16 *cw = (u16 *)(rowp + 64);
+    const u32 len = mid_cum_len(n);
+    for (u32 t = lane; t < len; t += WAVE) cw[t] = empty ? (t == 0 ? (u16)0 : t == 1 ? (u16)1024 : (u16)0x7fffu) : (t <= n ? S.cum[t] : (u16)0x7fffu);
+    auto owner = [&](u32 m) -> u32 {
+        u32 c = 0;
+        for (u32 t = 1; t < n; t++) c += (u32)S.cum[t] <= m ? 1u : 0u;       // (n <= 64; S.cum is in LDS, the same address in every lane)
+        return c;
+    };
+    u32 e = 0;
+    if (!empty) {
+        const u32 lo = owner(16u * lane), hi = owner(16u * lane + 15u);
+        e = lo & ~1u;
+        if (hi > e + 6u) e |= MID_OVF;                    // cum[hi + 1] must still lie in the window cum[e .. e + 7]
+    }
+    rowp[lane] = (u8)e;
+}
+
 // Whole wave: one direct block (r4x16_common.h, "level 6") from S.cum: fb[] = the symbols that have a frequency, by
 // rank, tab[j] = rank of the owner of slot 2j.  Callers synchronise before (S.cum complete) and after.
 __device__ void write_row_direct(u8 *blkp, FrontShared &S, u32 n, bool empty, u32 look, u32 lane, u32 &used)
@@ -1085,7 +1109,7 @@ __device__ __forceinline__ bool row_parse_wave(WinSrc &win, u32 wlimit, u32 p, u
 // the input itself, or tbuf where the table came as a nested order-0 stream.  One wave.
 __device__ void o1_tables(const u8 *in, ByteSrc &src, const u8 *tbuf, bool compressed, u32 bits, u32 tab_pos, u32 usz, u32 after_table,
                           u32 pay_pos, u32 pay_len, u32 s1_size, u8 *img, DecDesc *D, DecItem *I0, FrontShared &S, i32 *hst, u32 lane,
-                          u32 dir_budget)
+                          u32 dir_budget, u32 mid_budget)
 {
     const u32 look = bits == 12 ? 12 : 10;                             // :1027, :1071
     ByteSrc tsrc(compressed ? tbuf : in);      // tbuf was never read by this CU before the fence above
@@ -1118,8 +1142,11 @@ __device__ void o1_tables(const u8 *in, ByteSrc &src, const u8 *tbuf, bool compr
     const bool direct = (bits == 10 || bits == 12) && nsym <= DIR_MAX_NSYM && dir_img_bytes(nsym, nsym, look) + RING_BYTES <= dir_budget &&
                         s1_size >= dir_img_bytes(nsym, nsym, look) / 4u;     // (a step per 16 bytes of image at least: see o0_front)
     u32 dir_used = 0;                                               // symbols (64 i + lane) that have a frequency in some row
-    const bool packed = !direct && bits == 10 && nsym >= PK_MIN_NSYM && nsym <= PKW_MAX_NSYM;
-    const u32 stride = direct ? dir_blk_bytes(nsym, look) : packed ? pk_row_bytes(nsym) : img_row_bytes(nsym);
+    // (the mid rows: a batch of one partly filled round - r4x16_common.h, level 10)
+    const bool mid = !direct && bits == 10 && nsym >= MID_MIN_NSYM && nsym <= MID_MAX_NSYM && mid_img_bytes(nsym) + RING_BYTES <= mid_budget &&
+                     s1_size >= mid_img_bytes(nsym) / 4u;
+    const bool packed = !direct && !mid && bits == 10 && nsym >= PK_MIN_NSYM && nsym <= PKW_MAX_NSYM;
+    const u32 stride = direct ? dir_blk_bytes(nsym, look) : mid ? mid_row_bytes(nsym) : packed ? pk_row_bytes(nsym) : img_row_bytes(nsym);
     u8 *rows0 = img + img_alpha_bytes(nsym);
 
     // Every row lists a frequency for each member of F0 (decode_freq_d :327-358): rank them once.
@@ -1248,6 +1275,8 @@ __device__ void o1_tables(const u8 *in, ByteSrc &src, const u8 *tbuf, bool compr
         }
         if (direct)
             write_row_direct(rows0 + (u64)ci * stride, S, nsym, S.empty != 0, look, lane, dir_used);
+        else if (mid)
+            write_row_mid(rows0 + (u64)ci * stride, S, nsym, S.empty != 0, lane);
         else if (packed) {
 #ifndef VAR_NO_FIRST2
             if (lane == 0) ((u16 *)img)[ci] |= (u16)(((S.empty ? 0u : S.first) + 2u) << PK_FIRST_SHIFT);     // (first + 2: lookup_step_pk)
@@ -1281,8 +1310,9 @@ __device__ void o1_tables(const u8 *in, ByteSrc &src, const u8 *tbuf, bool compr
             I0->words = (u64)(in + p);
             I0->words_len = end - p;
             I0->out = D->s1; I0->out_sz = s1_size; I0->image = (u64)img;
-            I0->img_bytes = direct ? dir_img_bytes(nsym, nsym, look) : packed ? pk_img_bytes(nsym) : img_bytes(nsym, nsym); I0->nsym = nsym;
-            I0->packed = direct ? 2u : packed ? 1u : 0u;
+            I0->img_bytes = direct ? dir_img_bytes(nsym, nsym, look) : mid ? mid_img_bytes(nsym) : packed ? pk_img_bytes(nsym) : img_bytes(nsym, nsym);
+            I0->nsym = nsym;
+            I0->packed = direct ? 2u : mid ? 3u : packed ? 1u : 0u;
             I0->affine = affine;
             I0->look = look; I0->order = 1;
             I0->active = s1_size != 0;
@@ -1323,7 +1353,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(PHASE ? 8 
         if (lane == 0) H.status = ST_OK;
         __syncthreads();
         o1_tables(in, src, tbuf, true, R.bits, 0u, R.usz, R.after_table, R.pay_pos, R.pay_len, R.s1_size, img, D, I0, S, &H.status, lane,
-                  ws.direct_budget);
+                  ws.direct_budget, ws.mid_budget);
         return;
     }
 
@@ -1544,7 +1574,165 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(PHASE ? 8 
         }
         return;
     }
-    o1_tables(in, src, tbuf, false, bits, H.tab_pos, 0u, 0u, pay_pos, pay_len, s1_size, img, D, I0, S, &H.status, lane, ws.direct_budget);
+    o1_tables(in, src, tbuf, false, bits, H.tab_pos, 0u, 0u, pay_pos, pay_len, s1_size, img, D, I0, S, &H.status, lane, ws.direct_budget, ws.mid_budget);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The chain decoder for mid rows (r4x16_common.h, "level 10"), order 1, 10-bit tables.  The same ring, renormalisation
+// and output gathering as chain_decode_dir, laid out around its two dependent LDS reads:
+//     x -> bucket (m >> 4) -> [read: e | overflow flag]     shadow: ring dwords, last step's byte
+//       -> window address  -> [read: cum[e .. e + 7]]         shadow: the candidate words out of the ring dwords
+//       -> count the entries <= m (SWAR, no compares), pick cum[s], cum[s + 1] out of the four dwords, state update
+// A bucket flagged MID_OVF (more symbols share its sixteen slots than the window holds) takes a scan instead.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 chain_decode_mid(const u8 *img_lds, u32 nsym, u8 *ring, gcu8 *words, u32 words_len,
+                                                gu8 *out, u32 out_sz, u32 x, bool active, u32 lane)
+{
+    const u32 imga = lds_addr(img_lds);
+    const u32 k = lane & 3;
+    const u32 rows = imga + img_alpha_bytes(nsym), roww = mid_row_bytes(nsym);
+    const u32 nwords = words_len >> 1;
+    const u32 below = (1u << k) - 1u;
+    const u32 ringa = lds_addr(ring);
+    const u32 q = out_sz >> 2;
+    u32 count = q + (k == 3 ? out_sz - 4 * q : 0);
+    gu8 *op = out + (u64)k * q;
+    if (!active) count = 0;
+
+    gcu8 *abase = (gcu8 *)((u64)words & ~15ull);
+    const u32 off0 = (u32)((u64)words & 15ull);
+    const u32 avail = off0 + words_len;
+    const u32 lastc = avail ? (avail - 1u) >> 4 : 0u;
+    const bool loadable = active && avail != 0;
+    auto load_chunk = [&](u32 c) -> u32x4 {
+        u32x4 v = {0, 0, 0, 0};
+        if (loadable) v = *(gcu32x4 *)(abase + 16ull * (c < lastc ? c : lastc));
+        return v;
+    };
+    if (active) {
+        const u32x4 c0 = load_chunk(k), c1 = load_chunk(k + 4), c2 = load_chunk(k + 8);
+        *(u32x4 *)(ring + 16 * k) = c0;
+        *(u32x4 *)(ring + 64 + 16 * k) = c1;
+        *(u32x4 *)(ring + 128 + 16 * k) = c2;
+        if (k == 0) *(u32x2 *)(ring + 256) = c0.xy;
+    }
+    u32x4 pend = load_chunk(12 + k);
+    u32 half = 0;
+    __syncthreads();
+
+    u32 row = rows, cursor = 0, bad = 0, t = 0;
+    u32 acc = 0, a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    u32 hdr = 0, hdr_even = 0;
+    if (count) bad = *(LAS const u16 *)(unsigned long)imga;
+
+    auto trip = [&](auto fastc) {
+        constexpr bool FAST = decltype(fastc)::value;
+#pragma unroll
+        for (int u = 0; u < TRIP_STEPS; u++) {
+            const u32 T = t + (u32)u;
+            const bool live = FAST ? true : T < count;
+            // (1) head of the dependent chain: the bucket's entry
+            const u32 m = x & 1023u;
+            const u32 ent = *(LAS const volatile u8 *)(unsigned long)(row + (m >> 4));
+            __builtin_amdgcn_sched_barrier(0);
+            // (2) in its shadow: the ring dwords, the last step's byte
+            const u32 cb = off0 + 2 * cursor;
+            const u32 ra = ringa + (cb & 252u);
+            const u32x2 d01 = *(LAS const volatile u32x2_a4 *)(unsigned long)ra;
+            const u32 d0 = d01.x, d1 = d01.y, d2 = *(LAS const volatile u32 *)(unsigned long)(ra + 8u);
+            const u32 mm = __umul24(m, 0x10001u) + 0x80008000u;       // m | m << 16 | flags: the u16 rows' compare-free count
+            const u32 xs = x >> 10;
+            if (u > 0 || t > 0) {
+                if (!FAST) bad |= live ? hdr : 0u;
+                else if (u & 1) bad |= hdr | hdr_even;
+                else hdr_even = hdr;
+                acc = (FAST || T <= count) ? __builtin_amdgcn_alignbit(hdr, acc, 8) : acc;
+            }
+            if ((u & 3) == 0 && T >= 4 && (FAST || T <= count)) {
+                a0 = a1; a1 = a2; a2 = a3; a3 = acc;
+                if (u == 0 && (t & 15u) == 0 && active) {
+                    const u32x4 v = {a0, a1, a2, a3};
+                    *(GAS u32x4_unaligned *)op = v;
+                    op += 16;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // (3) the window cum[e .. e + 7]
+            const u32 e = ent & 0x7eu;
+            const u32 wa = row + 64u + 2u * e;                        // (e is even: 4-byte aligned)
+            const u32x2 w01 = *(LAS const volatile u32x2_a4 *)(unsigned long)wa, w23 = *(LAS const volatile u32x2_a4 *)(unsigned long)(wa + 8u);
+            __builtin_amdgcn_sched_barrier(0);
+            // (4) in its shadow: the four candidate words
+            const u32 wlo = __builtin_amdgcn_alignbyte(d1, d0, cb), whi = __builtin_amdgcn_alignbyte(d2, d1, cb);
+            __builtin_amdgcn_sched_barrier(0);
+            // (5) s = e + #{window entries <= m} - 1; (cum[s], cum[s + 1]) out of the four dwords
+            u32 kk = count_le(mm, w01) + count_le(mm, w23) - 1u;      // 0 .. 6 (cum[e] <= m always)
+            const bool kb1 = (kk & 2u) != 0, kb2 = (kk & 4u) != 0;
+            const u32 A = kb1 ? w01.y : w01.x, B = kb1 ? w23.y : w23.x;
+            const u32 Wd = kb2 ? B : A;
+            const u32 A1 = kb1 ? w23.x : w01.y;
+            const u32 Wd1 = kb2 ? w23.y : A1;
+            u32 pair = __builtin_amdgcn_alignbyte(Wd1, Wd, (kk & 1u) << 1);      // cum[s] | cum[s + 1] << 16
+            u32 s = e + kk;
+            const bool ovf = active && (ent & MID_OVF) != 0u;          // (idle lanes run the full trips on whatever their LDS holds:
+            if (wave_any(ovf)) {                                      //  they must not scan it - and the scan is bounded anyway)
+                // the scan: from the bucket's first owner on, until the next symbol starts beyond m
+                if (ovf) {
+                    u32 sc = e;
+                    u32 c0 = *(LAS const u16 *)(unsigned long)(row + 64u + 2u * sc), c1 = *(LAS const u16 *)(unsigned long)(row + 64u + 2u * sc + 2u);
+                    while (c1 <= m && sc + 1u < nsym) { sc++; c0 = c1; c1 = *(LAS const u16 *)(unsigned long)(row + 64u + 2u * sc + 2u); }
+                    s = sc; pair = c0 | (c1 << 16);
+                }
+            }
+            const u32 start = pair & 0xffffu, next = pair >> 16;
+            const u32 xn = __umul24(next - start, xs) + (m - start);  // freq <= 1024, x >> 10 < 2^22: exact mod 2^32
+            u32 rown1;
+            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(rown1) : "v"(s), "v"(roww), "v"(rows));
+            const u32 hn = *(LAS const volatile u16 *)(unsigned long)(imga + 2u * s);      // byte | ROW_EMPTY: looked at in the next step
+            hdr = live ? hn : hdr;
+            row = live ? rown1 : row;
+            x = live ? xn : x;
+            // (6) renormalise: chains refill in order 0..3 from the shared cursor (see chain_decode_lds)
+            const bool want = live && x < RANS_LOW;
+            const u32 wm = quad_ballot(want, lane);
+            const u32 pre = __popc(wm & below);
+            const bool take = FAST ? want : (want && cursor + pre < nwords);
+            const u32 w = __builtin_amdgcn_perm(whi, wlo, __umul24(pre, 0x0202u) + 0x0c0c0100u);
+            u32 xr = (x << 16) | w;
+            asm volatile("" : "+v"(xr));
+            x = take ? xr : x;
+            cursor += __popc(wm);
+        }
+        t += TRIP_STEPS;
+    };
+    while (wave_any(t < count)) {
+        const bool slow = active && (t + TRIP_STEPS > count || cursor + 4 * TRIP_STEPS > nwords);
+        if (!wave_any(slow)) trip(std::true_type{});
+        else trip(std::false_type{});
+        const u32 nh = (off0 + 2 * cursor) >> 6;
+        if (wave_any(active && nh != half)) {
+            if (active && nh != half) {
+                const u32 slot = ((nh + 2) & 3u) * 64u + 16u * k;
+                *(u32x4 *)(ring + slot) = pend;
+                if (slot == 0) *(u32x2 *)(ring + 256) = pend.xy;
+                pend = load_chunk(4 * (nh + 3) + k);
+                half = nh;
+            }
+            __syncthreads();
+        }
+    }
+    if (count) {
+        // t steps ran (see chain_decode_lds): a chain whose count equals t still has its last byte in hdr
+        const u32 lastq = count < t - 4 ? count : t - 4;
+        const u32 pushed = lastq >> 2, nd = pushed & 3u;
+        if (count == t) acc = __builtin_amdgcn_alignbit(hdr, acc, 8);
+        if (nd == 3) { *(gu32_unaligned *)op = a1; op += 4; }
+        if (nd >= 2) { *(gu32_unaligned *)op = a2; op += 4; }
+        if (nd >= 1) { *(gu32_unaligned *)op = a3; op += 4; }
+        const u32 rem = count - 4 * pushed;
+        for (u32 jj = 0; jj < rem; jj++) op[jj] = (u8)(acc >> (8 * (4 - rem + jj)));
+    }
+    return active ? (bad & ROW_EMPTY) : 0u;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1602,7 +1790,9 @@ __global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDes
         const u8 *im = lds + (u64)quad * lds_per_item;
         u8 *ring = lds + (u64)quad * lds_per_item + (lds_per_item - (TRIP == 8 ? RING_BYTES : RING_BYTES_SHORT));
         // order-0 and order-1 streams may share a wave: run the two loops back to back
-        if constexpr (LV == 6) {
+        if constexpr (LV == 10) {
+            bad = chain_decode_mid(im, nsym, ring, words, words_len, out, out_sz, x0, active && order == 1, lane);
+        } else if constexpr (LV == 6) {
             // (affine alphabets - byte = index + c - skip the alpha[] read per symbol; a wave takes that body only if
             //  all its streams are affine)
             const u32 aff = active ? I->affine : 1u;
@@ -2389,6 +2579,10 @@ static const struct { u32 bytes; int qpw; int lv; } DEC_CLASSES[] = {
     // 3,224 bytes of image + 136 of ring = 3,360, 16 x 3,360 = 42 LDS granules exactly - three workgroups of SIXTEEN
     // streams per CU where the long ring allows fifteen
     {3360, 16, 9},
+    // mid rows (level 10; only batches of one partly filled round make such images, r4x16_dec_mid_budget): four streams
+    // per wave - the loop is two LDS round trips per step, few lanes per access - and four waves per CU, one per SIMD:
+    // sixteen streams of up to 48 symbols (8,816 bytes) per CU, 4,096 per chip
+    {8976, 4, 10},
 };
 // workgroups of `lds_bytes` each that one CU holds at once (1,280-byte LDS granules, 32 wave slots)
 static int resident_per_cu(size_t lds_bytes, int waves_per_wg)
@@ -2538,12 +2732,12 @@ static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitem
         plan.wgs_full[ci] = (u16)(cu_count() * resident_per_cu(ldsb, 1));
         plan.rate[ci] = sched_rate(qpw, 1, resident_per_cu(ldsb, 1), cu_count());
         // (an order-0 image: at most IMG_O0_BYTES; depth 4 only as the lone row of an alphabet beyond 150 symbols)
-        const bool skip = (c.lv == 9 && !tab.short_ring) ||
+        const bool skip = (c.lv == 9 && !tab.short_ring) || (c.lv == 10 && !ws->mid_budget) ||
                           (one_row_only && (c.lv == 1 || c.lv == 2 || (c.lv >= 5 && c.lv != 8) || c.bytes > (c.lv == 4 ? 22528u : IMG_O0_BYTES + RING_BYTES + 128u))) ||
                           ((c.lv == 6 || c.lv == 7) && !ws->direct_budget);      // (no stream of this batch was given direct blocks)
         if (skip) continue;
         chain_fn kern =
-            c.lv == 9 ? k_dec_chain<true, 1, 4> : c.lv == 1 ? k_dec_chain<true, 1> : c.lv == 5 ? k_dec_chain<true, 5> : (c.lv == 2 || c.lv == 8) ? k_dec_chain<true, 2> : c.lv == 3 ? k_dec_chain<true, 3> :
+            c.lv == 10 ? k_dec_chain<true, 10> : c.lv == 9 ? k_dec_chain<true, 1, 4> : c.lv == 1 ? k_dec_chain<true, 1> : c.lv == 5 ? k_dec_chain<true, 5> : (c.lv == 2 || c.lv == 8) ? k_dec_chain<true, 2> : c.lv == 3 ? k_dec_chain<true, 3> :
             (c.lv == 6 || c.lv == 7) ? k_dec_chain<true, 6> : k_dec_chain<true, 4>;
         todo[ntodo++] = Launch{kern, r4x16_resident_grid(ldsb, 1, (nitems + qpw - 1) / qpw), qpw, ldsb, ci, c.bytes};
     }
@@ -2561,6 +2755,7 @@ static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitem
     if (r4x16_first_on_device(1u)) {
         lds_limit((const void *)k_dec_chain<true, 1>, 163840);
         lds_limit((const void *)k_dec_chain<true, 1, 4>, 163840);
+        lds_limit((const void *)k_dec_chain<true, 10>, 163840);
         lds_limit((const void *)k_dec_chain<true, 5>, 163840);
         lds_limit((const void *)k_dec_chain<true, 2>, 163840);
         lds_limit((const void *)k_dec_chain<true, 3>, 163840);
@@ -2603,6 +2798,16 @@ extern "C" u32 r4x16_dec_direct_budget(int nblk, const R4Opts *o)
     for (const auto &c : DEC_CLASSES)
         if (c.lv == 6 && (long)resident_per_cu((size_t)c.qpw * c.bytes, 1) * c.qpw >= per_cu && c.bytes > best) best = c.bytes;
     return best;
+}
+// LDS bytes a stream may spend on mid rows (level 10): the mid class's, if `nblk` streams fit `dec_mid` rounds of it
+// (sixteen per CU), else 0.
+extern "C" u32 r4x16_dec_mid_budget(int nblk, const R4Opts *o)
+{
+    const long rounds = o->v[OPT_DEC_MID];
+    if (rounds <= 0 || nblk <= 0) return 0u;
+    for (const auto &c : DEC_CLASSES)
+        if (c.lv == 10 && (long)nblk <= rounds * cu_count() * resident_per_cu((size_t)c.qpw * c.bytes, 1) * c.qpw) return c.bytes;
+    return 0u;
 }
 // Streams of one kind that a CU holds at once in the chain decoder (host arithmetic on the class table above).
 extern "C" int r4x16_dec_residency(u32 nsym, int order, u32 bits, int *streams_per_wave, int *waves_per_cu, int short_ring)

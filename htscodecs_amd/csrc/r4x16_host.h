@@ -30,6 +30,7 @@ void r4x16_launch_enc_chain(const EncWs *, int, hipStream_t, const R4Fork *, con
 void r4x16_launch_enc_finish(const BatchArgs *, const EncWs *, int, int, hipStream_t);
 u32  r4x16_compress_bound(u32 size, int order);
 u32  r4x16_dec_direct_budget(int nblk, const R4Opts *);
+u32  r4x16_dec_mid_budget(int nblk, const R4Opts *);
 u32  r4x16_enc_direct_budget(int nblk, const R4Opts *);
 void r4x16_launch_stripe(const u8 *, u8 *, u32, u32, int, hipStream_t);
 }

@@ -174,6 +174,9 @@ int rans4x16_hip_set_dev_stripe_planes(rans4x16_hip_ctx *ctx, int planes, unsign
  *   enc_direct            1     R4X16_ENC_DIRECT         encode: the same for symbol records
  *   back_wg_per_cu        0     R4X16_BACK_WG_PER_CU     decode: run-length expansion by a workgroup per block up to N
  *                                                        blocks per compute unit (0: always one wave per block)
+ *   dec_mid               0     R4X16_DEC_MID            decode: mid rows (bucket index + one 16-byte window of cumulative values) for
+ *                                                        batches of up to N rounds of sixteen streams per compute unit; 0 = never
+ *                                                        (built and measured in round 4, slower than the packed rows on quality data: off)
  *   dec_short_ring        0     R4X16_DEC_SHORT_RING     decode: packed rows of 43..46 symbols with a 128-byte word ring and four-step trips,
  *                                                        sixteen streams per wave instead of fifteen (48 per compute unit)
  *   sched_sort            1     R4X16_SCHED_SORT         chain kernels: streams of a class ordered by length, longest first

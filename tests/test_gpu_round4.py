@@ -200,3 +200,47 @@ def test_options_on_a_context(H):
         dc.set_option(name, before)
     with pytest.raises(KeyError):
         dc.set_option("no_such_option", 1)
+
+
+def test_mid_rows_alphabet_shapes_and_overflow_buckets(H, oracle):
+    """The mid rows (r4x16_common.h level 10: a bucket index per sixteen slots + one 16-byte window of cumulative values)
+    serve order-1 streams with 10-bit tables of 13 .. 64 symbols in batches of one partly filled round.  With the direct
+    rows switched off and dec_mid = 8 a batch of 2,300 blocks takes them over several rounds of the class: alphabets at
+    the boundaries (12 / 13 / 48 / 49 / 64 / 65 symbols: the neighbours keep their own row kinds), many symbols of
+    frequency 1 next to each other (buckets that overflow the window: the scan), contexts without a table row (damaged
+    streams are covered by the fuzz tests), quality data, ragged sizes.  Device-resident, every block the oracle's."""
+    import torch
+    rs = np.random.RandomState(1010)
+    blocks = []
+    for ns in (12, 13, 14, 20, 31, 32, 33, 47, 48, 49, 63, 64, 65, 80):
+        blocks.append(datagen.rand(30000 + ns, ns, ns, 33))                                   # flat: every symbol ~1024 / ns slots
+        blocks.append(datagen.weighted(40001, [3000] + [1] * (ns - 1), ns + 1))               # one heavy symbol, the rest at frequency 1-2
+        blocks.append(datagen.weighted(50003, [500, 400, 300] + [2] * (ns - 3), ns + 2))
+        blocks.append((datagen.weighted(20000, [9] * ns, ns + 3).astype(np.int32) * 3 + 5).astype(np.uint8))     # gaps in the alphabet
+    while len(blocks) < 2300:
+        n = int(rs.choice([3000, 9000, 65536, 70001, 150000]))
+        blocks.append(datagen.tile("q40+dir", n, len(blocks)))
+    blocks = [np.ascontiguousarray(b) for b in blocks]
+    orders = [1] * len(blocks)
+    want = [oracle.compress(b.tobytes(), 1) for b in blocks]
+    dc = H.DeviceCodec(0)
+    dc.set_option("dec_direct", 0)
+    dc.set_option("dec_mid", 8)
+    B = _Arena(H, dc, want, [len(b) for b in blocks])
+    for rep in range(2):
+        B.d_out.zero_(); B.out_size.zero_(); B.status.fill_(-1)
+        dc.uncompress(B.d_in, B.in_off, B.in_size, B.d_out, B.out_off, B.out_cap, B.out_size, B.status, int(B.sizes.max()), 0)
+        st, dec = B.results()
+        bad = [(i, len(blocks[i]), int(st[i])) for i in range(len(blocks)) if st[i] != 0 or dec[i] != blocks[i].tobytes()]
+        assert not bad, (rep, bad[:10])
+    # and as the budget rule picks them: 3,000 blocks (more than the direct rows hold, one round of the mid class)
+    dc2 = H.DeviceCodec(0)
+    dc2.set_option("dec_mid", 1)
+    more = [np.ascontiguousarray(datagen.tile("q40+dir", 65536, i)) for i in range(3000)]
+    wm = [oracle.compress(b.tobytes(), 1) for b in more[:40]]
+    src = wm * 75
+    B = _Arena(H, dc2, src, [65536] * 3000)
+    dc2.uncompress(B.d_in, B.in_off, B.in_size, B.d_out, B.out_off, B.out_cap, B.out_size, B.status, int(B.sizes.max()), 0)
+    st, dec = B.results()
+    assert not st.any()
+    assert all(dec[i] == more[i % 40].tobytes() for i in range(3000))
