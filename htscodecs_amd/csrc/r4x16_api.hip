@@ -139,6 +139,8 @@ extern "C" rans4x16_hip_ctx *rans4x16_hip_create(int device)
         rans4x16_hip_destroy(c);
         return nullptr;
     }
+    // (a stream alone codes 4 bytes per step: ~99 ns to encode, ~188 ns to decode - bytes per 10 ns tick)
+    c->hint[0].pace = 0.40f; c->hint[1].pace = 0.21f;
     for (int w = 0; w < 2; w++)
         if (hipHostMalloc((void **)&c->hint[w].work, SCHED_HINT_BYTES, hipHostMallocDefault) == hipSuccess) memset(c->hint[w].work, 0, SCHED_HINT_BYTES);
         else c->hint[w].work = nullptr;

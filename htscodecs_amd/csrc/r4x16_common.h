@@ -342,7 +342,9 @@ struct EncDesc {
 #define SCHED_START (1u * CLS_MAX)              // first position in the list
 #define SCHED_CLAIM (2u * CLS_MAX)              // next share to hand out
 #define SCHED_SEATS (3u * CLS_MAX)              // workgroups of the class's launch that may work
-#define SCHED_CNT_WORDS (4u * CLS_MAX)
+#define SCHED_TSTART (4u * CLS_MAX)             // when the class's first workgroup started / its last one ended (low dword of the
+#define SCHED_TEND  (5u * CLS_MAX)              // 100 MHz clock): how long the class really took, for the next batch's plan
+#define SCHED_CNT_WORDS (6u * CLS_MAX)
 
 struct SchedWs {
     u32 *key;        // [nitems]  class << 8 | 255 - bucket, or CLS_NONE

@@ -1816,6 +1816,7 @@ __global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDes
     if (active && bad) desc[I->blk].status = ST_CONTEXT;
     __syncthreads();                                       // LDS is reused by the next share
     }
+    walk.leave();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2525,7 +2526,7 @@ __global__ __launch_bounds__(256) void k_dec_vsize(BatchArgs a, int base, int nb
 }
 
 // ---- host-callable launchers (r4x16_api.hip) ---------------------------------------------------
-static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitems, bool one_row_only, hipStream_t s, const R4Fork *fk, const R4Opts *o, const SchedHint *hint);
+static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitems, bool one_row_only, hipStream_t s, const R4Fork *fk, const R4Opts *o, SchedHint *hint);
 extern "C" void r4x16_launch_dec_front(const BatchArgs *a, const DecWs *ws, int base, int nblk, hipStream_t s, const R4Opts *o)
 {
     if (ws->var) {
@@ -2692,7 +2693,7 @@ extern "C" void r4x16_launch_cls_group(const u32 *cls, int nitems, u32 *count, u
     hipLaunchKernelGGL(k_cls_scan, dim3(1), dim3(64), 0, s, count);
     hipLaunchKernelGGL(k_cls_scatter, dim3((nitems + 255) / 256), dim3(256), 0, s, cls, nitems, count, list);
 }
-extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t s, const R4Fork *fk, const R4Opts *o, const SchedHint *hint) { launch_dec_chain_of(ws, ws->items, nitems, false, s, fk, o, hint); }
+extern "C" void r4x16_launch_dec_chain(const DecWs *ws, int nitems, hipStream_t s, const R4Fork *fk, const R4Opts *o, SchedHint *hint) { launch_dec_chain_of(ws, ws->items, nitems, false, s, fk, o, hint); }
 static int dec_class_qpw(u32 ci, const R4Opts *o)
 {
     const auto &c = DEC_CLASSES[ci];
@@ -2704,7 +2705,7 @@ static int dec_class_qpw(u32 ci, const R4Opts *o)
     return qpw;
 }
 // one_row_only: the items are order-0 streams (one-row images): only the classes such an image can fall into are launched
-static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitems, bool one_row_only, hipStream_t s0, const R4Fork *fk, const R4Opts *o, const SchedHint *hint)
+static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitems, bool one_row_only, hipStream_t s0, const R4Fork *fk, const R4Opts *o, SchedHint *hint)
 {
     // Classes side by side (r4x16_sched.h, PLAN): the class launches are dealt out over the caller's stream and the side
     // streams (fk), and the device-written plan gives each class its stream's share of the chip.  Without side streams

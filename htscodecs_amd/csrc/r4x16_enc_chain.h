@@ -519,5 +519,6 @@ __global__ __launch_bounds__(256) void k_enc_chain(EncItem *items, const u32 *rc
     if (active && (lane & 3) == 0) I->pay_len = pay;
     if (LDS_IMG) __syncthreads();                          // LDS is reused by the next share
     }
+    walk.leave();
 }
 

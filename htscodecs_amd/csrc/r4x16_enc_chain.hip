@@ -113,7 +113,7 @@ static int enc_wgs_per_cu(const EncShape &sh)
     if (wgs * sh.waves > 32) wgs = 32 / sh.waves;
     return wgs < 1 ? 1 : (int)wgs;
 }
-extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t s0, const R4Fork *fk, const R4Opts *o, const SchedHint *hint)
+extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t s0, const R4Fork *fk, const R4Opts *o, SchedHint *hint)
 {
     // classes side by side over the caller's stream and the side streams, each with its stream's share of the chip
     // (launch_dec_chain_of, r4x16_sched.h); class index ci = position in the classify table: u16 classes, packed

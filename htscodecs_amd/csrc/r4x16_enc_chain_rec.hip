@@ -345,6 +345,7 @@ __global__ __launch_bounds__(WAVE) void k_enc_chain_rec(EncItem *items, const u3
         if (active && (lane & 3) == 0) I->pay_len = pay;
         __syncthreads();                                      // LDS is reused by the next share
     }
+    walk.leave();
 }
 
 extern "C" void r4x16_enc_chain_rec_lds_limit(int bytes)

@@ -22,11 +22,11 @@
 
 extern "C" {
 void r4x16_launch_dec_front(const BatchArgs *, const DecWs *, int, int, hipStream_t, const R4Opts *);
-void r4x16_launch_dec_chain(const DecWs *, int, hipStream_t, const R4Fork *, const R4Opts *, const SchedHint *);
+void r4x16_launch_dec_chain(const DecWs *, int, hipStream_t, const R4Fork *, const R4Opts *, SchedHint *);
 void r4x16_launch_dec_back(const BatchArgs *, const DecWs *, int, int, hipStream_t, const R4Opts *);
 void r4x16_launch_enc_front(const BatchArgs *, const EncWs *, int, int, hipStream_t, const R4Opts *);
 void r4x16_launch_enc_tables(const BatchArgs *, const EncWs *, int, int, hipStream_t);
-void r4x16_launch_enc_chain(const EncWs *, int, hipStream_t, const R4Fork *, const R4Opts *, const SchedHint *);
+void r4x16_launch_enc_chain(const EncWs *, int, hipStream_t, const R4Fork *, const R4Opts *, SchedHint *);
 void r4x16_launch_enc_finish(const BatchArgs *, const EncWs *, int, int, hipStream_t);
 u32  r4x16_compress_bound(u32 size, int order);
 u32  r4x16_dec_direct_budget(int nblk, const R4Opts *);
@@ -80,7 +80,7 @@ struct rans4x16_hip_ctx {
     // side streams for the class launches of small batches (created at first use)
     R4Fork fork = {};
     bool fork_made = false;
-    SchedHint hint[2] = {{nullptr}, {nullptr}};    // [0] encode, [1] decode: the last batch's work per class (pinned; r4x16_sched.h)
+    SchedHint hint[2] = {};    // [0] encode, [1] decode: the last batch's work per class (pinned; r4x16_sched.h)
     bool no_fork = false;                   // a lane of the host pipeline: the lanes are its concurrency (one priority each)
     // host-buffer batches: this context's own stream, and the lane contexts large batches are pipelined over
     hipStream_t stream = nullptr;

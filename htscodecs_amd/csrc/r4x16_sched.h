@@ -105,6 +105,12 @@ struct SchedWalk {
         const u32 seats = cnt[SCHED_SEATS];
         in = blockIdx.x < seats;
         stride = (int)(seats < gridDim.x ? seats : gridDim.x);
+        if (in && nwg > 0 && threadIdx.x == 0) atomicMin(&cnt[SCHED_TSTART], (u32)__builtin_amdgcn_s_memrealtime());
+    }
+    // a workgroup that worked leaves: the class has run at least until now
+    __device__ __forceinline__ void leave() const
+    {
+        if (in && nwg > 0 && threadIdx.x == 0) atomicMax(&cnt[SCHED_TEND], (u32)__builtin_amdgcn_s_memrealtime());
     }
     // next share of a ONE-WAVE workgroup (-1: none)
     __device__ __forceinline__ int next_wave()
@@ -154,17 +160,24 @@ static inline float sched_rate(int qpw, int waves_per_wg, int wgs_per_cu, int cu
 // wave's pace (1 MiB: ~50 ms to decode): two such classes behind each other on one stream are two such latencies.  So
 // the classes go out longest first - by max(longest chain, work per resident stream) - each to the stream with the
 // least so far.  Without a hint (first call) the launches are dealt out in turn.
-struct SchedHint { u64 *work; };                // pinned, [2 * CLS_MAX]: sums, then longest - and behind them the SCHED_CNT_WORDS
+struct SchedHint {
+    u64 *work;
+    // what the classes' launches really took, side by side, as rates in the plan's units (streams at a lone wave's pace),
+    // smoothed over the batches of this context; 0 = not learned.  `pace`: bytes per 10 ns tick of one stream alone.
+    float learned[CLS_MAX];
+    float pace;
+    bool side_by_side;       // how the last batch's launches were dealt out (rates are learned from side-by-side runs only)
+};                // pinned, [2 * CLS_MAX]: sums, then longest - and behind them the SCHED_CNT_WORDS
                                                 // dwords of SchedWs.cnt (counts, seats: for the trace); nullptr: no hint kept
 #define SCHED_HINT_BYTES (2 * CLS_MAX * sizeof(u64) + SCHED_CNT_WORDS * sizeof(u32))
 // launch_order: the order in which the launches should go out - the classes the last batch used first (an EMPTY class's
 // launch still has to get its workgroups through the dispatcher, which on a chip full of seated persistent workgroups
 // takes until LDS frees up: 18 ms were seen - anything queued behind it on its stream waits that long)
-void sched_assign_queues(const SchedPlan &plan, const int *todo_cls, int ntodo, int nq, const SchedHint *hint, u8 *queue_of_todo,
+void sched_assign_queues(SchedPlan &plan, const int *todo_cls, int ntodo, int nq, SchedHint *hint, u8 *queue_of_todo,
                          int *launch_order, const char *trace = nullptr);
 
 extern "C" {
-void r4x16_sched_hint_save(const SchedWs *w, const SchedHint *hint, hipStream_t s);
+void r4x16_sched_hint_save(const SchedWs *w, SchedHint *hint, hipStream_t s);
 void r4x16_voff_scan(u64 *v, int n, hipStream_t s);
 void r4x16_sched_zero(const SchedWs *w, hipStream_t s);
 void r4x16_sched_group(const SchedWs *w, int nitems, const SchedPlan *plan, hipStream_t s);

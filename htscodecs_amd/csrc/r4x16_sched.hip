@@ -7,7 +7,7 @@ __global__ __launch_bounds__(256) void k_sched_zero(SchedWs w)
 {
     const u32 i = blockIdx.x * 256u + threadIdx.x;
     if (i < 2u * SCHED_BINS) w.bins[i] = 0u;
-    if (i < SCHED_CNT_WORDS) w.cnt[i] = 0u;
+    if (i < SCHED_CNT_WORDS) w.cnt[i] = (i >= SCHED_TSTART && i < SCHED_TEND) ? 0xffffffffu : 0u;
     if (i < 2u * CLS_MAX) w.work[i] = 0ull;
 }
 
@@ -103,27 +103,50 @@ extern "C" void r4x16_sched_launch(const void *kernel, dim3 grid, dim3 block, vo
     (void)hipLaunchKernel(kernel, grid, block, args, lds, s);
 }
 
-void sched_assign_queues(const SchedPlan &plan, const int *todo_cls, int ntodo, int nq, const SchedHint *hint, u8 *queue_of_todo,
+void sched_assign_queues(SchedPlan &plan, const int *todo_cls, int ntodo, int nq, SchedHint *hint, u8 *queue_of_todo,
                          int *launch_order, const char *trace)
 {
     double load[R4_FORK_STREAMS + 1] = {0}, floor_q[R4_FORK_STREAMS + 1] = {0};
-    double t[CLS_MAX], fl[CLS_MAX];
+    double t[CLS_MAX], tl[CLS_MAX], fl[CLS_MAX];
     int order[CLS_MAX];
     bool any = false;
-    double sum_t = 0.0, seq = 0.0;
+    double sum_tl = 0.0, seq = 0.0;
+    const u32 *cnt = hint && hint->work ? (const u32 *)(hint->work + 2 * CLS_MAX) : nullptr;
+    float model_rate[CLS_MAX];
+    for (u32 c = 0; c < CLS_MAX; c++) model_rate[c] = plan.rate[c];
     for (int k = 0; k < ntodo; k++) {
         const int c = todo_cls[k];
         const double w = hint && hint->work ? (double)hint->work[c] : 0.0;
         fl[k] = hint && hint->work ? (double)hint->work[CLS_MAX + c] : 0.0;               // the longest chain: the class cannot end before it
-        t[k] = plan.wgs_full[c] && plan.rate[c] > 0.f ? w / (double)plan.rate[c] : 0.0;   // the class alone on the chip, throughput-bound
-        sum_t += t[k];
+        t[k] = plan.wgs_full[c] && plan.rate[c] > 0.f ? w / (double)plan.rate[c] : 0.0;   // the class alone on the chip, throughput-bound (model)
+        // What the class's launch really took last time, side by side with the others: work / (duration x its share of
+        // the chip) is its rate as it runs in company - where it was bound by throughput, not by its longest chain.
+        // Smoothed over the batches of the context.
+        if (cnt && hint->side_by_side && w > 0.0 && plan.wgs_full[c] && cnt[SCHED_SEATS + c] && hint->pace > 0.f) {
+            const u32 t0 = cnt[SCHED_TSTART + c], t1 = cnt[SCHED_TEND + c], seats = cnt[SCHED_SEATS + c] < plan.wgs_full[c] ? cnt[SCHED_SEATS + c] : plan.wgs_full[c];
+            const double ticks = (double)(u32)(t1 - t0), frac = (double)seats / plan.wgs_full[c];
+            // (bound by throughput: it took clearly longer than its longest chain takes alone)
+            if (t0 != 0xffffffffu && ticks > 1000.0 && ticks > 1.5 * fl[k] / hint->pace) {
+                // (within 0.4 .. 1.25 of the model: a class that looks slower than that is bound by its longest chains running
+                //  in a crowd, not by throughput, and more seats would only crowd it further - seen on the encoder's
+                //  class of 64-stream workgroups, which took 85 ms with 263 seats and 68 with 98)
+                float r = (float)(w / (ticks * frac) / hint->pace);
+                const float lo = 0.4f * model_rate[c], hi = 1.25f * model_rate[c];
+                r = r < lo ? lo : r > hi ? hi : r;
+                hint->learned[c] = hint->learned[c] > 0.f ? 0.5f * hint->learned[c] + 0.5f * r : r;
+            }
+        }
+        tl[k] = hint && hint->learned[c] > 0.f ? w / (double)hint->learned[c] : 1.3 * t[k];  // side by side (1.3: the model's allowance where nothing is learned)
+        if (hint && hint->learned[c] > 0.f) plan.rate[c] = hint->learned[c];                 // the plan's shares follow what was learned
+        sum_tl += tl[k];
         seq += fl[k] > t[k] ? fl[k] : t[k];
         if (t[k] > 0.0 || fl[k] > 0.0) any = true;
         order[k] = k;
     }
     for (int k = 0; k < ntodo; k++) launch_order[k] = k;
+    if (hint) hint->side_by_side = nq > 1;
     if (nq <= 1 || !any) { for (int k = 0; k < ntodo; k++) queue_of_todo[k] = (u8)(nq > 1 ? k % nq : 0); return; }
-    auto key = [&](int k) { return fl[k] > t[k] ? fl[k] : t[k]; };
+    auto key = [&](int k) { return fl[k] > tl[k] ? fl[k] : tl[k]; };
     std::stable_sort(order, order + ntodo, [&](int a, int b) { return key(a) > key(b); });
     int rr = 0;
     for (int j = 0; j < ntodo; j++) {
@@ -135,24 +158,26 @@ void sched_assign_queues(const SchedPlan &plan, const int *todo_cls, int ntodo, 
         queue_of_todo[k] = (u8)q;
     }
     // Side by side or one after the other?  Side by side hides the classes' chain latencies behind each other but costs
-    // throughput (workgroups of several sizes share a CU's LDS badly, the shares are estimates: 262,144 x 64 KiB mixed
-    // blocks took 30 % longer that way); one after the other every class has the chip to itself but pays its own
-    // longest chain.  With the last batch's figures both can be priced: whichever is shorter.
-    double conc = 1.3 * sum_t;
+    // throughput (workgroups of several sizes share a CU's LDS and issue slots badly: 262,144 x 64 KiB mixed blocks
+    // took 30 % longer that way); one after the other every class has the chip to itself but pays its own longest
+    // chain.  With the last batch's figures both can be priced: whichever is shorter.
+    double conc = sum_tl;
     for (int i = 0; i < nq; i++) if (floor_q[i] > conc) conc = floor_q[i];
-    if (seq <= conc) for (int k = 0; k < ntodo; k++) queue_of_todo[k] = 0;
+    const bool in_order = seq <= conc;
+    if (in_order) for (int k = 0; k < ntodo; k++) queue_of_todo[k] = 0;
+    if (hint) hint->side_by_side = !in_order;
     if (trace) {                                         // option sched_trace: what the LAST batch looked like, and this deal
-        const u32 *cnt = (const u32 *)(hint->work + 2 * CLS_MAX);
-        fprintf(stderr, "rans4x16_hip sched %s: last batch seq %.0f conc %.0f (sum_t %.0f) -> %s\n", trace, seq, conc, sum_t, seq <= conc ? "in stream order" : "side by side");
+        fprintf(stderr, "rans4x16_hip sched %s: last batch seq %.0f conc %.0f (sum of side-by-side times %.0f) -> %s\n", trace, seq, conc, sum_tl, in_order ? "in stream order" : "side by side");
         for (int k = 0; k < ntodo; k++) {
             const int c = todo_cls[k];
             if (t[k] > 0.0 || fl[k] > 0.0)
-                fprintf(stderr, "  class %2d qpw %2u full %4u rate %7.0f: streams %6u seats %4u work %12llu longest %8.0f t %9.0f -> stream %u\n", c, plan.qpw[c],
-                        plan.wgs_full[c], plan.rate[c], cnt[SCHED_COUNT + c], cnt[SCHED_SEATS + c], (unsigned long long)hint->work[c], fl[k], t[k], queue_of_todo[k]);
+                fprintf(stderr, "  class %2d qpw %2u full %4u rate %7.0f (learned %7.0f): streams %6u seats %4u took %8.3f ms work %12llu longest %8.0f t %9.0f -> stream %u\n", c,
+                        plan.qpw[c], plan.wgs_full[c], plan.rate[c], hint->learned[c], cnt[SCHED_COUNT + c], cnt[SCHED_SEATS + c],
+                        (double)(u32)(cnt[SCHED_TEND + c] - cnt[SCHED_TSTART + c]) / 1e5, (unsigned long long)hint->work[c], fl[k], t[k], queue_of_todo[k]);
         }
     }
 }
-extern "C" void r4x16_sched_hint_save(const SchedWs *w, const SchedHint *hint, hipStream_t s)
+extern "C" void r4x16_sched_hint_save(const SchedWs *w, SchedHint *hint, hipStream_t s)
 {
     if (hint && hint->work) {
         (void)hipMemcpyAsync(hint->work, w->work, 2 * CLS_MAX * sizeof(u64), hipMemcpyDeviceToHost, s);

@@ -10,4 +10,4 @@ for k in ("sched_sort", "sched_claim", "sched_concurrent"):
     if os.environ.get(k.upper()):
         dc.set_option(k, int(os.environ[k.upper()]))
 uni = int(sys.argv[2]) if len(sys.argv) > 2 else None
-print(json.dumps(bench.hetero_run(torch, H, dc, torch.device("cuda", 0), int(float(sys.argv[1]) * (1 << 30)), uniform=uni, reps=1, check=8)))
+print(json.dumps(bench.hetero_run(torch, H, dc, torch.device("cuda", 0), int(float(sys.argv[1]) * (1 << 30)), uniform=uni, reps=int(os.environ.get("REPS", 1)), check=8)))
