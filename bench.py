@@ -680,27 +680,33 @@ def main():
         traffic, traffic_source, sq, sq_all = None, None, None, {}
         build = library_hash()
         isa = {}
-        try:
-            with open(os.path.join(ROOT, "profiles", "r03_isa_counts.json")) as f:
-                j = json.load(f)
-            if j.get("library_sha256_16") == build:
-                isa = j["kernels"]
-        except (OSError, KeyError, ValueError):
-            pass
-        try:
-            with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
-                pmc = json.load(f)
-            w = pmc["workload"]
-            if (w["blocks"], w["block_size"], w["data"], w["order"]) == (nblk, bs, args.data, order) \
-                    and pmc.get("library_sha256_16") == build:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_isa_counts.json")), reverse=True):
+            try:
+                with open(path) as f:
+                    j = json.load(f)
+                if j.get("library_sha256_16") == build:
+                    isa = j["kernels"]
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+            try:
+                with open(path) as f:
+                    pmc = json.load(f)
+                w = pmc["workload"]
+                if (w["blocks"], w["block_size"], w["data"], w["order"]) != (nblk, bs, args.data, order) \
+                        or pmc.get("library_sha256_16") != build:
+                    continue
                 for key, v in pmc["kernels"].items():       # the instantiation that did the work (k_dec_chain<true, 1>, not the
                     if key.startswith(kname) and v["traffic_bytes"] > (traffic or 0):   # nested tables' k_dec_chain<true, 3>)
                         traffic = v["traffic_bytes"]
-                        traffic_source = "profiles/r03_pmc_traffic.json"
+                        traffic_source = os.path.relpath(path, ROOT)
                 sq_all = pmc.get("sq", {})
                 sq = sq_all.get(kname)
-        except (OSError, KeyError, ValueError):
-            pass
+                break
+            except (OSError, KeyError, ValueError):
+                pass
         chain = chain_figure(torch, dc, kname, dec_avg if kname == "k_dec_chain" else enc_avg, launches_per_step,
                              nblk, bs, dec_spc if kname == "k_dec_chain" else enc_spc,
                              dec_lanes if kname == "k_dec_chain" else enc_lanes, cus, probe, sq)
@@ -730,7 +736,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(alg_bytes),
                          "note": "avg_kernel_ms = HIP-event time of the chain kernel per step; the kernel is launched "
                                  "once per LDS size class and all but one class exit in microseconds, so compare with "
-                                 "rocprof's TotalDurationNs / steps (profiles/r03_final_working_launches.csv)"},
+                                 "rocprof's TotalDurationNs / steps (profiles/r04_final_working_launches.csv)"},
             "workspace_GB": round(ws_headline / 2**30, 2),
             "gate": {"roundtrip_blocks": nblk, "bytes_equal_cpu_blocks": gate_blocks,
                      "how": "untimed extra step into cleared outputs after the timed ones"},

@@ -26,8 +26,8 @@ static const struct { const char *name, *env; long dflt; } OPT_TAB[OPT_COUNT] = 
     /* OPT_HOST_THREADS      */ {"host_threads", "R4X16_HOST_THREADS", 8},
     /* OPT_HOST_LANES        */ {"host_lanes", "R4X16_HOST_LANES", 2},
     /* OPT_HOST_SLAB_MIN_MB  */ {"host_slab_min_mb", "R4X16_HOST_SLAB_MIN_MB", 32},
-    /* OPT_HOST_DEC_SLABS    */ {"host_dec_slabs", "R4X16_HOST_DEC_SLABS", 1},
-    /* OPT_HOST_ENC_SLABS    */ {"host_enc_slabs", "R4X16_HOST_ENC_SLABS", 1},
+    /* OPT_HOST_DEC_SLABS    */ {"host_dec_slabs", "R4X16_HOST_DEC_SLABS", 0},
+    /* OPT_HOST_ENC_SLABS    */ {"host_enc_slabs", "R4X16_HOST_ENC_SLABS", 0},
     /* OPT_HOST_PACK         */ {"host_pack", "R4X16_HOST_PACK", 1},
     /* OPT_HOST_TRACE        */ {"host_trace", "R4X16_HOST_TRACE", 0},
     /* OPT_DEC_QPW           */ {"dec_qpw", "R4X16_DEC_QPW", 0},

@@ -379,7 +379,14 @@ static int run_pipelined(rans4x16_hip_ctx *c, int n, bool decode,
     // exactly 1,024 blocks on ONE lane reach 25.3 GB/s (each takes the short-step rows, 31 ms, and its output leaves
     // while the next runs) - but only for alphabets whose direct rows fit four streams per CU, which the host cannot
     // know; with any other data three serial slabs cost three full chain latencies.  Not adopted.
-    size_t nslab = (rounds ? rounds : 1) * (size_t)nlanes * (size_t)(decode ? c->opts.v[OPT_HOST_DEC_SLABS] : c->opts.v[OPT_HOST_ENC_SLABS]);
+    // Round 4 (profiles/r04_host_timeline.md): what bounds a large batch is the copy-out (8.6 GB of decoded blocks at
+    // ~48 GB/s against ~40 GB/s of copy-in for half as many bytes), and it cannot start before the first slab's kernels
+    // are done - so slabs of about 2.3 GB of arena (input + capacity) each, however many that makes: 8,192 x 1 MiB decode
+    // 27.9 -> 33.5 GB/s with six slabs instead of two, encode 37.3 -> 39.0 with four; a 3,072-block batch keeps its two.
+    // host_dec_slabs / host_enc_slabs > 0 fix the slabs per lane instead.
+    const long per_lane = decode ? c->opts.v[OPT_HOST_DEC_SLABS] : c->opts.v[OPT_HOST_ENC_SLABS];
+    size_t nslab = per_lane > 0 ? (rounds ? rounds : 1) * (size_t)nlanes * (size_t)per_lane
+                                : std::max<size_t>((size_t)nlanes, (tot + ((size_t)1150 << 20)) / ((size_t)2300 << 20));
     const long slab_min_mb = c->opts.v[OPT_HOST_SLAB_MIN_MB];
     while (nslab > 1 && tot / nslab < ((size_t)(slab_min_mb > 0 ? slab_min_mb : 1) << 20)) nslab--;
     if (nslab > (size_t)n) nslab = (size_t)n;

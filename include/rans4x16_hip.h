@@ -189,7 +189,7 @@ int rans4x16_hip_set_dev_stripe_planes(rans4x16_hip_ctx *ctx, int planes, unsign
  *   host_threads          8     R4X16_HOST_THREADS       copier threads of the host pipeline
  *   host_lanes            2     R4X16_HOST_LANES         slabs of a host batch in flight at once
  *   host_slab_min_mb     32     R4X16_HOST_SLAB_MIN_MB   smallest slab
- *   host_dec_slabs / host_enc_slabs  1                   slabs per lane and round
+ *   host_dec_slabs / host_enc_slabs  0                   slabs per lane and round; 0 = by size (about 2.3 GB of input + capacity each)
  *   host_pack             1     R4X16_HOST_PACK          encode results gathered on the device before they cross PCIe
  *   host_stripe_dev       1     R4X16_HOST_STRIPE_DEV    X_STRIPE blocks of host batches through the device stripe kernels
  *   host_trace            0     R4X16_HOST_TRACE         timeline of a pipelined host batch on stderr

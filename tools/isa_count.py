@@ -18,8 +18,8 @@ def blocks_of(src, name):
     return blocks
 
 HOT = {   # kernel-name mangled prefix -> (label, instruction that occurs once per step in the hot body)
-    "_Z11k_dec_chainILb1ELi1EE": ("k_dec_chain<true,1>", "v_lshrrev_b64"),
-    "_Z11k_dec_chainILb1ELi6EE": ("k_dec_chain<true,6>", "v_lshrrev_b64"),
+    "_Z11k_dec_chainILb1ELi1ELi8EE": ("k_dec_chain<true,1>", "v_lshrrev_b64"),
+    "_Z11k_dec_chainILb1ELi6ELi8EE": ("k_dec_chain<true,6>", "v_lshrrev_b64"),
     "_Z11k_enc_chainILb1ELb1EE": ("k_enc_chain<true,true>", "ds_write_b16"),
     "_Z15k_enc_chain_rec": ("k_enc_chain_rec", "ds_write_b16"),
 }

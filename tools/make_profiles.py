@@ -79,6 +79,14 @@ with open(os.path.join(DST, f"{tag}_pmc_traffic.json"), "w") as f:
 os.makedirs(os.path.join(DST, "pmc"), exist_ok=True)
 shutil.copy(one("fetch/**/*counter_collection.csv"), os.path.join(DST, "pmc", f"{tag}_fetch_counter_collection.csv"))
 shutil.copy(one("write/**/*counter_collection.csv"), os.path.join(DST, "pmc", f"{tag}_write_counter_collection.csv"))
+if os.path.exists(os.path.join(SRC, "hetero.jsonl")):
+    with open(os.path.join(DST, f"{tag}_hetero.jsonl"), "w") as f:
+        for name in ("hetero.jsonl", "hetero_4g.jsonl"):
+            if os.path.exists(os.path.join(SRC, name)):
+                f.write(open(os.path.join(SRC, name)).read())
+if os.path.exists(os.path.join(SRC, "hetero_sched_trace.txt")):
+    with open(os.path.join(DST, f"{tag}_hetero_sched_trace.txt"), "w") as f:
+        f.write("".join(l for l in open(os.path.join(SRC, "hetero_sched_trace.txt")) if "Warning" not in l and "d_base" not in l and "amdgpu.ids" not in l))
 for name, dst in (("batch_sweep.jsonl", f"{tag}_batch_sweep.jsonl"), ("shapes.jsonl", f"{tag}_shapes.jsonl"),
                   ("sq_small_summary.txt", f"{tag}_sq_one_block.txt")):
     if os.path.exists(os.path.join(SRC, name)):

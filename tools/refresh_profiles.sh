@@ -1,15 +1,16 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): the bench line, the rocprofv3 kernel statistics of the same command, the two
 # PMC passes for HBM traffic and two SQ passes for the chain kernels' issue / LDS figures; everything lands under
-# gpurun_out/refresh/.  Afterwards, in the container: python3 tools/make_profiles.py r03  (summaries -> profiles/).
+# gpurun_out/refresh/.  Afterwards, in the container: python3 tools/make_profiles.py r04  (summaries -> profiles/).
 set -e
+set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/refresh   # (delete the local copy first: gpurun merges new files into it)
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 $R/bench.py --no-cpu --no-host --no-configs4 > $O/bench_prof.json 2> $O/bench_prof.err
-P="--steps 1 --warmup 1 --no-cpu --no-host --no-configs4"
+rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python3 $R/bench.py --no-cpu --no-host --no-configs4 --no-hetero > $O/bench_prof.json 2> $O/bench_prof.err
+P="--steps 1 --warmup 1 --no-cpu --no-host --no-configs4 --no-hetero"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch --output-format csv -- python3 $R/bench.py $P > $O/fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write --output-format csv -- python3 $R/bench.py $P > $O/write.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY \
@@ -19,6 +20,10 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_ACTIVE_I
 # keep the merge small: only the CSVs the summaries need
 find $O -name "*agent_info.csv" -delete
 tail -n 1 $O/bench.json
+# round 4: batches whose blocks differ in length, alphabet and order, with the scheduling switched on step by step
+HETERO_GIB=16 python3 $R/tools/batch_sweep.py --hetero $O/hetero.jsonl > $O/hetero.log 2>&1
+HETERO_GIB=4 python3 $R/tools/batch_sweep.py --hetero $O/hetero_4g.jsonl > $O/hetero_4g.log 2>&1
+REPS=3 R4X16_SCHED_TRACE=1 python3 $R/tools/hetero_trace.py 16 > $O/hetero_sched_trace.txt 2>&1
 # round 3: the batch-size sweep (what a caller gets below one round of resident streams) and the other shapes
 python3 $R/tools/batch_sweep.py $O/batch_sweep.jsonl > $O/batch_sweep.log 2>&1
 bash $R/tools/shapes.sh > $O/shapes.jsonl 2> $O/shapes.err
