@@ -286,8 +286,12 @@ typedef u32 GAS __attribute__((aligned(1))) gu32_unaligned;   // global dword st
 // one waiting in registers: a trip then moves the cursor by at most 32 bytes, so from anywhere in quarter h it stays
 // inside h and h + 1, and the quarter just left is overwritten at once.  136 bytes less per stream: 46-symbol packed
 // rows at 3,360 bytes, 3 x 16 streams per CU instead of 3 x 15 - for one more loop test per eight steps.
+#define ROW_BAD  0x200u      // alpha[] flag (rANS 4x8 images): decoding this symbol is an error
 #define RING_BYTES_SHORT 136u
-template <int ORDER, int LV, int TRIP = TRIP_STEPS>
+// BYTE (round 4): rANS 4x8's renormalisation on the same loop - L = 2^23, a byte if x < 2^23 and a second one if x < 2^15,
+// chains served in the order 0..3 (rANS_byte.h:541-551); `cursor` and `words_len` then count bytes, the look-up is the
+// 12-bit one of the u16 rows, and the flag of the symbol that owns slot 4095 of a 4095-sum table (ROW_BAD) is kept.
+template <int ORDER, int LV, int TRIP = TRIP_STEPS, bool BYTE = false>
 __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 *ring, gcu8 *words, u32 words_len,
                                                 gu8 *out, u32 out_sz, u32 x, u32 look, bool active, u32 lane)
 {
@@ -298,7 +302,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     constexpr bool PKD = LV == 1 || LV == 5, WIDE = LV == 5;       // packed rows (r4x16_common.h), with the 16-byte root
     static_assert(LV != 6 && LV != 10, "direct blocks and mid rows have their own loops: chain_decode_dir, chain_decode_mid");
     const u32 rows = lds_addr(img_lds) + img_alpha_bytes(nsym), roww = PKD ? pk_row_bytes(nsym) : img_row_bytes(nsym);
-    const u32 nwords = words_len >> 1;
+    const u32 nwords = BYTE ? words_len : words_len >> 1;  // units of the cursor: 16-bit words (bytes for rANS 4x8)
     const u32 below = (1u << k) - 1u;                      // quad lanes below this one
     constexpr u32 NQ = TRIP == 8 ? 4u : 2u, RB = 64u * NQ; // quarters and bytes of the ring
     u32 count;
@@ -347,6 +351,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     u32 acc = 0;                                          // order-1: the last (up to) 4 decoded bytes
     u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;                   // order-1: completed dwords not yet stored (a3 newest)
     u32 hdr = 0, hdr_even = 0;                            // order-1: alpha[] word of the symbol decoded last step
+    u32 badb = 0;                                         // BYTE: the alpha words of every symbol decoded (for ROW_BAD)
     if (ORDER == 1 && count) bad = img.ld16(0);
     if (PKD) hdr = img.ld16(0);                           // packed rows: bits 9.. of the context's alpha word = its `first`
 
@@ -361,7 +366,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             const bool live = FAST ? true : T < count;
             // next four candidate words (8 bytes at any byte alignment) from the ring; issued
             // before the table lookups so that their latency hides under them
-            const u32 cb = off0 + 2 * cursor;
+            const u32 cb = BYTE ? off0 + cursor : off0 + 2 * cursor;
             const u32 ra = cb & (RB - 4u);
             // Three ALIGNED dwords and a funnel shift: a dword read at a misaligned LDS address costs far
             // more than the extra read (measured: +12 % on the whole kernel per misaligned read and step).
@@ -403,6 +408,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
 #else
             const u32 hn = img.ld16(2 * s);               // byte value | ROW_EMPTY of the new context
 #endif
+            if (BYTE) badb |= (FAST || live) ? hn : 0u;   // rANS 4x8: ROW_BAD on ANY decoded symbol, the last one included
             u32 byte0 = 0;
             if (ORDER == 0) {
                 byte0 = hn & 0xffu;
@@ -447,6 +453,27 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
                 }
             }
             x = live ? xn : x;
+            if (BYTE) {
+                // a chain takes a byte if x < 2^23 and a second one if x < 2^15 (then x << 8 | b < 2^23 whatever b is)
+                const bool w1 = live && x < (1u << 23), w2 = live && x < (1u << 15);
+                const u32 m1 = quad_ballot(w1, lane), m2 = quad_ballot(w2, lane);
+                const u32 pre = __popc(m1 & below) + __popc(m2 & below);            // bytes the chains before this one take: 0 .. 6
+                u32 wlo, whi;
+                if (ORDER == 1) { wlo = __builtin_amdgcn_alignbyte(d1, d0, cb); whi = __builtin_amdgcn_alignbyte(d2, d1, cb); }
+                else { const u32 sh = (cb & 3u) * 8u; wlo = __builtin_amdgcn_alignbit(d1, d0, sh); whi = __builtin_amdgcn_alignbit(d2, d1, sh); }
+                // the two bytes at `pre`, the first one on top: b0 << 8 | b1
+                const u32 w = __builtin_amdgcn_perm(whi, wlo, __umul24(pre, 0x0101u) + 0x0c0c0001u);
+                u32 x2 = (x << 16) | w, x1 = (x << 8) | (w >> 8);
+                asm volatile("" : "+v"(x2), "+v"(x1));
+                if (FAST) x = w2 ? x2 : w1 ? x1 : x;
+                else {
+                    // nothing is read past the end of the stream: a chain gets what is left, up to what it asks for
+                    const u32 at = cursor + pre, room = at < nwords ? nwords - at : 0u, wantb = (w1 ? 1u : 0u) + (w2 ? 1u : 0u);
+                    const u32 takeb = wantb < room ? wantb : room;
+                    x = takeb > 1u ? x2 : takeb ? x1 : x;
+                }
+                cursor += __popc(m1) + __popc(m2);
+            } else {
             const bool want = live && x < RANS_LOW;
 
             // renormalise: chains refill in order 0..3 from the shared cursor.  After the first
@@ -467,6 +494,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             asm volatile("" : "+v"(xr));                  // keeps the refill arithmetic out of a branch
             x = take ? xr : x;
             cursor += __popc(wm);
+            }
 
             if (ORDER == 0) {
                 if (FAST) {
@@ -495,12 +523,12 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
         t += TRIP;
     };
     while (wave_any(t < count)) {
-        const bool slow = active && (t + TRIP > count || cursor + 4 * TRIP > nwords);
+        const bool slow = active && (t + TRIP > count || cursor + (BYTE ? 8 : 4) * TRIP > nwords);
         if (!wave_any(slow)) trip(std::true_type{});
         else trip(std::false_type{});
 
         // ring refill when the cursor has entered a new 64-byte quarter (at most 64 bytes ago)
-        const u32 nh = (off0 + 2 * cursor) >> 6;
+        const u32 nh = (BYTE ? off0 + cursor : off0 + 2 * cursor) >> 6;
         if (wave_any(active && nh != half)) {
             if (active && nh != half) {                   // idle lanes hold garbage cursors: they must not write LDS
                 // the quarter in `pend` was requested at the previous crossing: park it in the slot just vacated
@@ -526,7 +554,7 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
         const u32 rem = count - 4 * pushed;                // 0..4, in the top `rem` bytes of acc
         for (u32 j = 0; j < rem; j++) op[j] = (u8)(acc >> (8 * (4 - rem + j)));
     }
-    return active ? (bad & ROW_EMPTY) : 0u;        // idle lanes ran on garbage in the fast trips
+    return active ? ((bad & ROW_EMPTY) | (BYTE ? badb & ROW_BAD : 0u)) : 0u;        // idle lanes ran on garbage in the fast trips
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2890,7 +2918,6 @@ extern "C" void r4x16_launch_stripe(const u8 *src, u8 *dst, u32 n, u32 N, int jo
 // =============================================================================================
 #define X8_LOW   (1u << 23)
 #define X8_BITS  12u
-#define ROW_BAD  0x200u                                   // alpha[] flag: decoding this symbol is an error
 #define IMG8_MAX_NSYM 257u                                // 256 symbols + the flagged one
 #define IMG8_SLOT ((528u + 257u * 832u + 255u) & ~255u)   // alpha[257] + 257 four-level rows
 
@@ -3290,6 +3317,7 @@ __device__ __forceinline__ u32 chain_decode8_lds(const u8 *img_lds, u32 nsym, u8
 // wave; class 1 - images up to X8_SLOT1 (order 1, up to 50 symbols: the quality alphabets), 12 per wave; class 2 - the
 // rest, tables through L2
 #define X8_SLOT0 (IMG_O0_BYTES + X8_RING)
+#define X8_SLOT1A 5360u      // round 4: up to 46 symbols (the quality alphabets) - ten per wave, THREE waves per CU (30 streams)
 #define X8_SLOT1 6416u
 __global__ __launch_bounds__(256) void k8_classify(const X8Item *items, int nitems, u32 *cls, u32 *count)
 {
@@ -3299,7 +3327,7 @@ __global__ __launch_bounds__(256) void k8_classify(const X8Item *items, int nite
     u32 c = CLS_NONE;
     if (I->active) {
         const u32 need = img_bytes(I->nsym, I->order ? I->nsym : 1u) + X8_RING;
-        c = need <= X8_SLOT0 ? 0u : need <= X8_SLOT1 ? 1u : 2u;
+        c = need <= X8_SLOT0 ? 0u : need <= X8_SLOT1A ? 1u : need <= X8_SLOT1 ? 2u : 3u;
         atomicAdd(&count[c], 1u);
     }
     cls[i] = c;
@@ -3339,7 +3367,9 @@ __global__ __launch_bounds__(WAVE) void k8_dec_chain(const X8Item *items, BatchA
         __syncthreads();
         const u8 *im = lds + (u64)quad * slot_bytes;
         u8 *ring = lds + (u64)quad * slot_bytes + (slot_bytes - X8_RING);
-#define X8_RUN(O, L) bad |= chain_decode8_lds<O, L>(im, nsym, ring, bytes, blen, out, osz, x0, active && order == O && lv == L, lane)
+        // (round 4: the 4x16 decoder's loop with rANS 4x8's byte renormalisation - full trips without liveness selects,
+        //  speculative roots, gathered stores - instead of round 2's chain_decode8_lds)
+#define X8_RUN(O, L) bad |= chain_decode_lds<O, L, TRIP_STEPS, true>(im, nsym, ring, bytes, blen, out, osz, x0, X8_BITS, active && order == O && lv == L, lane)
         X8_RUN(0, 2); X8_RUN(0, 3); X8_RUN(0, 4);
         X8_RUN(1, 2);                                          // (X8_SLOT1 holds 2-read images only: up to 50 symbols)
 #undef X8_RUN
@@ -3372,11 +3402,13 @@ extern "C" void r4x8_launch_decode(const BatchArgs *a, u8 *ws, int base, int nbl
     hipLaunchKernelGGL(k8_classify, dim3((nblk + 255) / 256), dim3(256), 0, s, (const X8Item *)items, nblk, cls, cls_count);
     r4x16_launch_cls_group(cls, nblk, cls_count, cls_list, s);
     if (r4x16_first_on_device(16u)) lds_limit((const void *)k8_dec_chain<true>, 163840);
-    const int q0 = 16, q1 = 12;
+    const int q0 = 16, q1a = 10, q1 = 12;
     hipLaunchKernelGGL(k8_dec_chain<true>, dim3((nblk + q0 - 1) / q0), dim3(WAVE), (size_t)q0 * X8_SLOT0, s, (const X8Item *)items, *a, base,
                        (const u32 *)cls_list, (const u32 *)(cls_count + 0), q0, X8_SLOT0);
+    hipLaunchKernelGGL(k8_dec_chain<true>, dim3((nblk + q1a - 1) / q1a), dim3(WAVE), (size_t)q1a * X8_SLOT1A, s, (const X8Item *)items, *a, base,
+                       (const u32 *)cls_list, (const u32 *)(cls_count + 1), q1a, X8_SLOT1A);
     hipLaunchKernelGGL(k8_dec_chain<true>, dim3((nblk + q1 - 1) / q1), dim3(WAVE), (size_t)q1 * X8_SLOT1, s, (const X8Item *)items, *a, base,
-                       (const u32 *)cls_list, (const u32 *)(cls_count + 1), q1, X8_SLOT1);
+                       (const u32 *)cls_list, (const u32 *)(cls_count + 2), q1, X8_SLOT1);
     hipLaunchKernelGGL(k8_dec_chain<false>, dim3((nblk + 15) / 16), dim3(WAVE), 0, s, (const X8Item *)items, *a, base,
-                       (const u32 *)cls_list, (const u32 *)(cls_count + 2), 16, 0u);
+                       (const u32 *)cls_list, (const u32 *)(cls_count + 3), 16, 0u);
 }

@@ -94,33 +94,53 @@ __device__ __forceinline__ u32 chain_encode(gcu8 *data, u32 n, gcu8 *image, u32 
 // 16-byte store (a completed half of the ring, or a dump slot nobody reads).
 // (ENC_RING_BYTES, r4x16_common.h: the ring + a 2-byte dump slot for lanes that do not emit, padded)
 #define ENC_LRCP_BYTES 16400u        // RCPTAB_ENTRIES dwords, padded to 16
-struct EncOut {
+// BYTE: rANS 4x8's renormalisation (rANS_byte.h:320-402: L = 2^23, up to TWO bytes per chain and step, 12-bit
+// frequencies) on the same pipeline, ring and flush - round 4; the unit of `written` / the ring is then the byte.
+template <bool BYTE>
+struct EncOutT {
     u8 *ring;            // LDS
-    u32 ring126;         // LDS address of the ring's last word slot
+    u32 ring126;         // LDS address of the ring's last slot (word 126 / byte 127)
     gu8 *send;           // scratch_end of the stream
     gu8 *dump;           // this lane's 16 bytes of the dump area
-    u32 written;         // words emitted by the quad so far
+    u32 written;         // words (bytes) emitted by the quad so far
     u32 flushed;         // 64-byte halves already read out of the ring
     u32 k, lane;
     bool active;
     u32x4 held;          // a half read out of the ring, stored one double-trip later
     gu8 *held_dst;
+    static constexpr u32 HALF_SHIFT = BYTE ? 6u : 5u;    // units per 64-byte half, as a shift
     // rANS_word.h:281-321 for one symbol; x is this lane's state.  pk = start | freq << 16.
     // q = x / freq < 2^21 once x < x_max, so q * (M - freq) is a 24-bit multiply (mod 2^32).
     __device__ __forceinline__ void step(u32 &x, bool live, u32 rcp, u32 pk, u32 bits)
     {
         const u32 f = pk >> 16, start = pk & 0xffffu;
-        // the compare's own lane mask, and-ed with the live lanes on the scalar side (a ballot of the
-        // combined predicate would be rebuilt through a select and a second compare)
-        const bool over = x >= (f << (31u - bits));
-        const u64 m = __ballot(over) & __ballot(live);
-        const u32 em = (u32)(m >> (lane & ~3u)) & 0xfu;
-        const bool emit = live && over;
-        const u32 j = written + __popc(em >> (k + 1));
-        const u32 j63 = emit ? (j & 63u) : ~0u;                          // -1: the dump slot at ring + 128
-        *(LAS u16 *)(unsigned long)(ring126 - 2u * j63) = (u16)x;
-        const u32 xs = emit ? x >> 16 : x;
-        written += __popc(em);
+        u32 xs;
+        if (BYTE) {
+            // x_max = ((2^23 >> 12) << 8) * f; one byte while x >= x_max, a second one if x >> 8 still is
+            const u32 x_max = f << 19;
+            const bool o1 = x >= x_max, o2 = (x >> 8) >= x_max;
+            const u64 lv = __ballot(live);
+            const u32 e1 = (u32)((__ballot(o1) & lv) >> (lane & ~3u)) & 0xfu, e2 = (u32)((__ballot(o2) & lv) >> (lane & ~3u)) & 0xfu;
+            const bool emit1 = live && o1, emit2 = live && o2;
+            const u32 j = written + __popc(e1 >> (k + 1)) + __popc(e2 >> (k + 1));
+            const u32 j1 = emit1 ? (j & 127u) : ~0u, j2 = emit2 ? ((j + 1u) & 127u) : ~0u;       // -1: the dump slot at ring + 128
+            *(LAS u8 *)(unsigned long)(ring126 - j1) = (u8)x;
+            *(LAS u8 *)(unsigned long)(ring126 - j2) = (u8)(x >> 8);
+            xs = emit2 ? x >> 16 : emit1 ? x >> 8 : x;
+            written += __popc(e1) + __popc(e2);
+        } else {
+            // the compare's own lane mask, and-ed with the live lanes on the scalar side (a ballot of the
+            // combined predicate would be rebuilt through a select and a second compare)
+            const bool over = x >= (f << (31u - bits));
+            const u64 m = __ballot(over) & __ballot(live);
+            const u32 em = (u32)(m >> (lane & ~3u)) & 0xfu;
+            const bool emit = live && over;
+            const u32 j = written + __popc(em >> (k + 1));
+            const u32 j63 = emit ? (j & 63u) : ~0u;                          // -1: the dump slot at ring + 128
+            *(LAS u16 *)(unsigned long)(ring126 - 2u * j63) = (u16)x;
+            xs = emit ? x >> 16 : x;
+            written += __popc(em);
+        }
         // exact x / f: Alverson reciprocal for f >= 2; f == 1 has rcp = 2^32 - 1 and shift 0, which
         // gives x - 1: the compare's carry puts the 1 back (an add-with-carry, no select)
         const u32 fm1 = f - 1u;
@@ -133,7 +153,7 @@ struct EncOut {
     // conditional form: copy out the half that has just been completed, if any
     __device__ __forceinline__ void flush()
     {
-        const bool due = active && (written >> 5) != flushed;
+        const bool due = active && (written >> HALF_SHIFT) != flushed;
         if (wave_any(due)) {
             if (due) {
                 const u32x4 v = *(const u32x4 *)(ring + ((flushed & 1u) ? 0u : 64u) + 16u * k);
@@ -146,7 +166,7 @@ struct EncOut {
     __device__ __forceinline__ void flush_pipelined()
     {
         *(GAS u32x4_unaligned *)held_dst = held;
-        const bool due = active && (written >> 5) != flushed;
+        const bool due = active && (written >> HALF_SHIFT) != flushed;
         held = *(const u32x4 *)(ring + ((flushed & 1u) ? 0u : 64u) + 16u * k);
         held_dst = due ? send - 64ull * (flushed + 1u) + 16u * k : dump;
         flushed += due ? 1u : 0u;
@@ -156,25 +176,31 @@ struct EncOut {
         *(GAS u32x4_unaligned *)held_dst = held;
         held_dst = dump;
     }
-    // the words still in the ring, then the four states (RansEncFlush in order 3,2,1,0, :482-485)
+    // the words (bytes) still in the ring, then the four states (RansEncFlush in order 3,2,1,0, :482-485)
     __device__ __forceinline__ u32 finish(u32 x)
     {
         flush();
-        const u32 first = 32u * flushed;
+        if (BYTE) { flush(); }                           // (a double trip of byte steps can complete two halves)
+        const u32 first = (BYTE ? 64u : 32u) * flushed;
         const u32 rem = active ? written - first : 0u;
         for (u32 i = k; wave_any(i < rem); i += 4) {
             if (i < rem) {
                 const u32 j = first + i;
-                *(gu16 *)(send - 2ull * (j + 1u)) = *(const u16 *)(ring + ((~j << 1) & 126u));
+                if (BYTE) send[-(long)(j + 1u)] = *(const u8 *)(ring + (127u - (j & 127u)));
+                else *(gu16 *)(send - 2ull * (j + 1u)) = *(const u16 *)(ring + ((~j << 1) & 126u));
             }
         }
-        if (active) *(gu32 *)(send - 2ull * written - 16 + 4 * k) = x;
-        return active ? 2 * written + 16 : 0;
+        if (active) {
+            if (BYTE) { gu8 *d = send - written - 16 + 4 * k; d[0] = (u8)x; d[1] = (u8)(x >> 8); d[2] = (u8)(x >> 16); d[3] = (u8)(x >> 24); }
+            else *(gu32 *)(send - 2ull * written - 16 + 4 * k) = x;
+        }
+        return active ? (BYTE ? written : 2 * written) + 16 : 0;
     }
 };
+typedef EncOutT<false> EncOut;
 
 // PK: packed rows (r4x16_common.h) and a reciprocal table of the 1,025 frequencies a 10-bit table can hold.
-template <bool PK>
+template <bool PK, bool BYTE = false>
 __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, u8 *ring, const u32 *lrcp, gcu8 *data, u32 n, u32 ns,
                                                    u32 bits, gcu8 *safe, gu8 *scratch_end, gu8 *dump, bool active, u32 lane)
 {
@@ -207,8 +233,8 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, u8 *ring, 
         u32x2 r = {rcpof(pk), pk};
         return r;
     };
-    EncOut o{ring, (u32)(unsigned long)(LAS u8 *)ring + 126u, scratch_end, dump, 0u, 0u, k, lane, active, {0, 0, 0, 0}, dump};
-    u32 x = RANS_LOW;
+    EncOutT<BYTE> o{ring, (u32)(unsigned long)(LAS u8 *)ring + (BYTE ? 127u : 126u), scratch_end, dump, 0u, 0u, k, lane, active, {0, 0, 0, 0}, dump};
+    u32 x = BYTE ? (1u << 23) : RANS_LOW;
     const u32 q = active ? n >> 2 : 0;
     const u32 tail = active ? n - 4 * q : 0;
 
@@ -335,6 +361,7 @@ __device__ __forceinline__ u32 chain_encode_o1_lds(const u8 *img_lds, u8 *ring, 
 // the one-row image (:442-459: step s codes group g = gtop - s, chain k takes byte 4g + k; the top
 // group may be partial).  A trip of four steps covers four whole groups = 16 contiguous bytes, of
 // which this lane uses byte k of each dword.
+template <bool BYTE = false>
 __device__ __forceinline__ u32 chain_encode_o0_pipe(const u8 *img_lds, u8 *ring, const u32 *lrcp, gcu8 *data, u32 n,
                                                     u32 bits, gcu8 *safe, gu8 *scratch_end, gu8 *dump, bool active, u32 lane)
 {
@@ -349,8 +376,8 @@ __device__ __forceinline__ u32 chain_encode_o0_pipe(const u8 *img_lds, u8 *ring,
         u32x2 r = {rcpof(pk), pk};
         return r;
     };
-    EncOut o{ring, (u32)(unsigned long)(LAS u8 *)ring + 126u, scratch_end, dump, 0u, 0u, k, lane, active, {0, 0, 0, 0}, dump};
-    u32 x = RANS_LOW;
+    EncOutT<BYTE> o{ring, (u32)(unsigned long)(LAS u8 *)ring + (BYTE ? 127u : 126u), scratch_end, dump, 0u, 0u, k, lane, active, {0, 0, 0, 0}, dump};
+    u32 x = BYTE ? (1u << 23) : RANS_LOW;
     const u32 Q = active ? n >> 2 : 0;                    // whole groups
     const u32 rem = active ? n & 3u : 0;                  // bytes of the partial top group
 

@@ -218,3 +218,62 @@ extern "C" int r4x16_enc_residency(u32 nsym, int order, int *streams_per_wave, i
     *streams_per_wave = 16; *waves_per_cu = 8;
     return 128;
 }
+
+// ---------------------------------------------------------------------------------------------
+// rANS 4x8 (include/rans4x8_hip.h): the chain kernel for images that fit LDS.  Round 4: the 4x16 encoder's software
+// pipeline (chain_encode_o1_lds / chain_encode_o0_pipe: input pieces, compact indices, cumulative pairs and reciprocals
+// fetched trips ahead, emitted bytes through the LDS ring, 16-byte stores) with rANS 4x8's byte renormalisation
+// (EncOutT<true>: up to two bytes per chain and step, rANS_byte.h:320-402) instead of round 2's step-at-a-time loop -
+// the streams, the quarter maps and the u16 cumulative image are the same for both codecs.  A workgroup of up to four
+// waves shares one LDS copy of the reciprocal table; qpw streams per workgroup, spw per wave.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k8_enc_chain_pipe(EncItem *items, const u32 *rcptab_, u8 *dump_, const u32 *list, const u32 *count,
+                                                         u32 slot_bytes, int qpw, int spw)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 lds[];
+    const u32 tid = threadIdx.x, lane = tid & (WAVE - 1), wq = lane >> 2;
+    const u32 quad = (tid >> 6) * (u32)spw + wq;                 // stream slot inside the workgroup
+    const int nmine = (int)count[0];
+    list += count[CLS_MAX];
+    if ((int)blockIdx.x * qpw >= nmine) return;
+    const int slot = (int)blockIdx.x * qpw + (int)quad;
+    const bool mine = wq < (u32)spw && quad < (u32)qpw && slot < nmine;
+    EncItem *I = &items[list[mine ? slot : (int)blockIdx.x * qpw]];
+    const bool active = mine && I->active;
+    gcu32 *rcptab = to_global(rcptab_);
+    gcu8 *data = (gcu8 *)I->data;
+    gu8 *send = (gu8 *)I->scratch_end;
+    const u32 n = I->n, ns = I->ns, order = active ? I->order : 2u;
+    u32 *lrcp = (u32 *)lds;
+    u8 *slots = lds + ENC_LRCP_BYTES;
+    for (u32 j = tid; j < RCPTAB_ENTRIES; j += blockDim.x) lrcp[j] = rcptab[j];
+    // each wave copies the images of its own quads (16-byte pieces)
+    const u64 my_img = active ? I->image : 0ull;
+    const u32 nbytes = active ? ENC_IMG_IDX + (order ? 2u * ns * (ns + 1u) : 2u * 257u) : 0u;
+    const u32 wq0 = (tid >> 6) * (u32)spw;
+    for (int qd = 0; qd < 16; qd++) {
+        const u64 src = __shfl(my_img, qd * 4);
+        const u32 nb = __shfl(nbytes, qd * 4);
+        if (!src) continue;
+        gcu32x4 *sp = (gcu32x4 *)src;
+        u32x4 *dd = (u32x4 *)(slots + (u64)(wq0 + qd) * slot_bytes);
+        for (u32 j = lane; j < ((nb + 15) >> 4); j += WAVE) dd[j] = sp[j];
+    }
+    __syncthreads();
+    const u32 sl = active ? quad : 0u;                         // (lanes without a stream read and write the LDS of stream 0)
+    const u8 *im = slots + (u64)sl * slot_bytes;
+    u8 *ring = slots + (u64)sl * slot_bytes + (slot_bytes - ENC_RING_BYTES);
+    gu8 *dump = to_global(dump_) + 16u * ((blockIdx.x * blockDim.x + tid) & (ENC_DUMP_BYTES / 16u - 1u));
+    u32 pay = chain_encode_o1_lds<false, true>(im, ring, lrcp, data, n, ns, 12u, (gcu8 *)rcptab, send, dump, order == 1, lane);
+    pay |= chain_encode_o0_pipe<true>(im, ring, lrcp, data, n, 12u, (gcu8 *)rcptab, send, dump, order == 0, lane);
+    if (active && (lane & 3) == 0) I->pay_len = pay;
+}
+extern "C" void r4x8_enc_chain_launch(EncItem *items, const u32 *rcptab, u8 *dump, const u32 *list, const u32 *count, int nblk, u32 slot_bytes,
+                                      int qpw, int spw, hipStream_t s)
+{
+    if (r4x16_first_on_device(32u))
+        (void)hipFuncSetAttribute((const void *)k8_enc_chain_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    const int waves = (qpw + spw - 1) / spw;
+    hipLaunchKernelGGL(k8_enc_chain_pipe, dim3((nblk + qpw - 1) / qpw), dim3(WAVE * waves), ENC_LRCP_BYTES + (size_t)qpw * slot_bytes, s,
+                       items, rcptab, dump, list, count, slot_bytes, qpw, spw);
+}

@@ -1981,111 +1981,12 @@ __device__ __forceinline__ u32 chain_encode8(gcu8 *data, u32 n, gcu8 *image, u32
     return active ? written + 16 : 0;
 }
 
-// The same walk with the image and the reciprocal table in LDS and the input read in 16-byte windows two windows ahead
-// (the first version fetched symbol, index, cumulative pair and reciprocal with four loads through L2 that depended on
-// each other, 550 ns per step); the table data of a symbol is fetched one step before it is coded.
-#define X8E_LRCP_BYTES 16400u                                         // RCPTAB_ENTRIES dwords, padded to 16
-template <int ORDER>
-__device__ __forceinline__ u32 chain_encode8_lds(gcu8 *data, u32 n, const u8 *img_lds, u32 ns, const u32 *lrcp, gu8 *scratch_end,
-                                                 u32 room, bool active, u32 lane)
-{
-    const u32 k = lane & 3;
-    const u32 ibase = (u32)(unsigned long)(LAS const u8 *)img_lds, cbase = ibase + ENC_IMG_IDX;
-    auto idx_of = [&](u32 b) -> u32 { return *(LAS const u8 *)(unsigned long)(ibase + (b & 0xffu)); };
-    auto cum16 = [&](u32 i) -> u32 { return *(LAS const u16 *)(unsigned long)(cbase + 2u * i); };
-    const u32 rs = ns + 1;
-    u32 x = X8_LOW_E;
-    u32 written = 0;
-    u32 nsteps, first, p;
-    const u32 q = n >> 2;
-    if (ORDER == 0) {
-        const u32 gtop = n ? (n - 1) >> 2 : 0;
-        nsteps = n ? gtop + 1 : 0;
-        first = (4 * gtop + k < n) ? 0 : 1;
-        p = 4 * (gtop - (first ? 1 : 0)) + k;
-    } else {
-        const u32 tail = n - 4 * q;
-        nsteps = tail + q;
-        first = (k == 3) ? 0 : tail;
-        p = (k == 3) ? n - 1 : k * q + q - 1;
-    }
-    if (!active) { nsteps = 0; first = 0; }
-    const bool any = nsteps > first;
-    // input bytes: three 16-byte aligned windows, the one holding the byte wanted and the two below it
-    const u64 a0 = (u64)data;
-    u64 wa = any ? (a0 + p) & ~15ull : 0ull;                          // address of window 0
-    auto load_win = [&](u64 at) -> u32x4 {
-        u32x4 v = {0, 0, 0, 0};
-        if (any && at + 16 > a0 && at < a0 + n) v = *(gcu32x4 *)at;   // (an aligned piece that holds a byte of the input)
-        return v;
-    };
-    u32x4 w0 = load_win(wa), w1 = load_win(wa - 16), w2 = load_win(wa - 32);
-    auto byte_at = [&](u32 pos) -> u32 {                              // pos descends: at most one window step per call
-        const u64 at = a0 + pos;
-        if (at < wa) { w0 = w1; w1 = w2; wa -= 16; w2 = load_win(wa - 32); }
-        const u32 o = (u32)(at - wa);
-        const u32 lo = (o & 4u) ? w0.y : w0.x, hi = (o & 4u) ? w0.w : w0.z;
-        return (((o & 8u) ? hi : lo) >> (8u * (o & 3u))) & 0xffu;
-    };
-    const u32 stride = ORDER == 0 ? 4u : 1u;
-    // symbol s (cur), the one coded after it (nxt) and, fetched one step early, the table data of `cur`
-    u32 cur = 0, nxt = 0, pk = 0, rcp = 0;
-    u32 togo = any ? nsteps - first : 0;                              // symbols this chain still has to code
-    auto table_of = [&](u32 sym, u32 ctx, u32 &pk_, u32 &rcp_) {
-        const u32 i = (ORDER == 0 ? 0u : ctx * rs) + sym;
-        const u32 c0 = cum16(i), c1 = cum16(i + 1);
-        const u32 f = (c1 - c0) & 0xffffu;
-        pk_ = c0 | (f << 16);
-        rcp_ = lrcp[f < RCPTAB_ENTRIES - 1u ? f : RCPTAB_ENTRIES - 1u];
-    };
-    if (any) {
-        cur = idx_of(byte_at(p));
-        if (togo > 1) nxt = idx_of(byte_at(p - stride));
-        table_of(cur, togo > 1 ? nxt : 0u, pk, rcp);                   // the last symbol of an order-1 chain is coded in context 0
-    }
-    for (u32 s = 0; wave_any(s < nsteps); s++) {
-        const bool live = s >= first && s < nsteps;
-        // the symbol after next and the next one's table data: requested now, used a step later
-        u32 nn = 0, pk_n = 0, rcp_n = 0;
-        if (live && togo > 1) {
-            if (togo > 2) nn = idx_of(byte_at(p - 2 * stride));
-            table_of(nxt, togo > 2 ? nn : 0u, pk_n, rcp_n);
-        }
-        bool e1 = false, e2 = false;
-        if (live) {
-            const u32 x_max = (pk >> 16) << 19;                                  // rANS_byte.h:217 (f = 4096: 2^31)
-            e1 = x >= x_max;
-            e2 = (x >> 8) >= x_max;
-        }
-        const u32 m1 = quad_ballot(e1, lane), m2 = quad_ballot(e2, lane);
-        if (e1) {
-            const u32 at = written + __popc(m1 >> (k + 1)) + __popc(m2 >> (k + 1));
-            if (at + 2 <= room) {                                                // (never false for data the bound covers)
-                scratch_end[-(long)(at + 1)] = (u8)x;
-                if (e2) scratch_end[-(long)(at + 2)] = (u8)(x >> 8);
-            }
-            x >>= e2 ? 16 : 8;
-        }
-        written += __popc(m1) + __popc(m2);
-        if (live) {
-            x = enc_advance(x, rcp, pk, 12);
-            cur = nxt; nxt = nn; pk = pk_n; rcp = rcp_n;
-            p -= stride;
-            togo--;
-        }
-    }
-    // RansEncFlush x4 in the order 3,2,1,0 (:199-202): state 0 ends up lowest in memory
-    if (active && written + 16 <= room) {
-        gu8 *dst = scratch_end - written - 16 + 4 * k;
-        dst[0] = (u8)x; dst[1] = (u8)(x >> 8); dst[2] = (u8)(x >> 16); dst[3] = (u8)(x >> 24);
-    }
-    return active ? written + 16 : 0;
-}
-
+// (round 2's LDS form of this walk - image and reciprocal table in LDS, input in 16-byte windows - went in round 4: the
+//  streams whose images fit LDS now run on the 4x16 encoder's pipeline, r4x16_enc_chain.hip: k8_enc_chain_pipe)
 // streams by LDS need: class 0 - order-0 images (770 bytes), class 1 - order-1 images of up to 47 symbols, class 2 - the
-// rest (tables through L2); sixteen streams per wave, the reciprocal table once per workgroup
-#define X8E_SLOT0 784u
-#define X8E_SLOT1 4880u
+// rest (tables through L2)
+#define X8E_SLOT0 928u        // one-row image (770 bytes) + the ring of emitted bytes
+#define X8E_SLOT1 4880u       // order-1 images of up to 46 symbols (4,580 bytes) + the ring
 __global__ __launch_bounds__(256) void k8_enc_classify(const EncItem *items, int nitems, u32 *cls, u32 *count)
 {
     const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -2093,17 +1994,17 @@ __global__ __launch_bounds__(256) void k8_enc_classify(const EncItem *items, int
     const EncItem *I = &items[i];
     u32 c = CLS_NONE;
     if (I->active) {
-        const u32 need = ENC_IMG_IDX + (I->order ? 2u * I->ns * (I->ns + 1u) : 2u * 257u);
+        const u32 need = ENC_IMG_IDX + (I->order ? 2u * I->ns * (I->ns + 1u) : 2u * 257u) + ENC_RING_BYTES;     // (image + the ring of emitted bytes, r4x16_enc_chain.h)
         c = need <= X8E_SLOT0 ? 0u : need <= X8E_SLOT1 ? 1u : 2u;
         atomicAdd(&count[c], 1u);
     }
     cls[i] = c;
 }
 
-template <bool LDS_IMG>
-__global__ __launch_bounds__(WAVE) void k8_enc_chain(EncItem *items, const u32 *rcptab_, const u32 *list, const u32 *count, u32 room, u32 slot_bytes)
+// the chain kernel for images in LDS: r4x16_enc_chain.hip (k8_enc_chain_pipe: the 4x16 encoder's software pipeline with
+// rANS 4x8's byte renormalisation); images too large for LDS keep the general form:
+__global__ __launch_bounds__(WAVE) void k8_enc_chain_gm(EncItem *items, const u32 *rcptab_, const u32 *list, const u32 *count, u32 room)
 {
-    extern __shared__ __attribute__((aligned(16))) u8 lds[];
     const u32 lane = threadIdx.x, quad = lane >> 2;
     const int nmine = (int)count[0];
     list += count[CLS_MAX];
@@ -2116,29 +2017,9 @@ __global__ __launch_bounds__(WAVE) void k8_enc_chain(EncItem *items, const u32 *
     gcu8 *data = (gcu8 *)I->data;
     gu8 *send = (gu8 *)I->scratch_end;
     const u32 n = I->n, ns = I->ns, order = active ? I->order : 2u;
-    u32 pay;
-    if (LDS_IMG) {
-        u32 *lrcp = (u32 *)lds;
-        for (u32 j = lane; j < RCPTAB_ENTRIES; j += WAVE) lrcp[j] = rcptab[j];
-        const u64 my_img = active ? I->image : 0ull;
-        const u32 nbytes = active ? ENC_IMG_IDX + (order ? 2u * ns * (ns + 1u) : 2u * 257u) : 0u;
-        for (int qd = 0; qd < 16; qd++) {
-            const u64 src = __shfl(my_img, qd * 4);
-            const u32 nb = __shfl(nbytes, qd * 4);
-            if (!src) continue;
-            gcu32x4 *sp = (gcu32x4 *)src;
-            u32x4 *dd = (u32x4 *)(lds + X8E_LRCP_BYTES + (u64)qd * slot_bytes);
-            for (u32 j = lane; j < ((nb + 15) >> 4); j += WAVE) dd[j] = sp[j];
-        }
-        __syncthreads();
-        const u8 *im = lds + X8E_LRCP_BYTES + (u64)quad * slot_bytes;
-        pay = chain_encode8_lds<1>(data, n, im, ns, lrcp, send, room, order == 1, lane);
-        pay |= chain_encode8_lds<0>(data, n, im, ns, lrcp, send, room, order == 0, lane);
-    } else {
-        gcu8 *im = (gcu8 *)I->image;
-        pay = chain_encode8<1>(data, n, im, ns, rcptab, send, room, order == 1, lane);
-        pay |= chain_encode8<0>(data, n, im, ns, rcptab, send, room, order == 0, lane);
-    }
+    gcu8 *im = (gcu8 *)I->image;
+    u32 pay = chain_encode8<1>(data, n, im, ns, rcptab, send, room, order == 1, lane);
+    pay |= chain_encode8<0>(data, n, im, ns, rcptab, send, room, order == 0, lane);
     if (active && (lane & 3) == 0) I->pay_len = pay;
 }
 
@@ -2168,6 +2049,8 @@ __global__ __launch_bounds__(FINISH_THREADS) void k8_enc_finish(BatchArgs a, Enc
 
 extern "C" void r4x16_launch_cls_group(const u32 *cls, int nitems, u32 *count, u32 *list, hipStream_t s);   // r4x16_decode.hip
 extern "C" void r4x16_launch_cls_zero(u32 *count, hipStream_t s);
+extern "C" void r4x8_enc_chain_launch(EncItem *items, const u32 *rcptab, u8 *dump, const u32 *list, const u32 *count, int nblk, u32 slot_bytes,
+                                      int qpw, int spw, hipStream_t s);    // r4x16_enc_chain.hip
 extern "C" void r4x8_launch_encode(const BatchArgs *a, const EncWs *ws, int base, int nblk, hipStream_t s)
 {
     if (r4x16_first_on_device(8u))
@@ -2178,14 +2061,11 @@ extern "C" void r4x8_launch_encode(const BatchArgs *a, const EncWs *ws, int base
     r4x16_launch_cls_zero(ws->sched.cnt, s);
     hipLaunchKernelGGL(k8_enc_classify, dim3((nblk + 255) / 256), dim3(256), 0, s, (const EncItem *)ws->items, nblk, ws->sched.key, ws->sched.cnt);
     r4x16_launch_cls_group(ws->sched.key, nblk, ws->sched.cnt, ws->sched.list, s);
-    if (r4x16_first_on_device(32u))
-        (void)hipFuncSetAttribute((const void *)k8_enc_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
-    const int grid = (nblk + 15) / 16;
-    hipLaunchKernelGGL(k8_enc_chain<true>, dim3(grid), dim3(WAVE), X8E_LRCP_BYTES + 16 * X8E_SLOT0, s, ws->items, ws->rcptab,
-                       (const u32 *)ws->sched.list, (const u32 *)(ws->sched.cnt + 0), room, X8E_SLOT0);
-    hipLaunchKernelGGL(k8_enc_chain<true>, dim3(grid), dim3(WAVE), X8E_LRCP_BYTES + 16 * X8E_SLOT1, s, ws->items, ws->rcptab,
-                       (const u32 *)ws->sched.list, (const u32 *)(ws->sched.cnt + 1), room, X8E_SLOT1);
-    hipLaunchKernelGGL(k8_enc_chain<false>, dim3(grid), dim3(WAVE), 0, s, ws->items, ws->rcptab,
-                       (const u32 *)ws->sched.list, (const u32 *)(ws->sched.cnt + 2), room, 0u);
+    // class 0: one-row images (order 0), 4 waves x 16 streams; class 1: order-1 images of up to 46 symbols, 30 streams
+    // in four waves beside the one reciprocal table (16,400 + 30 x 4,880 = 162,800 bytes); class 2: tables through L2
+    r4x8_enc_chain_launch(ws->items, ws->rcptab, ws->dump, ws->sched.list, ws->sched.cnt + 0, nblk, X8E_SLOT0, 64, 16, s);
+    r4x8_enc_chain_launch(ws->items, ws->rcptab, ws->dump, ws->sched.list, ws->sched.cnt + 1, nblk, X8E_SLOT1, 30, 8, s);
+    hipLaunchKernelGGL(k8_enc_chain_gm, dim3((nblk + 15) / 16), dim3(WAVE), 0, s, ws->items, ws->rcptab,
+                       (const u32 *)ws->sched.list, (const u32 *)(ws->sched.cnt + 2), room);
     hipLaunchKernelGGL(k8_enc_finish, dim3(nblk), dim3(FINISH_THREADS), 0, s, *a, *ws, base, room);
 }
