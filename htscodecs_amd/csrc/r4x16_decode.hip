@@ -3317,7 +3317,7 @@ __device__ __forceinline__ u32 chain_decode8_lds(const u8 *img_lds, u32 nsym, u8
 // wave; class 1 - images up to X8_SLOT1 (order 1, up to 50 symbols: the quality alphabets), 12 per wave; class 2 - the
 // rest, tables through L2
 #define X8_SLOT0 (IMG_O0_BYTES + X8_RING)
-#define X8_SLOT1A 5360u      // round 4: up to 46 symbols (the quality alphabets) - ten per wave, THREE waves per CU (30 streams)
+#define X8_SLOT1A 5456u      // round 4: up to 47 symbols (the 45-46 of the quality alphabets and the flagged extra one) - fifteen per wave, two waves per CU (30 streams)
 #define X8_SLOT1 6416u
 __global__ __launch_bounds__(256) void k8_classify(const X8Item *items, int nitems, u32 *cls, u32 *count)
 {
@@ -3402,7 +3402,14 @@ extern "C" void r4x8_launch_decode(const BatchArgs *a, u8 *ws, int base, int nbl
     hipLaunchKernelGGL(k8_classify, dim3((nblk + 255) / 256), dim3(256), 0, s, (const X8Item *)items, nblk, cls, cls_count);
     r4x16_launch_cls_group(cls, nblk, cls_count, cls_list, s);
     if (r4x16_first_on_device(16u)) lds_limit((const void *)k8_dec_chain<true>, 163840);
-    const int q0 = 16, q1a = 10, q1 = 12;
+#ifdef X8_EXP
+    const int q0 = getenv("X8D_Q0") ? atoi(getenv("X8D_Q0")) : 16, q1a = getenv("X8D_Q1A") ? atoi(getenv("X8D_Q1A")) : 15, q1 = 12;
+#else
+    // (measured, tools/ab_x8.sh, 11,520 x 1 MiB q40: a round takes ~58 ms whatever the wave holds - 12, 14 or 15 streams in
+    //  each of two waves per CU: 100 GB/s; 8 x 3 waves: 87; 10 per wave does NOT make three waves: 54,560 bytes round up
+    //  past a third of the LDS - so the class holds as many streams as two waves can: 2 x 15 x 5,456 = 163,680 bytes)
+    const int q0 = 16, q1a = 15, q1 = 12;
+#endif
     hipLaunchKernelGGL(k8_dec_chain<true>, dim3((nblk + q0 - 1) / q0), dim3(WAVE), (size_t)q0 * X8_SLOT0, s, (const X8Item *)items, *a, base,
                        (const u32 *)cls_list, (const u32 *)(cls_count + 0), q0, X8_SLOT0);
     hipLaunchKernelGGL(k8_dec_chain<true>, dim3((nblk + q1a - 1) / q1a), dim3(WAVE), (size_t)q1a * X8_SLOT1A, s, (const X8Item *)items, *a, base,

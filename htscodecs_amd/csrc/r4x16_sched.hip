@@ -154,7 +154,15 @@ void sched_assign_queues(SchedPlan &plan, const int *todo_cls, int ntodo, int nq
         launch_order[j] = k;                             // (sorted: the used classes come first, the longest first)
         int q = 0;
         if (key(k) > 0.0) { for (int i = 1; i < nq; i++) if (load[i] < load[q]) q = i; load[q] += key(k); floor_q[q] += fl[k]; }
-        else q = rr++ % nq;                              // classes the last batch did not use: in turn
+        else {
+            // Classes the last batch did not use: in turn BEHIND the used classes, on their streams only.  On a stream of its
+            // own an empty launch starts together with the used ones, and where its workgroups happen to be placed first
+            // (they ask for a whole CU's LDS and leave at once) the dispatcher gives a used class's workgroup a seat beside
+            // another one instead: 4,096 x 1 MiB blocks encoded in 26.5 or 38.6 ms, by the process (gpurun_out/r04_bim_kt*).
+            int usedq[R4_FORK_STREAMS + 1], nu = 0;
+            for (int i = 0; i < nq; i++) if (load[i] > 0.0) usedq[nu++] = i;
+            q = nu ? usedq[rr++ % nu] : rr++ % nq;
+        }
         queue_of_todo[k] = (u8)q;
     }
     // Side by side or one after the other?  Side by side hides the classes' chain latencies behind each other but costs

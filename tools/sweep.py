@@ -10,6 +10,8 @@ import bench
 def run(nblk, bs, name, order, reps=2):
     dev = torch.device("cuda", 0)
     dc = H.DeviceCodec(0)
+    for kv in filter(None, os.environ.get("OPTS", "").split(",")):      # OPTS=name=value,... : options of this context
+        k, v = kv.split("="); dc.set_option(k, int(v))
     d_in, in_off, in_size = bench.build_batch(torch, dev, name, nblk, bs, 0)
     cap = H.rans_compress_bound_4x16(bs, order); slot = (cap + 255) // 256 * 256
     d_comp = torch.zeros(nblk * slot, dtype=torch.uint8, device=dev)
