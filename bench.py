@@ -407,6 +407,8 @@ def hetero_run(torch, H, dc, dev, total_bytes, uniform=None, reps=2, check=64, s
         same += 1
     tot = int(sizes.sum())
     be, bd = min(te), min(td)
+    if os.environ.get("HETERO_VERBOSE"):
+        print("hetero passes: enc ms", [round(x, 1) for x in te], "dec ms", [round(x, 1) for x in td], file=sys.stderr)
     return {"blocks": n, "bytes": tot, "sizes": "uniform %d" % uniform if uniform else "log-uniform 4096..1048576",
             "texts": "q4/q8/q40+dir by b mod 3", "orders": "drawn from %s" % (HETERO_ORDERS,),
             "enc_ms": round(be, 3), "dec_ms": round(bd, 3),

@@ -20,6 +20,7 @@ static const struct { const char *name, *env; long dflt; } OPT_TAB[OPT_COUNT] = 
     /* OPT_SCHED_CLAIM       */ {"sched_claim", "R4X16_SCHED_CLAIM", 1},
     /* OPT_SCHED_CONCURRENT  */ {"sched_concurrent", "R4X16_SCHED_CONCURRENT", 1},
     /* OPT_SCHED_TRACE       */ {"sched_trace", "R4X16_SCHED_TRACE", 0},
+    /* OPT_SCHED_LEARN       */ {"sched_learn", "R4X16_SCHED_LEARN", 2},
     /* OPT_MAX_WS_MB         */ {"max_workspace_mb", "R4X16_MAX_WS_MB", 160 << 10},
     /* OPT_HOST_STRIPE_DEV   */ {"host_stripe_dev", "R4X16_HOST_STRIPE_DEV", 1},
     /* OPT_HOST_PIPE_MB      */ {"host_pipe_mb", "R4X16_HOST_PIPE_MB", 64},

@@ -2775,6 +2775,7 @@ static void launch_dec_chain_of(const DecWs *ws, const DecItem *items, int nitem
     {
         int cls_of[CLS_MAX];
         for (int k = 0; k < ntodo; k++) cls_of[k] = (int)todo[k].ci;
+        if (hint) hint->learn = (o->v[OPT_SCHED_LEARN] & 2) != 0;
         sched_assign_queues(plan, cls_of, ntodo, nq, hint, qof, lorder, (hint && hint->work && o->v[OPT_SCHED_TRACE]) ? "decode" : nullptr);
         for (int k = 0; k < ntodo; k++) plan.queue[todo[k].ci] = qof[k];
     }
@@ -3402,14 +3403,10 @@ extern "C" void r4x8_launch_decode(const BatchArgs *a, u8 *ws, int base, int nbl
     hipLaunchKernelGGL(k8_classify, dim3((nblk + 255) / 256), dim3(256), 0, s, (const X8Item *)items, nblk, cls, cls_count);
     r4x16_launch_cls_group(cls, nblk, cls_count, cls_list, s);
     if (r4x16_first_on_device(16u)) lds_limit((const void *)k8_dec_chain<true>, 163840);
-#ifdef X8_EXP
-    const int q0 = getenv("X8D_Q0") ? atoi(getenv("X8D_Q0")) : 16, q1a = getenv("X8D_Q1A") ? atoi(getenv("X8D_Q1A")) : 15, q1 = 12;
-#else
-    // (measured, tools/ab_x8.sh, 11,520 x 1 MiB q40: a round takes ~58 ms whatever the wave holds - 12, 14 or 15 streams in
+    // (measured with the shape as a launch parameter, gpurun_out/r04_ab_x8*.txt, 11,520 x 1 MiB q40: a round takes ~58 ms whatever the wave holds - 12, 14 or 15 streams in
     //  each of two waves per CU: 100 GB/s; 8 x 3 waves: 87; 10 per wave does NOT make three waves: 54,560 bytes round up
     //  past a third of the LDS - so the class holds as many streams as two waves can: 2 x 15 x 5,456 = 163,680 bytes)
     const int q0 = 16, q1a = 15, q1 = 12;
-#endif
     hipLaunchKernelGGL(k8_dec_chain<true>, dim3((nblk + q0 - 1) / q0), dim3(WAVE), (size_t)q0 * X8_SLOT0, s, (const X8Item *)items, *a, base,
                        (const u32 *)cls_list, (const u32 *)(cls_count + 0), q0, X8_SLOT0);
     hipLaunchKernelGGL(k8_dec_chain<true>, dim3((nblk + q1a - 1) / q1a), dim3(WAVE), (size_t)q1a * X8_SLOT1A, s, (const X8Item *)items, *a, base,

@@ -78,7 +78,7 @@ struct R4Fork {
 // nothing on a call path reads the environment.  The launchers take the calling context's options as an argument.
 enum R4Opt {
     OPT_DEC_DIRECT, OPT_ENC_DIRECT, OPT_BACK_WG_PER_CU, OPT_DEC_MID, OPT_DEC_SHORT_RING,
-    OPT_SCHED_SORT, OPT_SCHED_CLAIM, OPT_SCHED_CONCURRENT, OPT_SCHED_TRACE, OPT_MAX_WS_MB,
+    OPT_SCHED_SORT, OPT_SCHED_CLAIM, OPT_SCHED_CONCURRENT, OPT_SCHED_TRACE, OPT_SCHED_LEARN, OPT_MAX_WS_MB,
     OPT_HOST_STRIPE_DEV, OPT_HOST_PIPE_MB, OPT_HOST_THREADS, OPT_HOST_LANES, OPT_HOST_SLAB_MIN_MB,
     OPT_HOST_DEC_SLABS, OPT_HOST_ENC_SLABS, OPT_HOST_PACK, OPT_HOST_TRACE,
     OPT_DEC_QPW, OPT_DEC_QPW_SMALL, OPT_DEC_QPW_PK, OPT_DEC_QPW_DIR,

@@ -149,6 +149,7 @@ extern "C" void r4x16_launch_enc_chain(const EncWs *ws, int nitems, hipStream_t 
     {
         int cls_of[CLS_MAX];
         for (int k = 0; k < ntodo; k++) cls_of[k] = (int)todo[k].ci;
+        if (hint) hint->learn = (o->v[OPT_SCHED_LEARN] & 1) != 0;
         sched_assign_queues(plan, cls_of, ntodo, nq, hint, qof, lorder, (hint && hint->work && o->v[OPT_SCHED_TRACE]) ? "encode" : nullptr);
         for (int k = 0; k < ntodo; k++) plan.queue[todo[k].ci] = qof[k];
     }

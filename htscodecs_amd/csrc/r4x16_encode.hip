@@ -2064,12 +2064,7 @@ extern "C" void r4x8_launch_encode(const BatchArgs *a, const EncWs *ws, int base
     // class 0: one-row images (order 0), 4 waves x 16 streams; class 1: order-1 images of up to 46 symbols, 30 streams
     // in four waves beside the one reciprocal table (16,400 + 30 x 4,880 = 162,800 bytes); class 2: tables through L2
     r4x8_enc_chain_launch(ws->items, ws->rcptab, ws->dump, ws->sched.list, ws->sched.cnt + 0, nblk, X8E_SLOT0, 64, 16, s);
-#ifdef X8_EXP
-    { const char *e1 = getenv("X8E_QPW"), *e2 = getenv("X8E_SPW");
-      r4x8_enc_chain_launch(ws->items, ws->rcptab, ws->dump, ws->sched.list, ws->sched.cnt + 1, nblk, X8E_SLOT1, e1 ? atoi(e1) : 30, e2 ? atoi(e2) : 8, s); }
-#else
     r4x8_enc_chain_launch(ws->items, ws->rcptab, ws->dump, ws->sched.list, ws->sched.cnt + 1, nblk, X8E_SLOT1, 30, 8, s);
-#endif
     hipLaunchKernelGGL(k8_enc_chain_gm, dim3((nblk + 15) / 16), dim3(WAVE), 0, s, ws->items, ws->rcptab,
                        (const u32 *)ws->sched.list, (const u32 *)(ws->sched.cnt + 2), room);
     hipLaunchKernelGGL(k8_enc_finish, dim3(nblk), dim3(FINISH_THREADS), 0, s, *a, *ws, base, room);

@@ -166,6 +166,7 @@ struct SchedHint {
     // smoothed over the batches of this context; 0 = not learned.  `pace`: bytes per 10 ns tick of one stream alone.
     float learned[CLS_MAX];
     float pace;
+    bool learn;              // option sched_learn: bit 0 the encoder's classes, bit 1 the decoder's
     bool side_by_side;       // how the last batch's launches were dealt out (rates are learned from side-by-side runs only)
 };                // pinned, [2 * CLS_MAX]: sums, then longest - and behind them the SCHED_CNT_WORDS
                                                 // dwords of SchedWs.cnt (counts, seats: for the trace); nullptr: no hint kept

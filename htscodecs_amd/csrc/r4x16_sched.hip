@@ -122,7 +122,7 @@ void sched_assign_queues(SchedPlan &plan, const int *todo_cls, int ntodo, int nq
         // What the class's launch really took last time, side by side with the others: work / (duration x its share of
         // the chip) is its rate as it runs in company - where it was bound by throughput, not by its longest chain.
         // Smoothed over the batches of the context.
-        if (cnt && hint->side_by_side && w > 0.0 && plan.wgs_full[c] && cnt[SCHED_SEATS + c] && hint->pace > 0.f) {
+        if (cnt && hint->learn && hint->side_by_side && w > 0.0 && plan.wgs_full[c] && cnt[SCHED_SEATS + c] && hint->pace > 0.f) {
             const u32 t0 = cnt[SCHED_TSTART + c], t1 = cnt[SCHED_TEND + c], seats = cnt[SCHED_SEATS + c] < plan.wgs_full[c] ? cnt[SCHED_SEATS + c] : plan.wgs_full[c];
             const double ticks = (double)(u32)(t1 - t0), frac = (double)seats / plan.wgs_full[c];
             // (bound by throughput: it took clearly longer than its longest chain takes alone)

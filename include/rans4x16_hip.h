@@ -184,6 +184,9 @@ int rans4x16_hip_set_dev_stripe_planes(rans4x16_hip_ctx *ctx, int planes, unsign
  *   sched_concurrent      1     R4X16_SCHED_CONCURRENT   chain kernels: the classes of a batch side by side on six streams,
  *                                                        each with its share of the chip (0: one after the other)
  *   sched_trace           0     R4X16_SCHED_TRACE        the last batch's classes, and how this one's launches are dealt out, on stderr
+ *   sched_learn           2     R4X16_SCHED_LEARN        bit 0 / bit 1: the encoder's / decoder's shares follow what the classes' launches of
+ *                                                        the context's earlier batches really took (measured: the decoder gains 10 % on a
+ *                                                        heterogeneous batch, the encoder's shares start to swing - so 2)
  *   max_workspace_mb  163840    R4X16_MAX_WS_MB          ceiling of the device workspace; larger batches are walked in chunks
  *   host_pipe_mb         64     R4X16_HOST_PIPE_MB       host batches of at least this many MiB (or 32 blocks) are pipelined
  *   host_threads          8     R4X16_HOST_THREADS       copier threads of the host pipeline
