@@ -342,9 +342,11 @@ def hetero_block(sizes, text, text_off, b):
     return np.ascontiguousarray(datagen.tile(HETERO_TEXTS[int(text[b])], int(sizes[b]), 0, offset=int(text_off[b])))
 
 
-def hetero_run(torch, H, dc, dev, total_bytes, uniform=None, reps=2, check=64, seed=2024, first_block=0, part=None):
+def hetero_run(torch, H, dc, dev, total_bytes, uniform=None, reps=5, check=64, seed=2024, first_block=0, part=None):
     """One heterogeneous (or comparison) batch through rans4x16_hip_{compress,uncompress}_dev with per-block orders:
-    best-of-`reps` HIP-event times of each direction, every block round-tripped, `check` blocks byte-compared with
+    best-of-`reps` HIP-event times of each direction (every pass's time is in the result too: the context's shares settle
+    over its first batches - option sched_learn - and the encoder's side-by-side classes vary by +-10 % from pass to pass),
+    every block round-tripped, `check` blocks byte-compared with
     the CPU checker.  part = (rank, world): the plan is the whole job's (world x total_bytes), cut into contiguous ranges
     of near-equal bytes by the library's own weighted partition (rans4x16_hip_partition); this rank runs its range."""
     share = None
@@ -412,6 +414,8 @@ def hetero_run(torch, H, dc, dev, total_bytes, uniform=None, reps=2, check=64, s
     return {"blocks": n, "bytes": tot, "sizes": "uniform %d" % uniform if uniform else "log-uniform 4096..1048576",
             "texts": "q4/q8/q40+dir by b mod 3", "orders": "drawn from %s" % (HETERO_ORDERS,),
             "enc_ms": round(be, 3), "dec_ms": round(bd, 3),
+            "enc_ms_passes": [round(x, 1) for x in te], "dec_ms_passes": [round(x, 1) for x in td],
+            "enc_ms_median": round(float(np.median(te)), 3), "dec_ms_median": round(float(np.median(td)), 3),
             "enc_GBps": round(tot / be / 1e6, 2), "dec_GBps": round(tot / bd / 1e6, 2),
             "both_GBps": round(tot / (be + bd) / 1e6, 2), "ratio": round(float(csz.sum()) / tot, 4),
             "roundtrip_ok": ok, "bytes_equal_cpu_blocks": same, "workspace_GB": round(dc.workspace_bytes() / 2**30, 2),
@@ -428,7 +432,9 @@ def hetero_leg(torch, H, dc, dev, total_bytes=16 << 30, first_block=0, part=None
     assert uni["roundtrip_ok"], "hetero leg (uniform 64 KiB): round trip"
     torch.cuda.empty_cache()
     return {"hetero": het, "uniform_64KiB": uni,
-            "enc_ratio": round(het["enc_GBps"] / uni["enc_GBps"], 3), "dec_ratio": round(het["dec_GBps"] / uni["dec_GBps"], 3)}
+            "enc_ratio": round(het["enc_GBps"] / uni["enc_GBps"], 3), "dec_ratio": round(het["dec_GBps"] / uni["dec_GBps"], 3),
+            "enc_ratio_median": round(uni["enc_ms_median"] * het["bytes"] / (het["enc_ms_median"] * uni["bytes"]), 3),
+            "dec_ratio_median": round(uni["dec_ms_median"] * het["bytes"] / (het["dec_ms_median"] * uni["bytes"]), 3)}
 
 
 def spawn_ranks(n):

@@ -495,7 +495,7 @@ __device__ __forceinline__ void wg_hist1(const u8 *data, u32 n, FP Fp0, u32 ns, 
         u32 prev = pi ? idx_of[p.before] : 0u;       // the first byte of the block is seen in context 0
 #pragma unroll
         for (int c = 0; c < 16; c++) {
-            atomicAdd(&Fp[(prev * ns + ci[c]) << csh], 1u);
+            atomicAdd(&Fp[(__umul24(prev, ns) + ci[c]) << csh], 1u);       // (24-bit multiply: full rate, see wg_hist1_range)
             prev = ci[c];
         }
     };
@@ -548,12 +548,21 @@ __device__ __forceinline__ void wg_hist1(const u8 *data, u32 n, FP Fp0, u32 ns, 
 // every other pass uses; the four pairs that are coded in context 0 (the first byte and the three quarter starts,
 // rANS_static4x16pr.c:720-723) are added there.  Returns true - provisional route only - if a byte was counted that is
 // not in the alphabet (outside the range, or in a gap of it).  LDS counters only; nsa * nsa <= 18 * FRONT_THREADS.
+// a * b + c for a, b < 2^24 in one full-rate instruction (the compiler splits the sum three ways - multiply, shift, v_add3 -
+// when it is written in C)
+__device__ __forceinline__ u32 mad24(u32 a, u32 b, u32 c) { u32 r; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ u32 lds_addr_of(const void *p) { return (u32)(unsigned long)(LAS const u8 *)p; }
+__device__ __forceinline__ void lds_inc(u32 byte_addr)
+{
+    __hip_atomic_fetch_add((LAS u32 *)(unsigned long)byte_addr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __device__ __forceinline__ bool wg_hist1_range(const u8 *data, u32 n, u32 *Fp0, u32 nsx, u32 copies, const EncShared &S, u32 lo, u32 nsa,
                                                bool prov, u32 tid)
 {
     const u32 csh = copies == 4 ? 2u : copies == 2 ? 1u : 0u;
     u32 *Fp = Fp0 + (tid & (copies - 1));
     const u32 top = nsa - 1, rsa = nsa | 1u;          // (odd row stride: an even one halves the banks a row pair can reach)
+    const u32 cs = csh + 2u, rowb = rsa << cs, fbase = lds_addr_of(Fp);
     const u32 full = n >> 4;
     struct Piece { u32x4 w; u32 before; };
     auto ld = [&](u32 pi) -> Piece {
@@ -571,11 +580,15 @@ __device__ __forceinline__ bool wg_hist1_range(const u8 *data, u32 n, u32 *Fp0, 
             ci[4 * c] = ix(ww[c] & 0xff); ci[4 * c + 1] = ix((ww[c] >> 8) & 0xff);
             ci[4 * c + 2] = ix((ww[c] >> 16) & 0xff); ci[4 * c + 3] = ix(ww[c] >> 24);
         }
-        u32 prev = ix(p.before);
+        // counter (prev, cur) of this thread's copy, as an LDS byte address: one 24-bit multiply-add for the row, one
+        // shift-add for the column (a plain `prev * rsa` is a 32-bit multiply, quarter rate: it was half of the loop's
+        // vector cycles - 472 instructions per 64 bytes, 64 of them v_mul_lo_u32)
+        u32 row = mad24(ix(p.before), rowb, fbase);                             // the row of the byte before, as an address
 #pragma unroll
         for (int c = 0; c < 16; c++) {
-            if (c || pi) atomicAdd(&Fp[(prev * rsa + ci[c]) << csh], 1u);       // (the block's first byte: context 0, below)
-            prev = ci[c];
+            const u32 at = (ci[c] << cs) + row;
+            if (c || pi) lds_inc(at);                                           // (the block's first byte: context 0, below)
+            row = mad24(ci[c], rowb, fbase);
         }
     };
     const u32 T = FRONT_THREADS;
