@@ -116,7 +116,7 @@ static inline __host__ __device__ u32 img_bytes(u32 n, u32 rows) { return img_al
 // the quality alphabets the headline benchmark is made of.  LDS bytes per stream decide how many streams a CU
 // holds, and resident streams are the decoder's throughput, so these rows spend 10 bits per entry instead of 16:
 //
-//   alpha[s] (u16) additionally carries, in bits 10..15, `first` of the row of context s: the index of that row's
+//   alpha[s] (u16) additionally carries, in bits 9..15, `first` + 2 of the row of context s: `first` = the index of that row's
 //   first symbol of non-zero frequency.
 //   A row is a run of dwords of three 10-bit fields at bit 0, 11 and 22 (bits 10 and 21 are zero: guard bits for
 //   a compare-free "field >= m" test, see lookup in r4x16_decode.hip).  Fields L[0..]:
@@ -125,9 +125,19 @@ static inline __host__ __device__ u32 img_bytes(u32 n, u32 rows) { return img_al
 //   1024, a start cannot say where the last symbol ends).  Symbol first + c, c = #{j >= 1 : L[j] < m}, owns slot m;
 //   its range is L[c] + 1 .. L[c + 1].  Leading symbols of zero frequency (byte 0 is in every order-1 alphabet
 //   and in almost no row) are skipped through `first`; later ones repeat their predecessor's end.
-//       dword 0      : root  = L[12], L[24], L[36]       (which group of twelve)
-//       dword 1 + i  : L[3i], L[3i + 1], L[3i + 2]       (group g is dwords 1 + 4g .. 1 + 4g + 4)
-//   G = ceil(n / 12) groups, 4G + 2 dwords (4G + 1 unless n = 12G): 68 bytes for 46 symbols against 108 of the u16 rows.
+//       root         : L[12], L[24], L[36]               (which group of twelve)
+//       leaf dword i : L[3i], L[3i + 1], L[3i + 2]       (group g is leaf dwords 4g .. 4g + 4)
+//   Up to 48 symbols (round 4, "layout 2": what a step reads together sits together - the step is a lone wave's
+//   instruction stream, and every LDS instruction in it is four issue cycles and a wait):
+//       head[s], 8 bytes per context, IN PLACE OF alpha[]: dword 0 = the root of the row of context s, dword 1 = its
+//                alpha word (byte value, ROW_EMPTY, first + 2) - the two things a step needs of the symbol it has just
+//                decoded, in one 8-byte read;
+//       rows     the leaf dwords alone, 16 G bytes per row (16 more when n = 12 G: the dword L[12 G ..]), 16-byte
+//                aligned: a group is one 16-byte read and a dword.
+//   46 symbols: 368 + 46 x 64 = 3,312 bytes (layout 1, root in front of each row: 3,224), 3,584 with the word ring =
+//   fifteen streams in 42 LDS granules exactly; 67.2 -> 63.4 instructions and 6.1 -> 4.4 LDS operations per step,
+//   headline decode chain 97.3 -> 93.5 ms.
+//   49..96 symbols ("wide"): alpha[] and rows of root + leaf as before.
 // ---------------------------------------------------------------------------------------------
 #define PK_MAX_NSYM 48u                                  // one root dword: up to four groups of twelve
 #define PKW_MAX_NSYM 96u                                 // "wide" packed rows: up to eight groups, 16-byte root
@@ -139,8 +149,12 @@ static inline __host__ __device__ u32 pk_groups(u32 n) { return (n + 11u) / 12u;
 static inline __host__ __device__ u32 pk_root_bytes(u32 n) { return n > PK_MAX_NSYM ? 16u : 4u; }
 // (the last dword, L[12G ..], can only be selected when the alphabet fills its last group: left out otherwise, and
 //  that read runs into the next row's root or the word ring - as with the u16 rows' last dword)
-static inline __host__ __device__ u32 pk_row_bytes(u32 n) { return pk_root_bytes(n) + 4u + 16u * pk_groups(n) - (n % 12u ? 4u : 0u); }
-static inline __host__ __device__ u32 pk_img_bytes(u32 n) { return img_alpha_bytes(n) + n * pk_row_bytes(n); }
+static inline __host__ __device__ u32 pk_head_bytes(u32 n) { return n > PK_MAX_NSYM ? img_alpha_bytes(n) : (8u * n + 15u) & ~15u; }
+static inline __host__ __device__ u32 pk_row_bytes(u32 n)
+{
+    return n > PK_MAX_NSYM ? pk_root_bytes(n) + 4u + 16u * pk_groups(n) - (n % 12u ? 4u : 0u) : 16u * pk_groups(n) + (n % 12u ? 0u : 16u);
+}
+static inline __host__ __device__ u32 pk_img_bytes(u32 n) { return pk_head_bytes(n) + n * pk_row_bytes(n); }
 
 // ---------------------------------------------------------------------------------------------
 // Direct rows ("level 6"): the short-step route for batches that leave LDS to spare.  The rows above trade

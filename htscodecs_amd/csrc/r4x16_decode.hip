@@ -149,19 +149,14 @@ __device__ __forceinline__ u32 lookup_step_pk(u32 row, u32x2 rootv, u32x2 rootw,
         const u32 gneg = __popc((root + GM) & GB);            // 2 - #{L[12], L[24] < m}
         const bool r3 = root < (m << 22);                     // L[36] < m: the top field needs no guard
         g = (r3 ? 3u : 2u) - gneg;
-        ga = row + 4u + 16u * g;
+        ga = row + 16u * g;
     }
-#ifdef VAR_ORDER
-    // Issue order = reverse order of first use: the compiler writes an s_waitcnt per LDS result as it is first used
-    // (lgkmcnt counts down in issue order), and a lone wave pays four cycles for each.  With the dword that is used LAST
-    // requested FIRST, the wait for the first compare covers it too.
-    const u32 D4 = *(LAS const volatile u32 *)(unsigned long)(ga + 16u);
-    const u32x2 D01 = *(LAS const volatile u32x2_a4 *)(unsigned long)ga, D23 = *(LAS const volatile u32x2_a4 *)(unsigned long)(ga + 8u);
-    const u32 D0 = D01.x, D1 = D01.y, D2 = D23.x, D3 = D23.y;
-#else
-    const u32 D0 = img0.ld32(ga), D1 = img0.ld32(ga + 4), D2 = img0.ld32(ga + 8), D3 = img0.ld32(ga + 12),
-              D4 = img0.ld32(ga + 16);
-#endif
+    u32 D0, D1, D2, D3, D4;
+    if (WIDE) { D0 = img0.ld32(ga); D1 = img0.ld32(ga + 4); D2 = img0.ld32(ga + 8); D3 = img0.ld32(ga + 12); D4 = img0.ld32(ga + 16); }
+    else {
+        const u32x4 Dq = *(LAS const u32x4 *)(unsigned long)ga;          // the group: one 16-byte read (rows are 16-byte aligned)
+        D0 = Dq.x; D1 = Dq.y; D2 = Dq.z; D3 = Dq.w; D4 = img0.ld32(ga + 16);
+    }
     // dword of three.  A leaf dword holds L[3i + 1], L[3i + 2] in its guarded low fields and L[3i] in its TOP field, so
     // the pivots L[12g + 3], L[12g + 6], L[12g + 9] are tested without extraction: top field < m  <=>  dword < m << 22.
     const u32 m22 = m << 22;
@@ -184,16 +179,12 @@ __device__ __forceinline__ u32 lookup_step_pk(u32 row, u32x2 rootv, u32x2 rootw,
     const u32 off = (m + np) & 1023u;                         // m - start
     const u32 xs = x >> 10;
     x = __umul24(fm1, xs) + xs + off;                         // freq <= 1024, x >> 10 < 2^22: exact mod 2^32
-#ifndef VAR_NO_FIRST2
     // `first` arrives with the + 2 already in it (the image stores first + 2): two multiply-adds and a subtraction
     // instead of two multiplies, a three-way add, a subtraction and an add
     u32 t;
     asm("v_mad_u32_u24 %0, %1, 12, %2" : "=v"(t) : "v"(g), "v"(first));
     asm("v_mad_u32_u24 %0, %1, 3, %2" : "=v"(t) : "v"(q), "v"(t));
     return t - rneg;
-#else
-    return first + 12u * g + 3u * q + 2u - rneg;
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -301,7 +292,8 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     const u32 mask = (1u << look) - 1;
     constexpr bool PKD = LV == 1 || LV == 5, WIDE = LV == 5;       // packed rows (r4x16_common.h), with the 16-byte root
     static_assert(LV != 6 && LV != 10, "direct blocks and mid rows have their own loops: chain_decode_dir, chain_decode_mid");
-    const u32 rows = lds_addr(img_lds) + img_alpha_bytes(nsym), roww = PKD ? pk_row_bytes(nsym) : img_row_bytes(nsym);
+    constexpr bool PK2 = LV == 1;                                  // layout 2 of the packed rows: 8-byte head entries (root, alpha word)
+    const u32 rows = lds_addr(img_lds) + (PKD ? pk_head_bytes(nsym) : img_alpha_bytes(nsym)), roww = PKD ? pk_row_bytes(nsym) : img_row_bytes(nsym);
     const u32 nwords = BYTE ? words_len : words_len >> 1;  // units of the cursor: 16-bit words (bytes for rANS 4x8)
     const u32 below = (1u << k) - 1u;                      // quad lanes below this one
     constexpr u32 NQ = TRIP == 8 ? 4u : 2u, RB = 64u * NQ; // quarters and bytes of the ring
@@ -346,14 +338,14 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
     u32 row = rows, cursor = 0, bad = 0, t = 0;
     // root separators of `row`, read as soon as the row is known (one step ahead of their use,
     // so that this LDS round trip runs beside the renormalisation instead of after it)
-    u32x2 root = LV == 1 ? u32x2{img0.ld32(row), 0u} : img0.ld64(row);
+    u32x2 root = PK2 ? u32x2{img.ld32(0), 0u} : LV == 1 ? u32x2{img0.ld32(row), 0u} : img0.ld64(row);
     u32x2 root2 = WIDE ? img0.ld64(row + 8) : u32x2{0u, 0u};
     u32 acc = 0;                                          // order-1: the last (up to) 4 decoded bytes
     u32 a0 = 0, a1 = 0, a2 = 0, a3 = 0;                   // order-1: completed dwords not yet stored (a3 newest)
     u32 hdr = 0, hdr_even = 0;                            // order-1: alpha[] word of the symbol decoded last step
     u32 badb = 0;                                         // BYTE: the alpha words of every symbol decoded (for ROW_BAD)
-    if (ORDER == 1 && count) bad = img.ld16(0);
-    if (PKD) hdr = img.ld16(0);                           // packed rows: bits 9.. of the context's alpha word = its `first`
+    if (ORDER == 1 && count) bad = img.ld16(PK2 ? 4 : 0);
+    if (PKD) hdr = img.ld16(PK2 ? 4 : 0);                       // packed rows: bits 9.. of the context's alpha word = its `first`
 
     // Four steps per trip: one loop test, one store and one ring check per trip.  A trip in which
     // every stream of the wave is still running on all four chains and has at least 16 words left
@@ -372,14 +364,8 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
             // more than the extra read (measured: +12 % on the whole kernel per misaligned read and step).
             // (volatile: keeps the compiler from sinking these reads into a branch, which would put their
             //  latency back on the dependent path; explicit LDS pointer: a volatile generic access goes FLAT)
-#ifdef VAR_ORDER
-            const u32 d2 = *(lvcu32 *)(ring + ra + 8);                         // (requested first, used last: see lookup_step_pk)
-            const u32x2 d01 = *(LAS const volatile u32x2_a4 *)(ring + ra);     // one ds_read2_b32
-            const u32 d0 = d01.x, d1 = d01.y;
-#else
             const u32x2 d01 = *(LAS const volatile u32x2_a4 *)(ring + ra);     // one ds_read2_b32
             const u32 d0 = d01.x, d1 = d01.y, d2 = *(lvcu32 *)(ring + ra + 8);
-#endif
 
             u32 xn = x;
             RootSpec spec;
@@ -392,22 +378,19 @@ __device__ __forceinline__ u32 chain_decode_lds(const u8 *img_lds, u32 nsym, u8 
                 s = lookup_step_pk<WIDE>(row, root, root2, hdr >> PK_FIRST_SHIFT, xn);
                 // the next row's root: requested as soon as the symbol is known, used at the top of the next step
                 asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(rown1) : "v"(s), "v"(roww), "v"(rows));   // (the compiler's own choice is a 64-bit multiply-add)
-#ifdef VAR_ORDER
-                hn_first = *(LAS const volatile u16 *)(unsigned long)(lds_addr(img_lds) + 2u * s);   // (before the root: the root is used first)
-#endif
                 if (WIDE) {
                     rootn1 = *(LAS const volatile u32x2_a4 *)(unsigned long)rown1;
                     rootn2 = *(LAS const volatile u32x2_a4 *)(unsigned long)(rown1 + 8u);
+                } else if (PK2) {
+                    // the head entry of the symbol just decoded: the root of ITS row and its alpha word, one 8-byte read
+                    const u32x2 h = *(LAS const volatile u32x2 *)(unsigned long)(lds_addr(img_lds) + 8u * s);
+                    rootn1.x = h.x; hn_first = h.y;
                 } else
                     rootn1.x = *(LAS const volatile u32 *)(unsigned long)rown1;
             } else {
                 s = lookup_step<(PKD ? 2 : LV)>(img0, row, look, mask, xn, LV == 2 ? &root : nullptr, speculate ? &spec : nullptr);
             }
-#ifdef VAR_ORDER
-            const u32 hn = PKD ? hn_first : img.ld16(2 * s);
-#else
-            const u32 hn = img.ld16(2 * s);               // byte value | ROW_EMPTY of the new context
-#endif
+            const u32 hn = PK2 ? hn_first : img.ld16(2 * s);   // byte value | ROW_EMPTY of the new context
             if (BYTE) badb |= (FAST || live) ? hn : 0u;   // rANS 4x8: ROW_BAD on ANY decoded symbol, the last one included
             u32 byte0 = 0;
             if (ORDER == 0) {
@@ -889,7 +872,7 @@ __device__ void write_row(u8 *rowp, const FrontShared &S, u32 n, bool empty, u32
 
 // Whole wave: one packed row (r4x16_common.h, "level 1") from S.cum / S.first.  An empty row is all 1023: any
 // lookup lands on its first symbol and the stream is failed through the ROW_EMPTY flag of that context.
-__device__ void write_row_pk(u8 *rowp, const FrontShared &S, u32 n, bool empty, u32 lane)
+__device__ void write_row_pk(u8 *rowp, u8 *headp, const FrontShared &S, u32 n, bool empty, u32 lane)
 {
     const u32 first = S.first;
     auto L = [&](u32 j) -> u32 {
@@ -897,6 +880,11 @@ __device__ void write_row_pk(u8 *rowp, const FrontShared &S, u32 n, bool empty, 
         const u32 idx = first + j;
         return idx <= n ? (u32)S.cum[idx] - 1u : 1023u;       // cum[first + 1 ..] >= 1: `first` has a frequency
     };
+    if (n <= PK_MAX_NSYM) {                               // layout 2: the root in the context's head entry, the row = leaf dwords only
+        if (lane == 0) ((u32 *)headp)[0] = L(12) | (L(24) << 11) | (L(36) << 22);
+        if (lane < pk_row_bytes(n) / 4u) { const u32 i = 3u * lane; ((u32 *)rowp)[lane] = L(i + 1) | (L(i + 2) << 11) | (L(i) << 22); }
+        return;
+    }
     const u32 ndw = pk_row_bytes(n) / 4u, rdw = pk_root_bytes(n) / 4u;
     if (lane < ndw) {
         u32 v;
@@ -1175,7 +1163,9 @@ __device__ void o1_tables(const u8 *in, ByteSrc &src, const u8 *tbuf, bool compr
                      s1_size >= mid_img_bytes(nsym) / 4u;
     const bool packed = !direct && !mid && bits == 10 && nsym >= PK_MIN_NSYM && nsym <= PKW_MAX_NSYM;
     const u32 stride = direct ? dir_blk_bytes(nsym, look) : mid ? mid_row_bytes(nsym) : packed ? pk_row_bytes(nsym) : img_row_bytes(nsym);
-    u8 *rows0 = img + img_alpha_bytes(nsym);
+    u8 *rows0 = img + (packed ? pk_head_bytes(nsym) : img_alpha_bytes(nsym));
+    const bool pk2 = packed && nsym <= PK_MAX_NSYM;       // the alpha word of context ci: in its 8-byte head entry
+    auto alpha_word = [&](u32 ci) -> u16 * { return pk2 ? (u16 *)(img + 8u * ci + 4u) : (u16 *)img + ci; };
 
     // Every row lists a frequency for each member of F0 (decode_freq_d :327-358): rank them once.
     if (lane == 0) {
@@ -1255,7 +1245,8 @@ __device__ void o1_tables(const u8 *in, ByteSrc &src, const u8 *tbuf, bool compr
                     if (total == 0) S.empty = 1;                       // :977-980
                 }
             }
-            ((u16 *)img)[ci] = (u16)(ctx | (S.empty ? ROW_EMPTY : 0u));
+            if (pk2) *(u32 *)(img + 8u * ci + 4u) = ctx | (S.empty ? ROW_EMPTY : 0u);
+            else ((u16 *)img)[ci] = (u16)(ctx | (S.empty ? ROW_EMPTY : 0u));
         }
         __syncthreads();
         if (!S.go) break;
@@ -1306,12 +1297,8 @@ __device__ void o1_tables(const u8 *in, ByteSrc &src, const u8 *tbuf, bool compr
         else if (mid)
             write_row_mid(rows0 + (u64)ci * stride, S, nsym, S.empty != 0, lane);
         else if (packed) {
-#ifndef VAR_NO_FIRST2
-            if (lane == 0) ((u16 *)img)[ci] |= (u16)(((S.empty ? 0u : S.first) + 2u) << PK_FIRST_SHIFT);     // (first + 2: lookup_step_pk)
-#else
-            if (lane == 0 && !S.empty) ((u16 *)img)[ci] |= (u16)(S.first << PK_FIRST_SHIFT);
-#endif
-            write_row_pk(rows0 + (u64)ci * stride, S, nsym, S.empty != 0, lane);
+            if (lane == 0) *alpha_word(ci) |= (u16)(((S.empty ? 0u : S.first) + 2u) << PK_FIRST_SHIFT);     // (first + 2: lookup_step_pk)
+            write_row_pk(rows0 + (u64)ci * stride, img + 8u * ci, S, nsym, S.empty != 0, lane);
         } else
             write_row(rows0 + (u64)ci * stride, S, nsym, S.empty != 0, lane);
         __syncthreads();
@@ -2575,7 +2562,8 @@ extern "C" void r4x16_launch_dec_front(const BatchArgs *a, const DecWs *ws, int 
 static const struct { u32 bytes; int qpw; int lv; } DEC_CLASSES[] = {
     // packed rows (level 1): 13..36 symbols in rows of up to 56 bytes, 37..48 of up to 72 (46 symbols: 68-byte rows,
     // 3,496 bytes with alphabet and ring: 3 x 15 streams per CU)
-    {1424, 16, 1}, {2448, 16, 1}, {3344, 16, 1}, {3496, 15, 1}, {3856, 13, 1},
+    // (layout 2: 46 symbols = 3,312 bytes of image, 3,584 with the ring: 15 streams = 42 LDS granules of 1,280 bytes exactly)
+    {1424, 16, 1}, {2448, 16, 1}, {3360, 16, 1}, {3584, 15, 1}, {3840, 14, 1}, {4128, 13, 1}, {4880, 11, 1},
     // wide packed rows (level 5): 49..96 symbols, rows of 84..148 bytes; three workgroups per CU
     {5520, 9, 5}, {7184, 7, 5}, {8912, 6, 5}, {10640, 5, 5}, {13200, 4, 5}, {14736, 3, 5},
     {656, 16, 2}, {1296, 16, 2}, {2576, 16, 2}, {3856, 16, 2}, {5008, 16, 2}, {5360, 10, 2}, {5392, 15, 2}, {6416, 12, 2},
@@ -2727,7 +2715,7 @@ static int dec_class_qpw(u32 ci, const R4Opts *o)
     const auto &c = DEC_CLASSES[ci];
     const int force_qpw = (int)o->v[OPT_DEC_QPW], force_small = (int)o->v[OPT_DEC_QPW_SMALL], force_pk = (int)o->v[OPT_DEC_QPW_PK],
               force_dir = (int)o->v[OPT_DEC_QPW_DIR];                                                    // tuning aids
-    int qpw = (c.lv == 1 && force_pk && c.bytes == 3496) ? force_pk :
+    int qpw = (c.lv == 1 && force_pk && (c.bytes == 3496 || c.bytes == 3584)) ? force_pk :
               c.lv != 2 ? c.qpw : (force_qpw && c.bytes == 5360) ? force_qpw : (force_small && c.bytes < 5360) ? force_small : c.qpw;
     if ((c.lv == 6 || c.lv == 7) && force_dir > 0 && qpw > force_dir) qpw = force_dir;
     return qpw;
