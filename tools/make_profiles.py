@@ -87,8 +87,12 @@ if os.path.exists(os.path.join(SRC, "hetero.jsonl")):
 if os.path.exists(os.path.join(SRC, "hetero_sched_trace.txt")):
     with open(os.path.join(DST, f"{tag}_hetero_sched_trace.txt"), "w") as f:
         f.write("".join(l for l in open(os.path.join(SRC, "hetero_sched_trace.txt")) if "Warning" not in l and "d_base" not in l and "amdgpu.ids" not in l))
+x8 = glob.glob(os.path.join(SRC, "x8stats", "**", "*kernel_stats.csv"), recursive=True)
+if x8:
+    shutil.copy(x8[0], os.path.join(DST, f"{tag}_4x8_kernel_stats.csv"))
 for name, dst in (("batch_sweep.jsonl", f"{tag}_batch_sweep.jsonl"), ("shapes.jsonl", f"{tag}_shapes.jsonl"),
-                  ("sq_small_summary.txt", f"{tag}_sq_one_block.txt")):
+                  ("sq_small_summary.txt", f"{tag}_sq_one_block.txt"), ("rate_4x8.txt", f"{tag}_4x8_rates.txt"),
+                  ("host_probe.txt", f"{tag}_host_probe.txt"), ("host_batch_rate.txt", f"{tag}_host_batch_rate.txt")):
     if os.path.exists(os.path.join(SRC, name)):
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, dst))
 print(json.dumps({k: v for k, v in traffic["kernels"].items()}, indent=1))
