@@ -137,7 +137,7 @@ int rans4x16_hip_uncompress_dev(rans4x16_hip_ctx *ctx, int n,
  * X_PACK / X_RLE depends on its own length, the device lays those regions out itself, and the host only has to bound
  * their total - total_in_size (encode: sum of d_in_size) / total_out_cap (decode: sum of d_out_cap over the blocks
  * that carry X_PACK or X_RLE; the sum over all blocks is a valid bound) instead of n x the largest block.  A batch of
- * 90,000 blocks of 4 KiB .. 1 MiB then takes a quarter of the workspace and is walked in one chunk.  0 = unknown
+ * 22,729 blocks of 4 KiB .. 1 MiB (4 GiB) then takes 29 GB of workspace instead of 62.  0 = unknown
  * (the plain calls above).  A batch that holds more than it announced fails the blocks that do not fit (UNSUPPORTED). */
 int rans4x16_hip_compress_dev_sized(rans4x16_hip_ctx *ctx, int n,
                                     const unsigned char *d_in, const uint64_t *d_in_off,
@@ -177,8 +177,8 @@ int rans4x16_hip_set_dev_stripe_planes(rans4x16_hip_ctx *ctx, int planes, unsign
  *   dec_mid               0     R4X16_DEC_MID            decode: mid rows (bucket index + one 16-byte window of cumulative values) for
  *                                                        batches of up to N rounds of sixteen streams per compute unit; 0 = never
  *                                                        (built and measured in round 4, slower than the packed rows on quality data: off)
- *   dec_short_ring        0     R4X16_DEC_SHORT_RING     decode: packed rows of 43..46 symbols with a 128-byte word ring and four-step trips,
- *                                                        sixteen streams per wave instead of fifteen (48 per compute unit)
+ *   dec_short_ring        0     R4X16_DEC_SHORT_RING     decode: packed rows of 43..44 symbols with a 128-byte word ring and four-step trips,
+ *                                                        sixteen streams per wave instead of fifteen (measured slower per round: off)
  *   sched_sort            1     R4X16_SCHED_SORT         chain kernels: streams of a class ordered by length, longest first
  *   sched_claim           1     R4X16_SCHED_CLAIM        chain kernels: shares claimed from a counter (0: fixed stride)
  *   sched_concurrent      1     R4X16_SCHED_CONCURRENT   chain kernels: the classes of a batch side by side on six streams,

@@ -5,6 +5,7 @@
 set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 GIB=${1:-3}; ORDER=${2:-1}
+cd $R
 python3 - "$GIB" <<'P'
 import sys, numpy as np
 sys.path.insert(0, sys.argv[0] if False else "tests")
