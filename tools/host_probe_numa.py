@@ -37,3 +37,15 @@ for name, call in (("plain", lambda bsz: L.rans4x16_hip_uncompress_batch(ctx.h, 
         ts.append(t1 - t0)
     print(f"{name}: decode GB/s per pass", [round(nblk * bs / t / 1e9, 1) for t in ts])
 assert (back == src).all()
+# alternating directions, as bench.py's host_path runs them: does a decode right after an encode pay for something?
+ts_e, ts_d = [], []
+for rep in range(4):
+    comp_sz = (C.c_uint * nblk)(*([cap] * nblk))
+    t0 = time.perf_counter(); rc = L.rans4x16_hip_compress_batch(ctx.h, nblk, in_p, in_sz, comp_p, comp_sz, ords, status); t1 = time.perf_counter()
+    assert rc == 0
+    bsz = (C.c_uint * nblk)(*([bs] * nblk))
+    t2 = time.perf_counter(); rc = L.rans4x16_hip_uncompress_batch(ctx.h, nblk, comp_p, comp_sz, back_p, bsz, status); t3 = time.perf_counter()
+    assert rc == 0
+    ts_e.append(t1 - t0); ts_d.append(t3 - t2)
+print("alternating: encode GB/s", [round(nblk * bs / t / 1e9, 1) for t in ts_e], "decode GB/s", [round(nblk * bs / t / 1e9, 1) for t in ts_d])
+print("workspace GB", round(L.rans4x16_hip_workspace_bytes(ctx.h) / 2**30, 2))
