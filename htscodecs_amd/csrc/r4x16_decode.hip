@@ -1794,7 +1794,9 @@ __global__ __launch_bounds__(WAVE) void k_dec_chain(const DecItem *items, DecDes
         // A per-stream stride of whole 128-byte lines puts every stream's table on the same banks (the 3,584 bytes of a
         // 46-symbol packed stream, layout 2, are 28 lines to the byte, and the wave's 42 LDS granules leave no byte to
         // skew them with): every other stream of such a class keeps its word ring in FRONT of its image, which shifts
-        // its tables by 272 bytes = 16 bytes mod 128.  Headline decode chain 93.4 -> 92.5 ms.
+        // its tables by 272 bytes = 16 bytes mod 128.  Headline decode chain 93.4 -> 92.5 ms.  (The short ring's 136 bytes
+        // would leave a flipped image 8 bytes off its 16-byte alignment: its class's stride, 3,360, is not a multiple of
+        // 128, so it never flips; a class that would has to keep a ring of a multiple of 16 bytes.)
         const u32 ringb = TRIP == 8 ? RING_BYTES : RING_BYTES_SHORT;
         const u32 flip_odd = (lds_per_item & 127u) == 0u ? 1u : 0u;
         // cooperative copy: the whole wave copies each quad's image in turn (16-byte pieces)
