@@ -342,7 +342,7 @@ def hetero_block(sizes, text, text_off, b):
     return np.ascontiguousarray(datagen.tile(HETERO_TEXTS[int(text[b])], int(sizes[b]), 0, offset=int(text_off[b])))
 
 
-def hetero_run(torch, H, dc, dev, total_bytes, uniform=None, reps=5, check=64, seed=2024, first_block=0, part=None):
+def hetero_run(torch, H, dc, dev, total_bytes, uniform=None, reps=8, check=64, seed=2024, first_block=0, part=None):
     """One heterogeneous (or comparison) batch through rans4x16_hip_{compress,uncompress}_dev with per-block orders:
     best-of-`reps` HIP-event times of each direction (every pass's time is in the result too: the context's shares settle
     over its first batches - option sched_learn - and the encoder's side-by-side classes vary by +-10 % from pass to pass),
@@ -764,6 +764,10 @@ def main():
             import gc
             gc.collect()
             torch.cuda.empty_cache()
+            if os.environ.get("BENCH_DEBUG"):
+                free, total = torch.cuda.mem_get_info()
+                print("before host_path: device memory free %.1f of %.1f GB; referrers of the codec: %s" % (
+                    free / 1e9, total / 1e9, [type(o).__name__ for o in gc.get_objects() if type(o).__name__ in ("DeviceCodec", "_Ctx")]), file=sys.stderr)
             out["host_path"] = host_path(H, args.data, bs, order)
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(order, bs, args.data)
