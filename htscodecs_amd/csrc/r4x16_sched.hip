@@ -69,7 +69,13 @@ __global__ __launch_bounds__(1024) void k_sched_scan(SchedWs w, SchedPlan plan)
             const u32 want = (n + qpw - 1u) / qpw;
             u32 s = want;
             if (fills > 1.f && tot > 0.f) {
-                s = (u32)ceilf(tq[q] / tot * (float)full);
+                // (a stream-queue with a small share - the queue of the batch's small classes, one after the other - gets
+                //  1.6 x its share: its classes then end well before the large ones instead of beside them, where their
+                //  swing - a dozen workgroups among thousands - decided when the batch ends.  Heterogeneous 16 GiB batch,
+                //  medians of six to eight passes, four alternations: encode 111 -> 103 ms, decode 91.3 -> 89.6)
+                float share = tq[q] / tot;
+                if (share < 0.2f) share *= 1.6f;
+                s = (u32)ceilf(share * (float)full);
                 if (s < 1u) s = 1u;
                 if (s > want) s = want;
             }
